@@ -1,0 +1,70 @@
+"""Builds airwave_amd/libairwave_hip.so for gfx950 with hipcc (no torch, no cmake).
+
+    python -m airwave_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the .so stays in-tree (git-ignored) so it travels with the
+repository snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libairwave_hip.so")
+OBJ = os.path.join(HERE, "_build")
+ARCH = "gfx950"
+
+SOURCES = [
+    "device/kernels.hip",
+    "runtime.cpp",
+    "host/tables.cpp",
+    "host/host_api.cpp",
+]
+HEADERS = [
+    "device/cplx.hpp", "device/tile_ols.hpp", "device/kernels.hpp", "runtime.hpp", "host/tables.hpp",
+    "../../include/airwave_hip.h",
+]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    common = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"--offload-arch={ARCH}",
+              "-Wall", "-Wno-unused-result", "-ffp-contract=fast"]
+    objs = []
+    for src in SOURCES:
+        spath = os.path.join(CSRC, src)
+        opath = os.path.join(OBJ, src.replace("/", "_") + ".o")
+        objs.append(opath)
+        if force or _stale(opath, [spath] + hdrs):
+            cmd = [hipcc()] + common + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", spath, "-o", opath]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+    if force or _stale(OUT, objs):
+        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

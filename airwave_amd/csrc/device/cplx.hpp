@@ -1,0 +1,118 @@
+// cplx.hpp — complex helpers and in-register radix-4/8/16 butterflies.
+//
+// Shared verbatim between the HIP kernels (hipcc, gfx950) and the CPU thread-emulation
+// harness under tests/emu/ (g++), so index math can be debugged without a GPU.
+// Everything is fully unrolled with compile-time indices so arrays stay in VGPRs.
+#pragma once
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define AW_HD __host__ __device__ __forceinline__
+#else
+#define AW_HD inline __attribute__((always_inline))
+#endif
+
+namespace awk {
+
+struct alignas(8) cf {
+    float x, y;
+};
+
+AW_HD cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
+AW_HD cf operator+(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
+AW_HD cf operator-(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
+AW_HD cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// a * conj(b)
+AW_HD cf cmulc(cf a, cf b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+AW_HD cf conj(cf a) { return mk(a.x, -a.y); }
+// acc + a*b
+AW_HD cf cfma(cf a, cf b, cf acc) {
+    return mk(acc.x + a.x * b.x - a.y * b.y, acc.y + a.x * b.y + a.y * b.x);
+}
+// acc + conj(a)*b
+AW_HD cf cfmac(cf a, cf b, cf acc) {
+    return mk(acc.x + a.x * b.x + a.y * b.y, acc.y + a.x * b.y - a.y * b.x);
+}
+// multiply by -i (forward quarter turn) or +i
+AW_HD cf mul_mi(cf a) { return mk(a.y, -a.x); }
+AW_HD cf mul_pi(cf a) { return mk(-a.y, a.x); }
+template <bool INV> AW_HD cf rot90(cf a) { return INV ? mul_pi(a) : mul_mi(a); }   // * W4^1
+// twiddle multiply: forward uses w, inverse uses conj(w)
+template <bool INV> AW_HD cf twmul(cf a, cf w) { return INV ? cmulc(a, w) : cmul(a, w); }
+
+constexpr float kS2 = 0.70710678118654752440f;   // cos(pi/4)
+constexpr float kC8 = 0.92387953251128675613f;   // cos(pi/8)
+constexpr float kS8 = 0.38268343236508977173f;   // sin(pi/8)
+
+// 4-point DFT, natural order in/out.  forward kernel e^{-2 pi i nk/4}.
+template <bool INV> AW_HD void fft4(cf &a0, cf &a1, cf &a2, cf &a3) {
+    const cf t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = rot90<INV>(a1 - a3);
+    a0 = t0 + t2; a1 = t1 + t3; a2 = t0 - t2; a3 = t1 - t3;
+}
+
+// multiply by W8^1 = (1 - i)/sqrt2 (forward) or its conjugate
+template <bool INV> AW_HD cf mul_w8_1(cf a) {
+    return INV ? mk((a.x - a.y) * kS2, (a.x + a.y) * kS2) : mk((a.x + a.y) * kS2, (a.y - a.x) * kS2);
+}
+// multiply by W8^3 = (-1 - i)/sqrt2 (forward) or its conjugate
+template <bool INV> AW_HD cf mul_w8_3(cf a) {
+    return INV ? mk((-a.x - a.y) * kS2, (a.x - a.y) * kS2) : mk((a.y - a.x) * kS2, (-a.x - a.y) * kS2);
+}
+
+// 8-point DFT, natural order in/out.
+template <bool INV> AW_HD void fft8(cf (&v)[8]) {
+    cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    cf o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    fft4<INV>(e0, e1, e2, e3);
+    fft4<INV>(o0, o1, o2, o3);
+    o1 = mul_w8_1<INV>(o1);
+    o2 = rot90<INV>(o2);
+    o3 = mul_w8_3<INV>(o3);
+    v[0] = e0 + o0; v[4] = e0 - o0;
+    v[1] = e1 + o1; v[5] = e1 - o1;
+    v[2] = e2 + o2; v[6] = e2 - o2;
+    v[3] = e3 + o3; v[7] = e3 - o3;
+}
+
+// multiply by W16^m (forward) / conj (inverse), m compile-time in {0,1,2,3,4,6,9}
+template <bool INV, int M> AW_HD cf mul_w16(cf a) {
+    if constexpr (M == 0) return a;
+    else if constexpr (M == 4) return rot90<INV>(a);
+    else if constexpr (M == 2) return mul_w8_1<INV>(a);
+    else if constexpr (M == 6) return mul_w8_3<INV>(a);
+    else {
+        // W16^1 = c - i s, W16^3 = s - i c, W16^9 = -c + i s   (c = cos(pi/8), s = sin(pi/8))
+        constexpr float wr = (M == 1) ? kC8 : (M == 3) ? kS8 : -kC8;
+        constexpr float wi_f = (M == 1) ? -kS8 : (M == 3) ? -kC8 : kS8;
+        const float wi = INV ? -wi_f : wi_f;
+        return mk(a.x * wr - a.y * wi, a.x * wi + a.y * wr);
+    }
+}
+
+// 16-point DFT, natural order in/out (4x4 decomposition).
+template <bool INV> AW_HD void fft16(cf (&v)[16]) {
+    // F_{n0}[k0] = fft4 over n1 of v[4 n1 + n0]
+    fft4<INV>(v[0], v[4], v[8], v[12]);
+    fft4<INV>(v[1], v[5], v[9], v[13]);
+    fft4<INV>(v[2], v[6], v[10], v[14]);
+    fft4<INV>(v[3], v[7], v[11], v[15]);
+    // now v[4 k0 + n0] holds F_{n0}[k0]; twiddle by W16^{n0 k0}
+    v[5] = mul_w16<INV, 1>(v[5]);  v[6] = mul_w16<INV, 2>(v[6]);   v[7] = mul_w16<INV, 3>(v[7]);
+    v[9] = mul_w16<INV, 2>(v[9]);  v[10] = mul_w16<INV, 4>(v[10]); v[11] = mul_w16<INV, 6>(v[11]);
+    v[13] = mul_w16<INV, 3>(v[13]); v[14] = mul_w16<INV, 6>(v[14]); v[15] = mul_w16<INV, 9>(v[15]);
+    // X[k0 + 4 k1] = fft4 over n0 of v[4 k0 + n0]  -> result index k1 lands in slot 4 k0 + k1
+    fft4<INV>(v[0], v[1], v[2], v[3]);
+    fft4<INV>(v[4], v[5], v[6], v[7]);
+    fft4<INV>(v[8], v[9], v[10], v[11]);
+    fft4<INV>(v[12], v[13], v[14], v[15]);
+    // slot 4 k0 + k1 holds X[k0 + 4 k1]: transpose to natural order
+    cf t;
+    t = v[1]; v[1] = v[4]; v[4] = t;
+    t = v[2]; v[2] = v[8]; v[8] = t;
+    t = v[3]; v[3] = v[12]; v[12] = t;
+    t = v[6]; v[6] = v[9]; v[9] = t;
+    t = v[7]; v[7] = v[13]; v[13] = t;
+    t = v[11]; v[11] = v[14]; v[14] = t;
+}
+
+}  // namespace awk

@@ -1,0 +1,150 @@
+// kernels.hip — gfx950 kernels of the batch HRIR spatializer.
+//
+// The tile body lives in tile_ols.hpp (shared with the CPU emulation harness); this file adds the
+// GPU execution context (LDS, barriers), the XCD-aware workgroup -> tile mapping and the small
+// utility kernels (history carry, synthetic fill, planar<->interleaved).
+#include "kernels.hpp"
+
+namespace awk {
+
+struct GpuCtx {
+    cf *lds_;
+    __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
+    __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
+    // wave id as a provably wave-uniform (SGPR) value: row bases become scalar
+    __device__ __forceinline__ int wave() const { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+    __device__ __forceinline__ cf *lds() const { return lds_; }
+    __device__ __forceinline__ void barrier() const { __syncthreads(); }
+    // Exchanges inside one wave need no s_barrier: a wave's LDS instructions execute in issue
+    // order.  The fences only stop the compiler from moving LDS accesses across the exchange.
+    __device__ __forceinline__ void wave_sync() const {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
+
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group).  Give
+// each XCD a contiguous run of tiles so that consecutive tiles of a stream, whose input windows
+// overlap by N - hop frames, share one L2 (MI355X_MICROARCH "Workgroup dispatch"; speed only).
+__device__ __forceinline__ long long xcd_remap(long long bid, long long nwg) {
+    const long long q = nwg / 8, r = nwg % 8;
+    const long long xcd = bid % 8, idx = bid / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int CS>
+__global__ void __launch_bounds__(kThreads) aw_fused_ols_kernel(TileParams p, long long nwg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GpuCtx ctx{reinterpret_cast<cf *>(smem)};
+    const long long id = xcd_remap((long long)blockIdx.x, nwg);
+    const long long stream = id / p.tiles_per_stream;
+    const int tile = (int)(id % p.tiles_per_stream);
+    tile_fused_ols<GpuCtx, CS>(ctx, p, stream, tile);
+}
+
+hipError_t prepare_kernels() {
+    hipError_t e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<0>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    return e;
+}
+
+const char *fused_ols_kernel_name(int n_channels) {
+    return n_channels == 8 ? "aw_fused_ols_kernel<8>" : n_channels == 2 ? "aw_fused_ols_kernel<2>" : "aw_fused_ols_kernel<0>";
+}
+
+hipError_t launch_fused_ols(const TileParams &p, int n_streams, hipStream_t stream) {
+    const long long nwg = (long long)n_streams * p.tiles_per_stream;
+    if (nwg <= 0) return hipSuccess;
+    if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)nwg), block(kThreads);
+    if (p.n_channels == 8)
+        hipLaunchKernelGGL(aw_fused_ols_kernel<8>, grid, block, kLdsBytes, stream, p, nwg);
+    else if (p.n_channels == 2)
+        hipLaunchKernelGGL(aw_fused_ols_kernel<2>, grid, block, kLdsBytes, stream, p, nwg);
+    else
+        hipLaunchKernelGGL(aw_fused_ols_kernel<0>, grid, block, kLdsBytes, stream, p, nwg);
+    return hipGetLastError();
+}
+
+// ---- history carry ---------------------------------------------------------------------------
+__global__ void aw_hist_update_kernel(const float *__restrict__ in, const float *__restrict__ hist_old,
+                                      float *__restrict__ hist_new, long long frames, int C, int hist_len) {
+    const long long s = blockIdx.y;
+    const long long per = (long long)hist_len * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long long)gridDim.x * blockDim.x) {
+        const long long fi = i / C;
+        const int ch = (int)(i - fi * C);
+        const long long f = frames - hist_len + fi;
+        const float v = f < 0 ? hist_old[s * per + (hist_len + f) * C + ch] : in[(s * frames + f) * C + ch];
+        hist_new[s * per + i] = v;
+    }
+}
+
+hipError_t launch_hist_update(const float *in, const float *hist_old, float *hist_new, long long frames,
+                              int n_channels, int hist_len, int n_streams, hipStream_t stream) {
+    if (hist_len <= 0 || n_streams <= 0) return hipSuccess;
+    const long long per = (long long)hist_len * n_channels;
+    unsigned gx = (unsigned)((per + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(aw_hist_update_kernel, dim3(gx, (unsigned)n_streams), dim3(256), 0, stream, in, hist_old,
+                       hist_new, frames, n_channels, hist_len);
+    return hipGetLastError();
+}
+
+// ---- synthetic input ------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void aw_synth_fill_kernel(float *__restrict__ dst, long long per_stream, unsigned long long seed,
+                                     unsigned long long first_stream) {
+    const unsigned long long s = blockIdx.y;
+    const unsigned long long key0 = (seed + first_stream + s) * 0x9E3779B97F4A7C15ull;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per_stream; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned top = (unsigned)(splitmix64(key0 + (unsigned long long)i) >> 40);
+        dst[s * per_stream + i] = (float)top * (1.0f / 16777216.0f) - 0.5f;
+    }
+}
+
+hipError_t launch_synth_fill(float *dst, int n_streams, long long per_stream, unsigned long long seed,
+                             unsigned long long first_stream, hipStream_t stream) {
+    if (n_streams <= 0 || per_stream <= 0) return hipSuccess;
+    long long gx = (per_stream + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(aw_synth_fill_kernel, dim3((unsigned)gx, (unsigned)n_streams), dim3(256), 0, stream, dst,
+                       per_stream, seed, first_stream);
+    return hipGetLastError();
+}
+
+// ---- planar <-> interleaved stereo (plugin-shaped entry) ---------------------------------------
+__global__ void aw_interleave2_kernel(const float *l, const float *r, float *dst, int frames) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < frames) { dst[2 * i] = l[i]; dst[2 * i + 1] = r[i]; }
+}
+__global__ void aw_deinterleave2_kernel(const float *src, float *l, float *r, int frames) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < frames) { l[i] = src[2 * i]; r[i] = src[2 * i + 1]; }
+}
+hipError_t launch_interleave2(const float *l, const float *r, float *dst, int frames, hipStream_t stream) {
+    if (frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aw_interleave2_kernel, dim3((frames + 255) / 256), dim3(256), 0, stream, l, r, dst, frames);
+    return hipGetLastError();
+}
+hipError_t launch_deinterleave2(const float *src, float *l, float *r, int frames, hipStream_t stream) {
+    if (frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aw_deinterleave2_kernel, dim3((frames + 255) / 256), dim3(256), 0, stream, src, l, r, frames);
+    return hipGetLastError();
+}
+
+}  // namespace awk

@@ -1,0 +1,30 @@
+// kernels.hpp — host-callable launchers for the HIP kernels (defined in kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "tile_ols.hpp"
+
+namespace awk {
+
+// Fused overlap-save spatializer: one workgroup per (stream, tile).  Returns hipSuccess or the
+// launch error.  `n_streams * p.tiles_per_stream` workgroups of kThreads.
+hipError_t launch_fused_ols(const TileParams &p, int n_streams, hipStream_t stream);
+const char *fused_ols_kernel_name(int n_channels);
+
+// hist_new[s][i][c] <- frame (frames - hist_len + i) of (hist_old ++ in), for every stream.
+hipError_t launch_hist_update(const float *in, const float *hist_old, float *hist_new, long long frames,
+                              int n_channels, int hist_len, int n_streams, hipStream_t stream);
+
+// dst[s][i] = U(-0.5,0.5) counter RNG (oracle/airwave_oracle.h: orc_synth_value)
+hipError_t launch_synth_fill(float *dst, int n_streams, long long per_stream, unsigned long long seed,
+                             unsigned long long first_stream, hipStream_t stream);
+
+// planar L/R (host layout staged on device) <-> interleaved helpers for the plugin-shaped entry
+hipError_t launch_interleave2(const float *left, const float *right, float *dst, int frames, hipStream_t stream);
+hipError_t launch_deinterleave2(const float *src, float *left, float *right, int frames, hipStream_t stream);
+
+hipError_t prepare_kernels();   // sets the dynamic-LDS attribute on every tile kernel (once)
+
+}  // namespace awk

@@ -1,0 +1,399 @@
+// host_api.cpp — host-side data model of the hot path behind the C ABI (no GPU needed):
+// WAVLoader, InputLayout, HRIRChannelMap, Resampler and the activatePreset assembly.
+// Native C++ equivalents of the reference's Swift types so the engine drops in.
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../runtime.hpp"
+
+using awr::fail;
+
+struct aw_wav {
+    double sample_rate = 0.0;
+    int channels = 0, frames = 0;
+    std::vector<float> planar;   // [channels][frames]
+};
+
+struct aw_layout {
+    std::vector<std::string> speakers;
+    std::string name;
+};
+
+struct aw_channel_map {
+    // insertion-ordered speaker -> (leftEar, rightEar); later setMapping overwrites (VirtualSpeaker.swift:110-112)
+    std::vector<std::string> keys;
+    std::map<std::string, std::pair<int, int>> idx;
+    void set(const std::string &s, int l, int r) {
+        if (!idx.count(s)) keys.push_back(s);
+        idx[s] = {l, r};
+    }
+};
+
+namespace {
+
+uint32_t rd32(const unsigned char *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint16_t rd16(const unsigned char *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+const char *const kLeftSide[] = {"FL", "BL", "SL", "TFL", "TBL", "FLC"};     // VirtualSpeaker.swift:143
+const char *const kRightSide[] = {"FR", "BR", "SR", "TFR", "TBR", "FRC"};    // :148
+bool in_set(const std::string &s, const char *const *set, int n) {
+    for (int i = 0; i < n; ++i)
+        if (s == set[i]) return true;
+    return false;
+}
+
+std::string trim_ws(const std::string &s) {   // .whitespaces: space and tab
+    size_t a = 0, b = s.size();
+    while (a < b && (s[a] == ' ' || s[a] == '\t')) ++a;
+    while (b > a && (s[b - 1] == ' ' || s[b - 1] == '\t')) --b;
+    return s.substr(a, b - a);
+}
+
+bool swift_int(const std::string &t, int *out) {   // Swift Int(String): optional sign + ASCII digits only
+    size_t i = 0;
+    if (i < t.size() && (t[i] == '+' || t[i] == '-')) ++i;
+    if (i >= t.size()) return false;
+    long long v = 0;
+    for (size_t j = i; j < t.size(); ++j) {
+        if (t[j] < '0' || t[j] > '9') return false;
+        v = v * 10 + (t[j] - '0');
+        if (v > 2147483647LL) return false;
+    }
+    *out = (int)(t[0] == '-' ? -v : v);
+    return true;
+}
+
+std::vector<std::string> split(const std::string &s, char sep) {
+    std::vector<std::string> out;
+    size_t start = 0;
+    for (;;) {
+        size_t p = s.find(sep, start);
+        if (p == std::string::npos) { out.push_back(s.substr(start)); break; }
+        out.push_back(s.substr(start, p - start));
+        start = p + 1;
+    }
+    return out;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* ---- WAVLoader.load (WAVLoader.swift:26-99) ------------------------------------------------------ */
+aw_status aw_wav_load(const char *path, aw_wav **out) {
+    if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (!path) return fail(AW_ERR_INVALID_ARGUMENT, "path is NULL");
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return fail(AW_ERR_WAV_FILE_READ, std::string("Failed to open WAV file: ") + path);
+    std::vector<unsigned char> b;
+    unsigned char chunk[65536];
+    size_t n;
+    while ((n = std::fread(chunk, 1, sizeof(chunk), f)) > 0) b.insert(b.end(), chunk, chunk + n);
+    std::fclose(f);
+    if (b.size() < 12 || std::memcmp(b.data(), "RIFF", 4) != 0 || std::memcmp(b.data() + 8, "WAVE", 4) != 0)
+        return fail(AW_ERR_WAV_FILE_READ, "Failed to open WAV file: not a RIFF/WAVE file");
+    const unsigned char *fmt = nullptr, *data = nullptr;
+    size_t fmt_len = 0, data_len = 0, pos = 12;
+    while (pos + 8 <= b.size()) {
+        const uint32_t sz = rd32(&b[pos + 4]);
+        const size_t avail = std::min<size_t>(sz, b.size() - pos - 8);
+        if (std::memcmp(&b[pos], "fmt ", 4) == 0) { fmt = &b[pos + 8]; fmt_len = avail; }
+        else if (std::memcmp(&b[pos], "data", 4) == 0) { data = &b[pos + 8]; data_len = avail; }
+        pos += 8 + (size_t)sz + (sz & 1u);
+    }
+    if (!fmt || !data || fmt_len < 16) return fail(AW_ERR_WAV_FILE_READ, "Failed to read audio data: missing fmt/data chunk");
+    int tag = rd16(fmt);
+    const int ch = rd16(fmt + 2);
+    const uint32_t rate = rd32(fmt + 4);
+    const int bits = rd16(fmt + 14);
+    if (tag == 0xFFFE && fmt_len >= 26) tag = rd16(fmt + 24);     // WAVE_FORMAT_EXTENSIBLE: SubFormat GUID's first word
+    if (ch <= 0) return fail(AW_ERR_INVALID_CHANNEL_COUNT, "Invalid channel count: " + std::to_string(ch));   // :40-42
+    const int bps = bits / 8;
+    const size_t frames = bps > 0 ? data_len / ((size_t)bps * ch) : 0;
+    if (frames == 0) return fail(AW_ERR_WAV_EMPTY_FILE, "WAV file is empty (0 frames)");                     // :44-46
+    const bool is_float = tag == 3, is_pcm = tag == 1;
+    if (!((is_float && (bits == 32 || bits == 64)) || (is_pcm && (bits == 8 || bits == 16 || bits == 24 || bits == 32))))
+        return fail(AW_ERR_WAV_UNSUPPORTED_FORMAT, "Unsupported WAV format");                                // :89-91
+    aw_wav *w = new (std::nothrow) aw_wav();
+    if (!w) return fail(AW_ERR_OUT_OF_MEMORY, "Failed to allocate audio buffer");                            // :49-54
+    w->sample_rate = (double)rate; w->channels = ch; w->frames = (int)frames;
+    w->planar.resize((size_t)ch * frames);
+    for (size_t i = 0; i < frames; ++i) {
+        for (int c = 0; c < ch; ++c) {
+            const unsigned char *p = data + (i * ch + c) * bps;
+            float v;
+            if (is_float && bits == 32) { uint32_t u = rd32(p); std::memcpy(&v, &u, 4); }
+            else if (is_float) { uint64_t u = (uint64_t)rd32(p) | ((uint64_t)rd32(p + 4) << 32); double d; std::memcpy(&d, &u, 8); v = (float)d; }
+            else if (bits == 16) v = (float)(int16_t)rd16(p) / 32768.0f;                                      // :77
+            else if (bits == 32) v = (float)((double)(int32_t)rd32(p) / 2147483648.0);                        // :86
+            else if (bits == 24) { int32_t s = (int32_t)(p[0] | (p[1] << 8) | (p[2] << 16)); if (s & 0x800000) s -= 0x1000000; v = (float)((double)s / 8388608.0); }
+            else v = ((float)p[0] - 128.0f) / 128.0f;
+            w->planar[(size_t)c * frames + i] = v;
+        }
+    }
+    *out = w;
+    return AW_OK;
+}
+void aw_wav_destroy(aw_wav *w) { delete w; }
+double aw_wav_sample_rate(const aw_wav *w) { return w ? w->sample_rate : 0.0; }
+int32_t aw_wav_channel_count(const aw_wav *w) { return w ? w->channels : 0; }
+int32_t aw_wav_frame_count(const aw_wav *w) { return w ? w->frames : 0; }
+const float *aw_wav_channel(const aw_wav *w, int32_t c) {
+    return (w && c >= 0 && c < w->channels) ? w->planar.data() + (size_t)c * w->frames : nullptr;
+}
+const float *aw_wav_planar(const aw_wav *w) { return w ? w->planar.data() : nullptr; }
+
+/* ---- InputLayout (VirtualSpeaker.swift:59-100) ---------------------------------------------------- */
+aw_status aw_layout_detect(int32_t n, aw_layout **out) {
+    if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (n < 0) return fail(AW_ERR_INVALID_ARGUMENT, "negative channel count");
+    aw_layout *l = new (std::nothrow) aw_layout();
+    if (!l) return fail(AW_ERR_OUT_OF_MEMORY, "layout");
+    switch (n) {                                                               // :88-99
+        case 2: l->speakers = {"FL", "FR"}; l->name = "Stereo"; break;
+        case 6: l->speakers = {"FL", "FR", "FC", "LFE", "BL", "BR"}; l->name = "5.1 Surround"; break;
+        case 8: l->speakers = {"FL", "FR", "FC", "LFE", "BL", "BR", "SL", "SR"}; l->name = "7.1 Surround"; break;
+        case 12: l->speakers = {"FL", "FR", "FC", "LFE", "BL", "BR", "SL", "SR", "TFL", "TFR", "TBL", "TBR"}; l->name = "7.1.4 Atmos"; break;
+        default:
+            for (int i = 0; i < n; ++i) l->speakers.push_back("Ch" + std::to_string(i));
+            l->name = std::to_string(n) + " Channel";
+    }
+    *out = l;
+    return AW_OK;
+}
+aw_status aw_layout_create(const char *const *names, int32_t count, const char *name, aw_layout **out) {
+    if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (count < 0 || (count > 0 && !names)) return fail(AW_ERR_INVALID_ARGUMENT, "bad speaker list");
+    aw_layout *l = new (std::nothrow) aw_layout();
+    if (!l) return fail(AW_ERR_OUT_OF_MEMORY, "layout");
+    for (int i = 0; i < count; ++i) {
+        if (!names[i]) { delete l; return fail(AW_ERR_INVALID_ARGUMENT, "NULL speaker name"); }
+        l->speakers.emplace_back(names[i]);
+    }
+    l->name = name ? name : "";
+    *out = l;
+    return AW_OK;
+}
+void aw_layout_destroy(aw_layout *l) { delete l; }
+int32_t aw_layout_count(const aw_layout *l) { return l ? (int32_t)l->speakers.size() : 0; }
+const char *aw_layout_speaker(const aw_layout *l, int32_t i) {
+    return (l && i >= 0 && i < (int32_t)l->speakers.size()) ? l->speakers[(size_t)i].c_str() : nullptr;
+}
+const char *aw_layout_name(const aw_layout *l) { return l ? l->name.c_str() : nullptr; }
+
+/* ---- HRIRChannelMap (VirtualSpeaker.swift:103-347) -------------------------------------------------- */
+static aw_status map_new(aw_channel_map **out, aw_channel_map **m) {
+    if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    *m = new (std::nothrow) aw_channel_map();
+    if (!*m) return fail(AW_ERR_OUT_OF_MEMORY, "channel map");
+    return AW_OK;
+}
+
+aw_status aw_map_hesuvi14(const aw_layout *spk, aw_channel_map **out) {       // :270-297
+    aw_channel_map *m;
+    aw_status st = map_new(out, &m);
+    if (st != AW_OK) return st;
+    if (!spk) { delete m; return fail(AW_ERR_INVALID_ARGUMENT, "speakers is NULL"); }
+    static const struct { const char *s; int l, r; } T[] = {{"FL", 0, 1}, {"FR", 8, 7}, {"FC", 6, 13}, {"LFE", 6, 13},
+                                                             {"BL", 4, 5}, {"BR", 12, 11}, {"SL", 2, 3}, {"SR", 10, 9}};
+    for (const auto &s : spk->speakers)
+        for (const auto &t : T)
+            if (s == t.s) m->set(s, t.l, t.r);
+    *out = m;
+    return AW_OK;
+}
+
+aw_status aw_map_hesuvi7(const aw_layout *spk, aw_channel_map **out) {        // :224-250
+    aw_channel_map *m;
+    aw_status st = map_new(out, &m);
+    if (st != AW_OK) return st;
+    if (!spk) { delete m; return fail(AW_ERR_INVALID_ARGUMENT, "speakers is NULL"); }
+    static const struct { const char *s; int l, r; } T[] = {{"FL", 0, 1}, {"FR", 1, 0}, {"FC", 2, 2}, {"LFE", 2, 2},
+                                                             {"BL", 3, 4}, {"BR", 4, 3}, {"SL", 5, 6}, {"SR", 6, 5}};
+    for (const auto &s : spk->speakers)
+        for (const auto &t : T)
+            if (s == t.s) m->set(s, t.l, t.r);
+    *out = m;
+    return AW_OK;
+}
+
+aw_status aw_map_interleaved_pairs(const aw_layout *spk, aw_channel_map **out) {   // :126-159
+    aw_channel_map *m;
+    aw_status st = map_new(out, &m);
+    if (st != AW_OK) return st;
+    if (!spk) { delete m; return fail(AW_ERR_INVALID_ARGUMENT, "speakers is NULL"); }
+    for (size_t i = 0; i < spk->speakers.size(); ++i) {
+        const int base = (int)i * 2;
+        const std::string &s = spk->speakers[i];
+        if (in_set(s, kRightSide, 6)) m->set(s, base + 1, base);               // right side: pair swapped
+        else m->set(s, base, base + 1);                                          // left side and centre speakers
+        (void)kLeftSide;
+    }
+    *out = m;
+    return AW_OK;
+}
+
+aw_status aw_map_split_blocks(const aw_layout *spk, aw_channel_map **out) {    // :200-209
+    aw_channel_map *m;
+    aw_status st = map_new(out, &m);
+    if (st != AW_OK) return st;
+    if (!spk) { delete m; return fail(AW_ERR_INVALID_ARGUMENT, "speakers is NULL"); }
+    const int n = (int)spk->speakers.size();
+    for (int i = 0; i < n; ++i) m->set(spk->speakers[(size_t)i], i, i + n);
+    *out = m;
+    return AW_OK;
+}
+
+aw_status aw_map_parse_text(const char *text, aw_channel_map **out) {          // parseHeSuViFormat :301-346
+    aw_channel_map *m;
+    aw_status st = map_new(out, &m);
+    if (st != AW_OK) return st;
+    if (!text) { delete m; return fail(AW_ERR_INVALID_ARGUMENT, "text is NULL"); }
+    std::string t(text), norm;
+    for (size_t i = 0; i < t.size(); ++i) {       // .newlines: \n, \r\n, \r
+        if (t[i] == '\r') { norm.push_back('\n'); if (i + 1 < t.size() && t[i + 1] == '\n') ++i; }
+        else norm.push_back(t[i]);
+    }
+    static const struct { const char *alias; const char *spk; } A[] = {
+        {"FL", "FL"}, {"L", "FL"}, {"FR", "FR"}, {"R", "FR"}, {"FC", "FC"}, {"C", "FC"}, {"LFE", "LFE"}, {"SUB", "LFE"},
+        {"BL", "BL"}, {"RL", "BL"}, {"BR", "BR"}, {"RR", "BR"}, {"SL", "SL"}, {"SR", "SR"}, {"TFL", "TFL"},
+        {"TFR", "TFR"}, {"TBL", "TBL"}, {"TBR", "TBR"}};
+    for (const std::string &raw : split(norm, '\n')) {
+        const std::string line = trim_ws(raw);
+        if (line.empty() || line[0] == '#' || line[0] == ';') continue;        // :308-311
+        const auto parts = split(line, '=');
+        if (parts.size() != 2) continue;                                         // :315
+        const std::string name = trim_ws(parts[0]);
+        std::vector<int> idx;
+        for (const std::string &tok : split(trim_ws(parts[1]), ',')) {
+            int v;
+            if (swift_int(trim_ws(tok), &v)) idx.push_back(v);                    // compactMap { Int(...) }  :320
+        }
+        if (idx.size() != 2) continue;                                           // :322
+        std::string upper = name;
+        for (auto &ch : upper) ch = (char)std::toupper((unsigned char)ch);
+        std::string speaker = name;                                              // default: .custom(speakerName)  :339
+        for (const auto &a : A)
+            if (upper == a.alias) { speaker = a.spk; break; }
+        m->set(speaker, idx[0], idx[1]);
+    }
+    *out = m;
+    return AW_OK;
+}
+
+void aw_map_destroy(aw_channel_map *m) { delete m; }
+int32_t aw_map_count(const aw_channel_map *m) { return m ? (int32_t)m->keys.size() : 0; }
+int32_t aw_map_get(const aw_channel_map *m, const char *speaker, int32_t *l, int32_t *r) {
+    if (!m || !speaker) return 0;
+    auto it = m->idx.find(speaker);
+    if (it == m->idx.end()) return 0;
+    if (l) *l = it->second.first;
+    if (r) *r = it->second.second;
+    return 1;
+}
+
+aw_status aw_map_resolve(const aw_channel_map *m, const aw_layout *layout, int32_t n_tracks, int32_t *left,
+                         int32_t *right) {
+    if (!m || !layout || !left || !right) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    int mapped = 0;
+    for (size_t i = 0; i < layout->speakers.size(); ++i) {
+        left[i] = right[i] = -1;
+        auto it = m->idx.find(layout->speakers[i]);
+        if (it == m->idx.end()) continue;                                        // HRIRManager.swift:370-372
+        const int l = it->second.first, r = it->second.second;
+        if (!(l < n_tracks && r < n_tracks) || l < 0 || r < 0)                   // :375-379
+            return fail(AW_ERR_INVALID_CHANNEL_MAPPING, "HRIR indices (" + std::to_string(l) + ", " + std::to_string(r) +
+                                                            ") out of range for " + std::to_string(n_tracks) + " channels");
+        left[i] = l; right[i] = r;
+        ++mapped;
+    }
+    if (mapped == 0) return fail(AW_ERR_CONVOLUTION_SETUP_FAILED, "No valid renderers created");   // :420-422
+    return AW_OK;
+}
+
+/* ---- Resampler (Resampler.swift:31-68) -------------------------------------------------------------- */
+int32_t aw_resample_output_count(int32_t count, double from_rate, double to_rate) {
+    if (std::fabs(from_rate - to_rate) < 0.01) return count;                   // :33-35
+    const double stride = from_rate / to_rate;                                  // :37
+    return (int32_t)((double)count / stride);                                   // :38
+}
+
+aw_status aw_resample(const float *input, int32_t count, double from_rate, double to_rate, float *output,
+                      int32_t capacity, int32_t *output_count) {
+    if (!input || !output || !output_count || count < 0) return fail(AW_ERR_INVALID_ARGUMENT, "bad argument");
+    const int n_out = aw_resample_output_count(count, from_rate, to_rate);
+    *output_count = n_out > 0 ? n_out : 0;
+    if (n_out <= 0) return AW_OK;                                               // guard outputCount > 0 else { return [] }
+    if (capacity < n_out) return fail(AW_ERR_INVALID_ARGUMENT, "output capacity too small");
+    if (std::fabs(from_rate - to_rate) < 0.01) { std::memcpy(output, input, sizeof(float) * (size_t)count); return AW_OK; }
+    const float step = (float)(from_rate / to_rate);                            // var step: Float = Float(stride)  :55
+    for (int i = 0; i < n_out; ++i) {
+        const float pos = (float)i * step;                                      // vDSP_vramp(start 0, step)  :56
+        long long i0 = (long long)std::floor(pos);
+        const float frac = pos - (float)i0;
+        long long a = std::min<long long>(i0, count - 1), b = std::min<long long>(i0 + 1, count - 1);
+        output[i] = input[a] + frac * (input[b] - input[a]);
+    }
+    return AW_OK;
+}
+
+/* ---- HRIRManager.activatePreset (HRIRManager.swift:347-446) ------------------------------------------ */
+aw_status aw_preset_activate(aw_context *ctx, const char *wav_path, double target_rate, const aw_layout *layout,
+                             const aw_channel_map *custom_map, int32_t n_streams, aw_spatializer **sp_out,
+                             aw_hrir **hrir_out) {
+    if (!sp_out) return fail(AW_ERR_INVALID_ARGUMENT, "spatializer_out is NULL");
+    *sp_out = nullptr;
+    if (hrir_out) *hrir_out = nullptr;
+    if (!ctx || !wav_path || !layout) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    aw_wav *wav = nullptr;
+    aw_status st = aw_wav_load(wav_path, &wav);                                  // :349
+    if (st != AW_OK) return st;
+    aw_channel_map *own = nullptr;
+    const aw_channel_map *map = custom_map;
+    if (!map) {                                                                   // :355-360
+        st = wav->channels == 7 ? aw_map_hesuvi7(layout, &own) : aw_map_hesuvi14(layout, &own);
+        if (st != AW_OK) { aw_wav_destroy(wav); return st; }
+        map = own;
+    }
+    const int C = (int)layout->speakers.size();
+    std::vector<int32_t> lt((size_t)std::max(C, 1)), rt((size_t)std::max(C, 1));
+    st = aw_map_resolve(map, layout, wav->channels, lt.data(), rt.data());        // :366-379, :420-422
+    aw_map_destroy(own);
+    if (st != AW_OK) { aw_wav_destroy(wav); return st; }
+    std::vector<float> tracks;
+    int taps = wav->frames;
+    if (target_rate > 0.0 && std::fabs(wav->sample_rate - target_rate) > 0.01) {  // :389-403
+        taps = aw_resample_output_count(wav->frames, wav->sample_rate, target_rate);
+        if (taps <= 0) { aw_wav_destroy(wav); return fail(AW_ERR_CONVOLUTION_SETUP_FAILED, "resampled HRIR is empty"); }
+        tracks.resize((size_t)wav->channels * taps);
+        for (int c = 0; c < wav->channels; ++c) {
+            int n = 0;
+            st = aw_resample(aw_wav_channel(wav, c), wav->frames, wav->sample_rate, target_rate,
+                             tracks.data() + (size_t)c * taps, taps, &n);
+            if (st != AW_OK) { aw_wav_destroy(wav); return st; }
+        }
+    } else {
+        tracks = wav->planar;
+    }
+    aw_hrir *hrir = nullptr;
+    st = aw_hrir_create(ctx, tracks.data(), wav->channels, taps, target_rate > 0.0 ? target_rate : wav->sample_rate, &hrir);
+    aw_wav_destroy(wav);
+    if (st != AW_OK) return st;
+    st = aw_spatializer_create(ctx, hrir, C, lt.data(), rt.data(), n_streams, 0, sp_out);   // :406-418
+    if (st != AW_OK || !hrir_out) aw_hrir_destroy(hrir);
+    else *hrir_out = hrir;
+    return st;
+}
+
+}  // extern "C"

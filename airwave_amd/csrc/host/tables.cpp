@@ -1,0 +1,87 @@
+#include "tables.hpp"
+
+#include <cmath>
+#include <complex>
+
+namespace awh {
+
+using cd = std::complex<double>;
+
+static void fft_inplace(std::vector<cd> &a) {
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const double ang = -2.0 * M_PI / (double)len;
+        for (size_t i = 0; i < n; i += len) {
+            for (size_t k = 0; k < len / 2; ++k) {
+                const cd w(std::cos(ang * (double)k), std::sin(ang * (double)k));
+                const cd u = a[i + k], v = a[i + k + len / 2] * w;
+                a[i + k] = u + v;
+                a[i + k + len / 2] = u - v;
+            }
+        }
+    }
+}
+
+static awk::cf unit(double num, double den) {   // exp(-2 pi i num / den)
+    const double a = -2.0 * M_PI * num / den;
+    return awk::mk((float)std::cos(a), (float)std::sin(a));
+}
+
+void build_twiddles(Twiddles &tw) {
+    tw.tw1.resize(512 * 16);
+    for (int t = 0; t < 512; ++t)
+        for (int k1 = 0; k1 < 16; ++k1) tw.tw1[t * 16 + k1] = unit((double)t * k1, awk::kN);
+    tw.twa.resize(64 * 8);
+    for (int l = 0; l < 64; ++l)
+        for (int ka = 0; ka < 8; ++ka) tw.twa[l * 8 + ka] = unit((double)l * ka, 512.0);
+    tw.twb.resize(8 * 8);
+    for (int l0 = 0; l0 < 8; ++l0)
+        for (int kb = 0; kb < 8; ++kb) tw.twb[l0 * 8 + kb] = unit((double)l0 * kb, 64.0);
+}
+
+void build_pair_tables(const float *tracks, int n_tracks, int taps, int n_channels,
+                       const int32_t *left_track, const int32_t *right_track, int tap_offset,
+                       int tap_count, std::vector<awk::cf2> &out) {
+    const int N = awk::kN;
+    const int n_pairs = (n_channels + 1) / 2;
+    out.assign((size_t)n_pairs * N, awk::cf2{awk::mk(0, 0), awk::mk(0, 0)});
+    const double scale = 1.0 / (2.0 * (double)N);
+    std::vector<cd> zl(N), zr(N);
+    auto tap = [&](int track, int i) -> double {
+        if (track < 0 || track >= n_tracks) return 0.0;
+        const int idx = tap_offset + i;
+        return (idx < taps && i < tap_count) ? (double)tracks[(size_t)track * taps + idx] : 0.0;
+    };
+    for (int p = 0; p < n_pairs; ++p) {
+        const int a = 2 * p, b = 2 * p + 1;
+        const int la = left_track[a], ra = right_track[a];
+        const int lb = b < n_channels ? left_track[b] : -1, rb = b < n_channels ? right_track[b] : -1;
+        // a channel is rendered only when BOTH ears are mapped (the reference looks up a pair or skips)
+        const bool use_a = la >= 0 && ra >= 0, use_b = lb >= 0 && rb >= 0;
+        for (int i = 0; i < N; ++i) {
+            zl[i] = cd(use_a ? tap(la, i) : 0.0, use_b ? tap(lb, i) : 0.0);   // h_aL + i h_bL
+            zr[i] = cd(use_a ? tap(ra, i) : 0.0, use_b ? tap(rb, i) : 0.0);   // h_aR + i h_bR
+        }
+        fft_inplace(zl);
+        fft_inplace(zr);
+        const cd I(0.0, 1.0);
+        for (int k = 0; k < N; ++k) {
+            const int nk = (N - k) & (N - 1);
+            const cd g1l = std::conj(zl[nk]) * scale, g1r = std::conj(zr[nk]) * scale;   // (H_a - i H_b)/(2N)
+            const cd g2l = zl[k] * scale, g2r = zr[k] * scale;                             // (H_a + i H_b)/(2N)
+            const cd A = g1l + I * g1r, B = g2l + I * g2r;
+            const int k1 = k & 15, k2 = k >> 4;
+            awk::cf2 &e = out[(size_t)p * N + (size_t)k1 * awk::kSub + k2];
+            e.a = awk::mk((float)A.real(), (float)A.imag());
+            e.b = awk::mk((float)B.real(), (float)B.imag());
+        }
+    }
+}
+
+}  // namespace awh

@@ -1,0 +1,28 @@
+// tables.hpp — host-side (double precision) preparation of the frequency-domain filter tables
+// and twiddles consumed by the tile kernels.  This is the MI355X analogue of the per-engine
+// HRIR partition FFTs in ConvolutionEngine.init (Airwave/ConvolutionEngine.swift:141-175) and of
+// FFTSetupManager's twiddle cache (Airwave/FFTSetupManager.swift:41-60): computed once per
+// spatializer, shared by every stream.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../device/tile_ols.hpp"
+
+namespace awh {
+
+// Per-thread / per-lane twiddle rows (see TileParams): tw1[512][16], twa[64][8], twb[8][8].
+struct Twiddles {
+    std::vector<awk::cf> tw1, twa, twb;
+};
+void build_twiddles(Twiddles &tw);
+
+// Tables for taps [tap_offset, tap_offset + tap_count) of every (pair, ear) filter, laid out
+// [pair][k1][k2] with k = k1 + 16 k2 (see tile_ols.hpp).  Channels whose track index is < 0
+// contribute a zero filter (skipped speakers, HRIRManager.swift:370-372).  `scale` is folded
+// into the tables (1/N for the inverse transform).
+void build_pair_tables(const float *tracks, int n_tracks, int taps, int n_channels,
+                       const int32_t *left_track, const int32_t *right_track, int tap_offset,
+                       int tap_count, std::vector<awk::cf2> &out);
+
+}  // namespace awh

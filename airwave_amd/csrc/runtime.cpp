@@ -1,0 +1,581 @@
+// runtime.cpp — device-side objects of the C ABI: context, HRIR set, batch spatializer, the mono
+// engine trio and the callback-size adapter.  Compiled by hipcc as host C++.
+#include "runtime.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "host/tables.hpp"
+
+namespace awr {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+aw_status fail(aw_status code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+aw_status hip_fail(hipError_t e, const char *what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? AW_ERR_OUT_OF_MEMORY : AW_ERR_HIP;
+}
+
+}  // namespace awr
+
+using awr::fail;
+
+extern "C" {
+
+const char *aw_version(void) { return "airwave-hip 0.1 (gfx950)"; }
+
+const char *aw_last_error_message(void) { return awr::g_last_error.c_str(); }
+
+const char *aw_status_string(aw_status s) {
+    switch (s) {
+        case AW_OK: return "ok";
+        case AW_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case AW_ERR_OUT_OF_MEMORY: return "out of memory";
+        case AW_ERR_HIP: return "HIP runtime error";
+        case AW_ERR_NO_DEVICE: return "no HIP device";
+        case AW_ERR_INVALID_CHANNEL_MAPPING: return "Invalid channel mapping";            // HRIRManager.swift:754
+        case AW_ERR_CONVOLUTION_SETUP_FAILED: return "Failed to set up convolution";      // :752
+        case AW_ERR_INVALID_CHANNEL_COUNT: return "Invalid channel count";                // :748, WAVLoader.swift:137
+        case AW_ERR_WAV_FILE_READ: return "WAV file read error";                          // WAVLoader.swift:135
+        case AW_ERR_WAV_EMPTY_FILE: return "WAV file is empty (0 frames)";                // :139
+        case AW_ERR_WAV_UNSUPPORTED_FORMAT: return "Unsupported WAV format";              // :143
+        case AW_ERR_BLOCK_SIZE_MISMATCH: return "frame count differs from the engine block size";
+        default: return "unknown status";
+    }
+}
+
+/* ---- context ------------------------------------------------------------------------------ */
+static aw_status context_create_impl(int32_t device, void *ext_stream, bool use_ext, aw_context **out) {
+    if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(AW_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= count) return fail(AW_ERR_NO_DEVICE, "device ordinal out of range");
+    AW_HIP_TRY(hipSetDevice(device));
+    aw_context *c = new (std::nothrow) aw_context();
+    if (!c) return fail(AW_ERR_OUT_OF_MEMORY, "context");
+    c->device = device;
+    if (use_ext) {
+        c->stream = reinterpret_cast<hipStream_t>(ext_stream);
+        c->owns_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return awr::hip_fail(e, "hipStreamCreate"); }
+        c->owns_stream = true;
+    }
+    hipError_t e = hipEventCreate(&c->t0);
+    if (e == hipSuccess) e = hipEventCreate(&c->t1);
+    if (e == hipSuccess) e = awk::prepare_kernels();
+    awh::Twiddles tw;
+    awh::build_twiddles(tw);
+    auto upload = [&](const std::vector<awk::cf> &v, awk::cf **d) -> hipError_t {
+        hipError_t r = hipMalloc(reinterpret_cast<void **>(d), v.size() * sizeof(awk::cf));
+        if (r != hipSuccess) return r;
+        return hipMemcpy(*d, v.data(), v.size() * sizeof(awk::cf), hipMemcpyHostToDevice);
+    };
+    if (e == hipSuccess) e = upload(tw.tw1, &c->d_tw1);
+    if (e == hipSuccess) e = upload(tw.twa, &c->d_twa);
+    if (e == hipSuccess) e = upload(tw.twb, &c->d_twb);
+    if (e != hipSuccess) {
+        aw_context_destroy(c);
+        return awr::hip_fail(e, "context setup");
+    }
+    *out = c;
+    return AW_OK;
+}
+
+aw_status aw_context_create(int32_t device, aw_context **out) { return context_create_impl(device, nullptr, false, out); }
+aw_status aw_context_create_on_stream(int32_t device, void *hip_stream, aw_context **out) {
+    return context_create_impl(device, hip_stream, true, out);
+}
+
+void aw_context_destroy(aw_context *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_tw1) (void)hipFree(c->d_tw1);
+    if (c->d_twa) (void)hipFree(c->d_twa);
+    if (c->d_twb) (void)hipFree(c->d_twb);
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+aw_status aw_context_synchronize(aw_context *c) {
+    if (!c) return fail(AW_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    AW_HIP_TRY(hipStreamSynchronize(c->stream));
+    return AW_OK;
+}
+
+void *aw_context_stream(aw_context *c) { return c ? reinterpret_cast<void *>(c->stream) : nullptr; }
+
+aw_status aw_context_timer_start(aw_context *c) {
+    if (!c) return fail(AW_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    AW_HIP_TRY(hipEventRecord(c->t0, c->stream));
+    return AW_OK;
+}
+
+aw_status aw_context_timer_stop(aw_context *c, float *ms) {
+    if (!c || !ms) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    AW_HIP_TRY(hipEventRecord(c->t1, c->stream));
+    AW_HIP_TRY(hipEventSynchronize(c->t1));
+    AW_HIP_TRY(hipEventElapsedTime(ms, c->t0, c->t1));
+    return AW_OK;
+}
+
+aw_status aw_device_alloc(aw_context *c, size_t bytes, void **dptr) {
+    if (!c || !dptr) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    AW_HIP_TRY(hipSetDevice(c->device));
+    AW_HIP_TRY(hipMalloc(dptr, bytes ? bytes : 1));
+    return AW_OK;
+}
+aw_status aw_device_free(aw_context *c, void *dptr) {
+    if (!c) return fail(AW_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (dptr) AW_HIP_TRY(hipFree(dptr));
+    return AW_OK;
+}
+aw_status aw_memcpy_h2d(aw_context *c, void *dst, const void *src, size_t bytes) {
+    if (!c || (bytes && (!dst || !src))) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    AW_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    AW_HIP_TRY(hipStreamSynchronize(c->stream));
+    return AW_OK;
+}
+aw_status aw_memcpy_d2h(aw_context *c, void *dst, const void *src, size_t bytes) {
+    if (!c || (bytes && (!dst || !src))) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    AW_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    AW_HIP_TRY(hipStreamSynchronize(c->stream));
+    return AW_OK;
+}
+
+/* ---- HRIR set ------------------------------------------------------------------------------- */
+aw_status aw_hrir_create(aw_context *ctx, const float *tracks, int32_t n_tracks, int32_t taps, double sample_rate,
+                         aw_hrir **out) {
+    if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (!ctx || !tracks) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_tracks <= 0) return fail(AW_ERR_INVALID_CHANNEL_COUNT, "HRIR needs at least one track");
+    if (taps <= 0) return fail(AW_ERR_WAV_EMPTY_FILE, "HRIR has no taps");
+    aw_hrir *h = new (std::nothrow) aw_hrir();
+    if (!h) return fail(AW_ERR_OUT_OF_MEMORY, "hrir");
+    h->ctx = ctx; h->n_tracks = n_tracks; h->taps = taps; h->sample_rate = sample_rate;
+    h->tracks.assign(tracks, tracks + (size_t)n_tracks * taps);
+    *out = h;
+    return AW_OK;
+}
+void aw_hrir_destroy(aw_hrir *h) { delete h; }
+int32_t aw_hrir_track_count(const aw_hrir *h) { return h ? h->n_tracks : 0; }
+int32_t aw_hrir_taps(const aw_hrir *h) { return h ? h->taps : 0; }
+double aw_hrir_sample_rate(const aw_hrir *h) { return h ? h->sample_rate : 0.0; }
+
+/* ---- spatializer ---------------------------------------------------------------------------- */
+static aw_status sp_alloc_hist(aw_spatializer *sp) {
+    const size_t n = (size_t)sp->n_streams * sp->hist_len * sp->n_channels;
+    for (int i = 0; i < 2; ++i) {
+        AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sp->d_hist[i]), std::max<size_t>(n, 1) * sizeof(float)));
+        AW_HIP_TRY(hipMemsetAsync(sp->d_hist[i], 0, std::max<size_t>(n, 1) * sizeof(float), sp->ctx->stream));
+    }
+    sp->hist_cur = 0;
+    return AW_OK;
+}
+
+aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_in, const int32_t *left_track,
+                                const int32_t *right_track, int32_t n_streams, int32_t block_hint,
+                                aw_spatializer **out) {
+    (void)block_hint;
+    if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (!ctx || !hrir || !left_track || !right_track) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_in <= 0 || n_streams <= 0) return fail(AW_ERR_INVALID_ARGUMENT, "channel and stream counts must be positive");
+    // the per-speaker loop of activatePreset: skip unmapped, bounds-check, need >= 1 renderer
+    int mapped = 0;
+    for (int c = 0; c < n_in; ++c) {
+        const int l = left_track[c], r = right_track[c];
+        if (l < 0 || r < 0) continue;                                        // HRIRManager.swift:370-372
+        if (l >= hrir->n_tracks || r >= hrir->n_tracks)                      // :375-379
+            return fail(AW_ERR_INVALID_CHANNEL_MAPPING,
+                        "HRIR indices (" + std::to_string(l) + ", " + std::to_string(r) + ") out of range for " +
+                            std::to_string(hrir->n_tracks) + " channels");
+        ++mapped;
+    }
+    if (mapped == 0) return fail(AW_ERR_CONVOLUTION_SETUP_FAILED, "No valid renderers created");   // :420-422
+    AW_HIP_TRY(hipSetDevice(ctx->device));
+
+    aw_spatializer *sp = new (std::nothrow) aw_spatializer();
+    if (!sp) return fail(AW_ERR_OUT_OF_MEMORY, "spatializer");
+    sp->ctx = ctx; sp->n_channels = n_in; sp->n_pairs = (n_in + 1) / 2; sp->n_streams = n_streams;
+    sp->taps = hrir->taps;
+    const int N = awk::kN;
+    if (hrir->taps - 1 <= N - 2048) {
+        sp->path = 0;
+        sp->hop = N - (hrir->taps - 1);
+        sp->hist_len = N - sp->hop;
+        sp->partitions = 1;
+    } else {
+        sp->path = 1;
+        sp->hop = N / 2;
+        sp->partitions = (hrir->taps + sp->hop - 1) / sp->hop;
+        sp->hist_len = sp->partitions * sp->hop;
+    }
+    std::vector<awk::cf2> tab, all;
+    for (int q = 0; q < sp->partitions; ++q) {
+        const int off = sp->path == 0 ? 0 : q * sp->hop;
+        const int cnt = sp->path == 0 ? hrir->taps : sp->hop;
+        awh::build_pair_tables(hrir->tracks.data(), hrir->n_tracks, hrir->taps, n_in, left_track, right_track, off,
+                               cnt, tab);
+        all.insert(all.end(), tab.begin(), tab.end());
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&sp->d_tab), all.size() * sizeof(awk::cf2));
+    if (e == hipSuccess) e = hipMemcpy(sp->d_tab, all.data(), all.size() * sizeof(awk::cf2), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { aw_spatializer_destroy(sp); return awr::hip_fail(e, "filter tables"); }
+    aw_status st = sp_alloc_hist(sp);
+    if (st != AW_OK) { aw_spatializer_destroy(sp); return st; }
+    e = hipEventCreate(&sp->k0);
+    if (e == hipSuccess) e = hipEventCreate(&sp->k1);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { aw_spatializer_destroy(sp); return awr::hip_fail(e, "spatializer setup"); }
+    *out = sp;
+    return AW_OK;
+}
+
+void aw_spatializer_destroy(aw_spatializer *sp) {
+    if (!sp) return;
+    (void)hipSetDevice(sp->ctx->device);
+    (void)hipStreamSynchronize(sp->ctx->stream);
+    if (sp->d_tab) (void)hipFree(sp->d_tab);
+    for (int i = 0; i < 2; ++i)
+        if (sp->d_hist[i]) (void)hipFree(sp->d_hist[i]);
+    if (sp->d_spec) (void)hipFree(sp->d_spec);
+    if (sp->d_stage_in) (void)hipFree(sp->d_stage_in);
+    if (sp->d_stage_out) (void)hipFree(sp->d_stage_out);
+    if (sp->k0) (void)hipEventDestroy(sp->k0);
+    if (sp->k1) (void)hipEventDestroy(sp->k1);
+    for (auto &pr : sp->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto ev : sp->event_pool) (void)hipEventDestroy(ev);
+    delete sp;
+}
+
+int32_t aw_spatializer_stream_count(const aw_spatializer *sp) { return sp ? sp->n_streams : 0; }
+int32_t aw_spatializer_channel_count(const aw_spatializer *sp) { return sp ? sp->n_channels : 0; }
+int64_t aw_spatializer_info(const aw_spatializer *sp, int32_t what) {
+    if (!sp) return -1;
+    switch (what) {
+        case 0: return awk::kN;
+        case 1: return sp->hop;
+        case 2: return sp->partitions;
+        case 3: return sp->path;
+        case 4: return sp->hist_len;
+        default: return -1;
+    }
+}
+
+aw_status aw_spatializer_set_profiling(aw_spatializer *sp, int32_t enabled) {
+    if (!sp) return fail(AW_ERR_INVALID_ARGUMENT, "sp is NULL");
+    sp->profiling = enabled != 0;
+    sp->kernel_ms_sum = 0.0;
+    sp->kernel_launches = 0;
+    return AW_OK;
+}
+
+static hipEvent_t sp_get_event(aw_spatializer *sp) {
+    if (!sp->event_pool.empty()) {
+        hipEvent_t e = sp->event_pool.back();
+        sp->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+int32_t aw_spatializer_kernel_time(aw_spatializer *sp, double *avg_ms, const char **kernel_name) {
+    if (!sp) return 0;
+    for (auto &pr : sp->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+            sp->kernel_ms_sum += ms;
+            sp->kernel_launches += 1;
+        }
+        sp->event_pool.push_back(pr.first);
+        sp->event_pool.push_back(pr.second);
+    }
+    sp->pending.clear();
+    if (avg_ms) *avg_ms = sp->kernel_launches ? sp->kernel_ms_sum / sp->kernel_launches : 0.0;
+    if (kernel_name) *kernel_name = sp->path == 0 ? awk::fused_ols_kernel_name(sp->n_channels) : "aw_part_cmac_ifft_kernel";
+    const int n = sp->kernel_launches;
+    sp->kernel_ms_sum = 0.0;
+    sp->kernel_launches = 0;
+    return n;
+}
+
+static aw_status sp_process_fused(aw_spatializer *sp, const float *in, float *out, int64_t frames) {
+    awk::TileParams p{};
+    p.in = in; p.out = out; p.hist = sp->d_hist[sp->hist_cur];
+    p.tab = sp->d_tab; p.tw1 = sp->ctx->d_tw1; p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb;
+    p.frames = frames; p.n_channels = sp->n_channels; p.n_pairs = sp->n_pairs;
+    p.hop = sp->hop; p.hist_len = sp->hist_len;
+    p.tiles_per_stream = (int)((frames + sp->hop - 1) / sp->hop);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (sp->profiling) {
+        e0 = sp_get_event(sp); e1 = sp_get_event(sp);
+        AW_HIP_TRY(hipEventRecord(e0, sp->ctx->stream));
+    }
+    AW_HIP_TRY(awk::launch_fused_ols(p, sp->n_streams, sp->ctx->stream));
+    if (sp->profiling) {
+        AW_HIP_TRY(hipEventRecord(e1, sp->ctx->stream));
+        sp->pending.emplace_back(e0, e1);
+    }
+    return AW_OK;
+}
+
+aw_status aw_spatializer_process(aw_spatializer *sp, const float *in, float *out, int64_t frames) {
+    if (!sp || !in || !out) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (frames <= 0) return frames == 0 ? AW_OK : fail(AW_ERR_INVALID_ARGUMENT, "frames must be >= 0");
+    AW_HIP_TRY(hipSetDevice(sp->ctx->device));
+    aw_status st = AW_OK;
+    if (sp->path == 0) st = sp_process_fused(sp, in, out, frames);
+    else return fail(AW_ERR_CONVOLUTION_SETUP_FAILED, "partitioned (long-tap) path is not built in this revision");
+    if (st != AW_OK) return st;
+    // carry the convolution tail: next call's history = last hist_len frames of (history ++ input)
+    float *h_old = sp->d_hist[sp->hist_cur], *h_new = sp->d_hist[sp->hist_cur ^ 1];
+    AW_HIP_TRY(awk::launch_hist_update(in, h_old, h_new, frames, sp->n_channels, sp->hist_len, sp->n_streams,
+                                       sp->ctx->stream));
+    sp->hist_cur ^= 1;
+    return AW_OK;
+}
+
+static aw_status sp_grow(float **buf, size_t *cap, size_t need) {
+    if (*cap >= need) return AW_OK;
+    if (*buf) AW_HIP_TRY(hipFree(*buf));
+    *buf = nullptr; *cap = 0;
+    AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(buf), need * sizeof(float)));
+    *cap = need;
+    return AW_OK;
+}
+
+aw_status aw_spatializer_process_host(aw_spatializer *sp, const float *in, float *out, int64_t frames) {
+    if (!sp || !in || !out) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (frames <= 0) return frames == 0 ? AW_OK : fail(AW_ERR_INVALID_ARGUMENT, "frames must be >= 0");
+    AW_HIP_TRY(hipSetDevice(sp->ctx->device));
+    const size_t n_in = (size_t)sp->n_streams * frames * sp->n_channels, n_out = (size_t)sp->n_streams * frames * 2;
+    aw_status st = sp_grow(&sp->d_stage_in, &sp->stage_in_cap, n_in);
+    if (st == AW_OK) st = sp_grow(&sp->d_stage_out, &sp->stage_out_cap, n_out);
+    if (st != AW_OK) return st;
+    AW_HIP_TRY(hipMemcpyAsync(sp->d_stage_in, in, n_in * sizeof(float), hipMemcpyHostToDevice, sp->ctx->stream));
+    st = aw_spatializer_process(sp, sp->d_stage_in, sp->d_stage_out, frames);
+    if (st != AW_OK) return st;
+    AW_HIP_TRY(hipMemcpyAsync(out, sp->d_stage_out, n_out * sizeof(float), hipMemcpyDeviceToHost, sp->ctx->stream));
+    AW_HIP_TRY(hipStreamSynchronize(sp->ctx->stream));
+    return AW_OK;
+}
+
+aw_status aw_spatializer_process_planar(aw_spatializer *sp, const float *in_l, const float *in_r, float *out_l,
+                                        float *out_r, int32_t frames) {
+    if (!sp || !in_l || !out_l || !out_r) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (sp->n_streams != 1 || sp->n_channels != 2)
+        return fail(AW_ERR_INVALID_ARGUMENT, "planar entry needs a 1-stream, 2-channel spatializer");
+    if (frames <= 0) return frames == 0 ? AW_OK : fail(AW_ERR_INVALID_ARGUMENT, "frameCount must be >= 0");
+    AW_HIP_TRY(hipSetDevice(sp->ctx->device));
+    hipStream_t s = sp->ctx->stream;
+    // staging layout: [in interleaved 2F | planar L F | planar R F] and [out interleaved 2F | L F | R F]
+    aw_status st = sp_grow(&sp->d_stage_in, &sp->stage_in_cap, (size_t)frames * 4);
+    if (st == AW_OK) st = sp_grow(&sp->d_stage_out, &sp->stage_out_cap, (size_t)frames * 4);
+    if (st != AW_OK) return st;
+    float *d_il = sp->d_stage_in + 2 * (size_t)frames, *d_ir = d_il + frames;
+    float *d_ol = sp->d_stage_out + 2 * (size_t)frames, *d_or = d_ol + frames;
+    AW_HIP_TRY(hipMemcpyAsync(d_il, in_l, sizeof(float) * frames, hipMemcpyHostToDevice, s));
+    AW_HIP_TRY(hipMemcpyAsync(d_ir, in_r ? in_r : in_l, sizeof(float) * frames, hipMemcpyHostToDevice, s));   // mono dup, RealtimeAudioProcessor.swift:95-107
+    AW_HIP_TRY(awk::launch_interleave2(d_il, d_ir, sp->d_stage_in, frames, s));
+    st = aw_spatializer_process(sp, sp->d_stage_in, sp->d_stage_out, frames);
+    if (st != AW_OK) return st;
+    AW_HIP_TRY(awk::launch_deinterleave2(sp->d_stage_out, d_ol, d_or, frames, s));
+    AW_HIP_TRY(hipMemcpyAsync(out_l, d_ol, sizeof(float) * frames, hipMemcpyDeviceToHost, s));
+    AW_HIP_TRY(hipMemcpyAsync(out_r, d_or, sizeof(float) * frames, hipMemcpyDeviceToHost, s));
+    AW_HIP_TRY(hipStreamSynchronize(s));
+    return AW_OK;
+}
+
+aw_status aw_spatializer_reset(aw_spatializer *sp) {
+    if (!sp) return fail(AW_ERR_INVALID_ARGUMENT, "sp is NULL");
+    AW_HIP_TRY(hipSetDevice(sp->ctx->device));
+    const size_t n = (size_t)sp->n_streams * sp->hist_len * sp->n_channels;
+    for (int i = 0; i < 2; ++i)
+        AW_HIP_TRY(hipMemsetAsync(sp->d_hist[i], 0, std::max<size_t>(n, 1) * sizeof(float), sp->ctx->stream));
+    return AW_OK;
+}
+
+/* ---- mono engine (ConvolutionEngine) ------------------------------------------------------- */
+aw_status aw_engine_create(aw_context *ctx, const float *hrir_samples, int32_t count, int32_t block_size,
+                           aw_engine **out) {
+    if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (!ctx || !hrir_samples) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (count <= 0 || block_size <= 0) return fail(AW_ERR_CONVOLUTION_SETUP_FAILED, "empty HRIR or non-positive block size");
+    aw_engine *e = new (std::nothrow) aw_engine();
+    if (!e) return fail(AW_ERR_OUT_OF_MEMORY, "engine");
+    e->ctx = ctx; e->block_size = block_size;
+    aw_status st = aw_hrir_create(ctx, hrir_samples, 1, count, 0.0, &e->hrir);
+    const int32_t zero = 0;
+    if (st == AW_OK) st = aw_spatializer_create(ctx, e->hrir, 1, &zero, &zero, 1, block_size, &e->sp);
+    if (st != AW_OK) { aw_engine_destroy(e); return st; }
+    e->tmp_out.assign((size_t)block_size * 2, 0.f);
+    *out = e;
+    return AW_OK;
+}
+
+void aw_engine_destroy(aw_engine *e) {
+    if (!e) return;
+    aw_spatializer_destroy(e->sp);
+    aw_hrir_destroy(e->hrir);
+    delete e;
+}
+
+int32_t aw_engine_block_size(const aw_engine *e) { return e ? e->block_size : 0; }
+
+aw_status aw_engine_process(aw_engine *e, const float *input, float *output) {
+    if (!e || !input || !output) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    aw_status st = aw_spatializer_process_host(e->sp, input, e->tmp_out.data(), e->block_size);
+    if (st != AW_OK) return st;
+    for (int i = 0; i < e->block_size; ++i) output[i] = e->tmp_out[2 * (size_t)i];
+    return AW_OK;
+}
+
+aw_status aw_engine_process_n(aw_engine *e, const float *input, float *output, int32_t frame_count) {
+    if (!e) return fail(AW_ERR_INVALID_ARGUMENT, "engine is NULL");
+    if (frame_count != e->block_size)      // guard count == blockSize else { return }  ConvolutionEngine.swift:372
+        return fail(AW_ERR_BLOCK_SIZE_MISMATCH, "frameCount != blockSize: block ignored");
+    return aw_engine_process(e, input, output);
+}
+
+aw_status aw_engine_process_accumulate(aw_engine *e, const float *input, float *acc) {
+    if (!e || !input || !acc) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    aw_status st = aw_spatializer_process_host(e->sp, input, e->tmp_out.data(), e->block_size);
+    if (st != AW_OK) return st;
+    for (int i = 0; i < e->block_size; ++i) acc[i] += e->tmp_out[2 * (size_t)i];    // vDSP_vadd, ConvolutionEngine.swift:393
+    return AW_OK;
+}
+
+aw_status aw_engine_reset(aw_engine *e) {
+    if (!e) return fail(AW_ERR_INVALID_ARGUMENT, "engine is NULL");
+    return aw_spatializer_reset(e->sp);
+}
+
+/* ---- callback-size adapter (RealtimeAudioProcessor) ---------------------------------------- */
+aw_status aw_realtime_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_renderers, const int32_t *left_track,
+                             const int32_t *right_track, int32_t block_size, int32_t max_frames, aw_realtime **out) {
+    if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (!ctx || !hrir) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (block_size <= 0 || max_frames <= 0)      // precondition(blockSize > 0), (maxFramesPerCallback > 0)  :35-36
+        return fail(AW_ERR_INVALID_ARGUMENT, "blockSize and maxFramesPerCallback must be positive");
+    if (n_renderers < 0 || (n_renderers > 0 && (!left_track || !right_track)))
+        return fail(AW_ERR_INVALID_ARGUMENT, "bad renderer list");
+    aw_realtime *p = new (std::nothrow) aw_realtime();
+    if (!p) return fail(AW_ERR_OUT_OF_MEMORY, "realtime");
+    p->ctx = ctx; p->block_size = block_size; p->max_frames = max_frames; p->n_renderers = n_renderers;
+    p->fifo_capacity = max_frames + block_size;                         // :41
+    p->pending.assign((size_t)block_size * 2, 0.f);
+    p->fifo_left.assign((size_t)p->fifo_capacity, 0.f);
+    p->fifo_right.assign((size_t)p->fifo_capacity, 0.f);
+    const int used = std::min(n_renderers, 2);                          // min(renderers.count, 2)  :145
+    if (used > 0) {
+        int32_t lt[2] = {-1, -1}, rt[2] = {-1, -1};
+        for (int r = 0; r < used; ++r) { lt[r] = left_track[r]; rt[r] = right_track[r]; }
+        aw_status st = aw_spatializer_create(ctx, hrir, 2, lt, rt, 1, block_size, &p->sp);
+        if (st != AW_OK) { aw_realtime_destroy(p); return st; }
+    }
+    *out = p;
+    return AW_OK;
+}
+
+void aw_realtime_destroy(aw_realtime *p) {
+    if (!p) return;
+    aw_spatializer_destroy(p->sp);
+    delete p;
+}
+
+aw_status aw_realtime_process(aw_realtime *p, const float *in_l, const float *in_r, float *out_l, float *out_r,
+                              int32_t frame_count) {
+    if (!p) return fail(AW_ERR_INVALID_ARGUMENT, "processor is NULL");
+    if (frame_count <= 0) return AW_OK;                                 // guard frameCount > 0 else { return }  :84
+    if (!in_l || !out_l || !out_r) return fail(AW_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (frame_count > p->max_frames)                                    // precondition  :85
+        return fail(AW_ERR_INVALID_ARGUMENT, "frameCount exceeds maxFramesPerCallback");
+    const int B = p->block_size;
+    p->ready_in.clear();
+    int off = 0;
+    while (off < frame_count) {                                         // :88-116
+        const int copy = std::min(B - p->pending_count, frame_count - off);
+        for (int i = 0; i < copy; ++i) {
+            p->pending[2 * (size_t)(p->pending_count + i)] = in_l[off + i];
+            p->pending[2 * (size_t)(p->pending_count + i) + 1] = (in_r ? in_r : in_l)[off + i];   // mono dup :95-107
+        }
+        p->pending_count += copy;
+        off += copy;
+        if (p->pending_count == B) {
+            // processPendingBlock (:141-172) — blocks completed inside one callback are convolved
+            // together in one device call below; the result is block-size independent.
+            p->ready_in.insert(p->ready_in.end(), p->pending.begin(), p->pending.end());
+            p->pending_count = 0;
+        }
+    }
+    const int ready_frames = (int)(p->ready_in.size() / 2);
+    if (ready_frames > 0) {
+        p->ready_out.assign((size_t)ready_frames * 2, 0.f);             // memset blockLeft/blockRight :142-143
+        if (p->sp) {
+            aw_status st = aw_spatializer_process_host(p->sp, p->ready_in.data(), p->ready_out.data(), ready_frames);
+            if (st != AW_OK) return st;
+        }
+        for (int i = 0; i < ready_frames; ++i) {                        // FIFO push :166-171
+            const int w = (p->fifo_read_index + p->fifo_count) % p->fifo_capacity;
+            p->fifo_left[(size_t)w] = p->ready_out[2 * (size_t)i];
+            p->fifo_right[(size_t)w] = p->ready_out[2 * (size_t)i + 1];
+            p->fifo_count += 1;
+        }
+    }
+    for (int i = 0; i < frame_count; ++i) {                             // drain :174-190
+        if (p->fifo_count > 0) {
+            out_l[i] = p->fifo_left[(size_t)p->fifo_read_index];
+            out_r[i] = p->fifo_right[(size_t)p->fifo_read_index];
+            p->fifo_read_index = (p->fifo_read_index + 1) % p->fifo_capacity;
+            p->fifo_count -= 1;
+        } else {
+            out_l[i] = 0.f;
+            out_r[i] = 0.f;
+        }
+    }
+    return AW_OK;
+}
+
+aw_status aw_realtime_reset(aw_realtime *p) {                           // :121-139
+    if (!p) return fail(AW_ERR_INVALID_ARGUMENT, "processor is NULL");
+    if (p->sp) {
+        aw_status st = aw_spatializer_reset(p->sp);
+        if (st != AW_OK) return st;
+    }
+    std::fill(p->pending.begin(), p->pending.end(), 0.f);
+    std::fill(p->fifo_left.begin(), p->fifo_left.end(), 0.f);
+    std::fill(p->fifo_right.begin(), p->fifo_right.end(), 0.f);
+    p->pending_count = 0; p->fifo_read_index = 0; p->fifo_count = 0;
+    return AW_OK;
+}
+
+/* ---- synthetic input --------------------------------------------------------------------------- */
+aw_status aw_synth_fill(aw_context *ctx, float *dst, int32_t n_streams, int64_t frames, int32_t n_channels,
+                        uint64_t seed, uint64_t first_stream) {
+    if (!ctx || !dst) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_streams <= 0 || frames <= 0 || n_channels <= 0) return fail(AW_ERR_INVALID_ARGUMENT, "non-positive size");
+    AW_HIP_TRY(hipSetDevice(ctx->device));
+    AW_HIP_TRY(awk::launch_synth_fill(dst, n_streams, frames * n_channels, seed, first_stream, ctx->stream));
+    return AW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+// runtime.hpp — internal C++ objects behind the opaque C handles of include/airwave_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/airwave_hip.h"
+#include "device/kernels.hpp"
+
+namespace awr {
+
+void set_error(const std::string &msg);
+aw_status fail(aw_status code, const std::string &msg);
+aw_status hip_fail(hipError_t e, const char *what);
+
+#define AW_HIP_TRY(expr)                                          \
+    do {                                                          \
+        hipError_t _e = (expr);                                   \
+        if (_e != hipSuccess) return ::awr::hip_fail(_e, #expr);  \
+    } while (0)
+
+}  // namespace awr
+
+struct aw_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    awk::cf *d_tw1 = nullptr, *d_twa = nullptr, *d_twb = nullptr;   // twiddle rows (FFTSetupManager analogue)
+};
+
+struct aw_hrir {
+    aw_context *ctx = nullptr;
+    int n_tracks = 0, taps = 0;
+    double sample_rate = 0.0;
+    std::vector<float> tracks;   // [n_tracks][taps], host
+};
+
+struct aw_spatializer {
+    aw_context *ctx = nullptr;
+    int n_channels = 0, n_pairs = 0, n_streams = 0, taps = 0;
+    int path = 0;             // 0 fused single-partition overlap-save, 1 partitioned
+    int hop = 0, hist_len = 0, partitions = 1;
+    awk::cf2 *d_tab = nullptr;          // [partitions][pairs][N]
+    float *d_hist[2] = {nullptr, nullptr};
+    int hist_cur = 0;
+    // partitioned path scratch (grow-only): input-window spectra [stream][block][pair][N]
+    awk::cf *d_spec = nullptr;
+    size_t spec_capacity = 0;           // elements
+    // host-entry staging (grow-only)
+    float *d_stage_in = nullptr, *d_stage_out = nullptr;
+    size_t stage_in_cap = 0, stage_out_cap = 0;   // floats
+    // profiling of the dominant kernel
+    bool profiling = false;
+    hipEvent_t k0 = nullptr, k1 = nullptr;
+    double kernel_ms_sum = 0.0;
+    int kernel_launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // recorded, not yet read
+    std::vector<hipEvent_t> event_pool;
+};
+
+struct aw_engine {
+    aw_context *ctx = nullptr;
+    aw_hrir *hrir = nullptr;
+    aw_spatializer *sp = nullptr;
+    int block_size = 0;
+    std::vector<float> tmp_out;   // [block][2]
+};
+
+struct aw_realtime {
+    aw_context *ctx = nullptr;
+    aw_spatializer *sp = nullptr;     // 1 stream, 2 input channels (L, R) -> first min(n,2) renderers
+    int block_size = 0, max_frames = 0, fifo_capacity = 0, n_renderers = 0;
+    std::vector<float> pending;       // [block][2] interleaved L,R
+    std::vector<float> ready_in;      // completed blocks of this callback, interleaved
+    std::vector<float> ready_out;
+    std::vector<float> fifo_left, fifo_right;
+    int pending_count = 0, fifo_read_index = 0, fifo_count = 0;
+};

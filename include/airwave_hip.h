@@ -1,0 +1,207 @@
+/*
+ * airwave_hip.h — C ABI of the MI355X-native batch HRIR spatializer (libairwave_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of sallliisa/Airwave: the per-virtual-speaker
+ * partitioned FFT convolution + stereo downmix (ConvolutionEngine / VirtualSpeaker /
+ * RealtimeAudioProcessor / HRIRManager.activatePreset).  Every entry point cites the reference
+ * interface it replaces (paths relative to the reference repository root).  Host code in any
+ * language binds these symbols (Swift module map + wrapper: swift/; ctypes: airwave_amd/;
+ * C++ RAII mirror: include/airwave_hip.hpp).  See INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C types only; opaque handles; every function returns aw_status (0 = ok);
+ *    no exceptions or callbacks cross the boundary; aw_last_error_message() gives detail.
+ *  - a handle is single-threaded for process/reset (like ConvolutionEngine: "not thread-safe,
+ *    one owner"); independent handles are independent.
+ *  - creation may block and allocate (the reference builds engines on a background queue,
+ *    HRIRManager.swift:347); aw_spatializer_process on device buffers does not allocate once
+ *    the handle has seen a call of that size class (scratch is grow-only).
+ *  - there is NO CPU fallback: without a HIP device every create returns AW_ERR_NO_DEVICE.
+ */
+#ifndef AIRWAVE_HIP_H
+#define AIRWAVE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AW_API __attribute__((visibility("default")))
+
+/* ---- status codes ---------------------------------------------------------------------------- */
+typedef int32_t aw_status;
+enum {
+    AW_OK = 0,
+    AW_ERR_INVALID_ARGUMENT = 1,         /* Swift precondition failures (RealtimeAudioProcessor.swift:35-36,85) */
+    AW_ERR_OUT_OF_MEMORY = 2,
+    AW_ERR_HIP = 3,                      /* any HIP runtime error; message has hipGetErrorString */
+    AW_ERR_NO_DEVICE = 4,                /* no HIP device / ordinal out of range */
+    AW_ERR_INVALID_CHANNEL_MAPPING = 5,  /* HRIRError.invalidChannelMapping  HRIRManager.swift:375-379 */
+    AW_ERR_CONVOLUTION_SETUP_FAILED = 6, /* HRIRError.convolutionSetupFailed HRIRManager.swift:406-409,420-422 */
+    AW_ERR_INVALID_CHANNEL_COUNT = 7,    /* WAVError/HRIRError.invalidChannelCount WAVLoader.swift:40-42, HRIRManager.swift:223 */
+    AW_ERR_WAV_FILE_READ = 8,            /* WAVError.fileReadError   WAVLoader.swift:31-33,59-61 */
+    AW_ERR_WAV_EMPTY_FILE = 9,           /* WAVError.emptyFile       WAVLoader.swift:44-46 */
+    AW_ERR_WAV_UNSUPPORTED_FORMAT = 10,  /* WAVError.unsupportedFormat WAVLoader.swift:89-91 */
+    AW_ERR_BLOCK_SIZE_MISMATCH = 11      /* ConvolutionEngine.process(input:output:frameCount:) guard, ConvolutionEngine.swift:372 */
+};
+AW_API const char *aw_status_string(aw_status s);
+AW_API const char *aw_last_error_message(void); /* thread-local, valid until the next failing call */
+
+/* ---- context: device + stream + twiddle tables -------------------------------------------------
+ * Replaces FFTSetupManager.shared.getSetup(log2n:) (FFTSetupManager.swift:41-60): the twiddle
+ * table is built once per context and shared by every spatializer/engine created on it. */
+typedef struct aw_context aw_context;
+AW_API aw_status aw_context_create(int32_t device_ordinal, aw_context **out);
+/* Same, but launches on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+AW_API aw_status aw_context_create_on_stream(int32_t device_ordinal, void *hip_stream, aw_context **out);
+AW_API void aw_context_destroy(aw_context *ctx);
+AW_API aw_status aw_context_synchronize(aw_context *ctx);
+AW_API void *aw_context_stream(aw_context *ctx);          /* the hipStream_t kernels are launched on */
+/* HIP-event stopwatch on the context's stream (bench.py times the kernels with these). */
+AW_API aw_status aw_context_timer_start(aw_context *ctx);
+AW_API aw_status aw_context_timer_stop(aw_context *ctx, float *elapsed_ms); /* records, syncs, returns ms */
+
+/* Device memory helpers for hosts without their own HIP bindings (Swift, ctypes). */
+AW_API aw_status aw_device_alloc(aw_context *ctx, size_t bytes, void **dptr);
+AW_API aw_status aw_device_free(aw_context *ctx, void *dptr);
+AW_API aw_status aw_memcpy_h2d(aw_context *ctx, void *dst_device, const void *src_host, size_t bytes);
+AW_API aw_status aw_memcpy_d2h(aw_context *ctx, void *dst_host, const void *src_device, size_t bytes);
+
+/* ---- HRIR set --------------------------------------------------------------------------------
+ * The planar impulse responses a preset provides (WAVData.audioData, WAVLoader.swift:12-17):
+ * tracks is [n_tracks][taps] float32 on the HOST. */
+typedef struct aw_hrir aw_hrir;
+AW_API aw_status aw_hrir_create(aw_context *ctx, const float *tracks, int32_t n_tracks, int32_t taps,
+                                double sample_rate, aw_hrir **out);
+AW_API void aw_hrir_destroy(aw_hrir *h);
+AW_API int32_t aw_hrir_track_count(const aw_hrir *h);
+AW_API int32_t aw_hrir_taps(const aw_hrir *h);
+AW_API double aw_hrir_sample_rate(const aw_hrir *h);
+
+/* ---- batch spatializer -----------------------------------------------------------------------
+ * n_streams independent streams, each = the engine network HRIRManager.activatePreset builds
+ * (one ConvolutionEngine per (input channel, ear), HRIRManager.swift:366-418) plus the downmix
+ * of RealtimeAudioProcessor.processPendingBlock (RealtimeAudioProcessor.swift:141-164) without
+ * its two-renderer cap:  out_L = sum_c x_c * h[left_track[c]],  out_R = sum_c x_c * h[right_track[c]].
+ * A channel with left_track[c] < 0 or right_track[c] < 0 is skipped (HRIRManager.swift:370-372);
+ * an index >= n_tracks is AW_ERR_INVALID_CHANNEL_MAPPING (:375-379); no mapped channel at all is
+ * AW_ERR_CONVOLUTION_SETUP_FAILED (:420-422).  block_hint: 0 = automatic (results do not depend on it). */
+typedef struct aw_spatializer aw_spatializer;
+AW_API aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_in_channels,
+                                       const int32_t *left_track, const int32_t *right_track,
+                                       int32_t n_streams, int32_t block_hint, aw_spatializer **out);
+AW_API void aw_spatializer_destroy(aw_spatializer *sp);
+/* Offline/batch entry: DEVICE buffers.  in: [stream][frames][n_in_channels] interleaved float32,
+ * out: [stream][frames][2].  Any frames >= 1; state (the convolution tail) carries over to the
+ * next call exactly like consecutive ConvolutionEngine.process calls.  Asynchronous on the
+ * context stream. */
+AW_API aw_status aw_spatializer_process(aw_spatializer *sp, const float *in_device, float *out_device, int64_t frames);
+/* Same with HOST buffers (staged through device scratch; synchronous). */
+AW_API aw_status aw_spatializer_process_host(aw_spatializer *sp, const float *in_host, float *out_host, int64_t frames);
+/* StereoAudioProcessing.process shape (AudioPipeline.swift:3-11) for a 1-stream, 2-channel
+ * spatializer: planar HOST buffers, input_right may be NULL (mono duplication). Zero latency. */
+AW_API aw_status aw_spatializer_process_planar(aw_spatializer *sp, const float *input_left, const float *input_right,
+                                               float *output_left, float *output_right, int32_t frame_count);
+/* ConvolutionEngine.reset() for every engine of every stream (ConvolutionEngine.swift:397-407). */
+AW_API aw_status aw_spatializer_reset(aw_spatializer *sp);
+AW_API int32_t aw_spatializer_stream_count(const aw_spatializer *sp);
+AW_API int32_t aw_spatializer_channel_count(const aw_spatializer *sp);
+/* Introspection for benches/tests: 0 fft length, 1 hop, 2 partitions, 3 path (0 fused, 1 partitioned) */
+AW_API int64_t aw_spatializer_info(const aw_spatializer *sp, int32_t what);
+/* Average device time of the dominant kernel over the launches since the last call (HIP events
+ * on the context stream); used for bench.py's roofline object.  Returns launches counted. */
+AW_API aw_status aw_spatializer_set_profiling(aw_spatializer *sp, int32_t enabled);
+AW_API int32_t aw_spatializer_kernel_time(aw_spatializer *sp, double *avg_ms, const char **kernel_name);
+
+/* ---- mono engine: ConvolutionEngine (ConvolutionEngine.swift:14-408) ---------------------------
+ * init?(hrirSamples:blockSize:) :68 / process(input:output:) :232 / processAndAccumulate :388 /
+ * reset() :397.  HOST buffers of exactly block_size frames. */
+typedef struct aw_engine aw_engine;
+AW_API aw_status aw_engine_create(aw_context *ctx, const float *hrir_samples, int32_t count, int32_t block_size,
+                                  aw_engine **out);
+AW_API void aw_engine_destroy(aw_engine *e);
+AW_API aw_status aw_engine_process(aw_engine *e, const float *input, float *output);
+/* frame_count != block_size returns AW_ERR_BLOCK_SIZE_MISMATCH and leaves output untouched
+ * (the Swift array wrapper silently returns, ConvolutionEngine.swift:370-373). */
+AW_API aw_status aw_engine_process_n(aw_engine *e, const float *input, float *output, int32_t frame_count);
+AW_API aw_status aw_engine_process_accumulate(aw_engine *e, const float *input, float *output_accumulator);
+AW_API aw_status aw_engine_reset(aw_engine *e);
+AW_API int32_t aw_engine_block_size(const aw_engine *e);
+
+/* ---- callback-size adapter: RealtimeAudioProcessor (RealtimeAudioProcessor.swift:11-191) --------
+ * Renderer r convolves with hrir tracks (left_track[r], right_track[r]); like the reference only
+ * the first min(n_renderers, 2) renderers run, fed from the left / right input (:145-147).
+ * Pending-buffer + FIFO semantics, latency block_size - callback frames, silence on underflow. */
+typedef struct aw_realtime aw_realtime;
+AW_API aw_status aw_realtime_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_renderers,
+                                    const int32_t *left_track, const int32_t *right_track, int32_t block_size,
+                                    int32_t max_frames_per_callback, aw_realtime **out);
+AW_API void aw_realtime_destroy(aw_realtime *p);
+AW_API aw_status aw_realtime_process(aw_realtime *p, const float *input_left, const float *input_right,
+                                     float *left_output, float *right_output, int32_t frame_count);
+AW_API aw_status aw_realtime_reset(aw_realtime *p);
+
+/* ---- host-side data model (no GPU needed) ----------------------------------------------------- */
+/* WAVLoader.load (WAVLoader.swift:26-99): any RIFF/WAVE -> planar float32. */
+typedef struct aw_wav aw_wav;
+AW_API aw_status aw_wav_load(const char *path, aw_wav **out);
+AW_API void aw_wav_destroy(aw_wav *w);
+AW_API double aw_wav_sample_rate(const aw_wav *w);
+AW_API int32_t aw_wav_channel_count(const aw_wav *w);
+AW_API int32_t aw_wav_frame_count(const aw_wav *w);
+AW_API const float *aw_wav_channel(const aw_wav *w, int32_t channel);   /* frame_count floats */
+AW_API const float *aw_wav_planar(const aw_wav *w);                     /* [channels][frames] */
+
+/* InputLayout (VirtualSpeaker.swift:59-100).  Speakers are identified by their case name
+ * ("FL", "FR", "FC", "LFE", "BL", "BR", "SL", "SR", "TFL", ... ) or, for .custom, the custom name. */
+typedef struct aw_layout aw_layout;
+AW_API aw_status aw_layout_detect(int32_t channel_count, aw_layout **out);      /* InputLayout.detect :88-99 */
+AW_API aw_status aw_layout_create(const char *const *speaker_names, int32_t count, const char *name, aw_layout **out);
+AW_API void aw_layout_destroy(aw_layout *l);
+AW_API int32_t aw_layout_count(const aw_layout *l);
+AW_API const char *aw_layout_speaker(const aw_layout *l, int32_t index);
+AW_API const char *aw_layout_name(const aw_layout *l);
+
+/* HRIRChannelMap (VirtualSpeaker.swift:103-347): speaker -> (left-ear track, right-ear track). */
+typedef struct aw_channel_map aw_channel_map;
+AW_API aw_status aw_map_hesuvi14(const aw_layout *speakers, aw_channel_map **out);          /* :270-297 */
+AW_API aw_status aw_map_hesuvi7(const aw_layout *speakers, aw_channel_map **out);           /* :224-250 */
+AW_API aw_status aw_map_interleaved_pairs(const aw_layout *speakers, aw_channel_map **out); /* :126-159 */
+AW_API aw_status aw_map_split_blocks(const aw_layout *speakers, aw_channel_map **out);      /* :200-209 */
+AW_API aw_status aw_map_parse_text(const char *text, aw_channel_map **out);                 /* parseHeSuViFormat :301-346 */
+AW_API void aw_map_destroy(aw_channel_map *m);
+AW_API int32_t aw_map_count(const aw_channel_map *m);
+/* getIndices(for:) :115-117 — returns 1 and fills the indices when the speaker is mapped, else 0. */
+AW_API int32_t aw_map_get(const aw_channel_map *m, const char *speaker, int32_t *left_ear, int32_t *right_ear);
+/* The per-speaker loop of activatePreset (HRIRManager.swift:366-379,420-422): fills
+ * left_track/right_track[layout count] with -1 for unmapped speakers. */
+AW_API aw_status aw_map_resolve(const aw_channel_map *m, const aw_layout *layout, int32_t n_tracks,
+                                int32_t *left_track, int32_t *right_track);
+
+/* Resampler.resampleHighQuality (Resampler.swift:31-68), the INTENDED linear interpolation
+ * out[i] = lerp(input, i * fromRate / toRate); see DESIGN.md for the vDSP_vgenp divergence. */
+AW_API int32_t aw_resample_output_count(int32_t count, double from_rate, double to_rate);
+AW_API aw_status aw_resample(const float *input, int32_t count, double from_rate, double to_rate, float *output,
+                             int32_t output_capacity, int32_t *output_count);
+
+/* HRIRManager.activatePreset body (HRIRManager.swift:347-446): load WAV -> choose map (7 tracks:
+ * hesuvi7, else hesuvi14; or `custom_map`) -> resolve -> resample HRIR to target rate when it
+ * differs by > 0.01 Hz -> build the spatializer.  *hrir_out (optional) receives the HRIR handle
+ * the spatializer was built from (caller destroys both). */
+AW_API aw_status aw_preset_activate(aw_context *ctx, const char *wav_path, double target_sample_rate,
+                                    const aw_layout *input_layout, const aw_channel_map *custom_map,
+                                    int32_t n_streams, aw_spatializer **spatializer_out, aw_hrir **hrir_out);
+
+/* Seeded synthetic input on the device: U(-0.5,0.5) counter RNG,
+ * value(stream, i) as oracle/airwave_oracle.h:orc_synth_value.  dst: [n_streams][frames][n_channels]. */
+AW_API aw_status aw_synth_fill(aw_context *ctx, float *dst_device, int32_t n_streams, int64_t frames,
+                               int32_t n_channels, uint64_t seed, uint64_t first_stream);
+
+AW_API const char *aw_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

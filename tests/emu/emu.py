@@ -1,0 +1,56 @@
+"""TEST-ONLY: ctypes access to the thread-emulated tile kernel (tests/emu/emu_harness.cpp)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+_LIB = os.path.join(_HERE, "libemu.so")
+_SRCS = [os.path.join(_HERE, "emu_harness.cpp"), os.path.join(_ROOT, "airwave_amd/csrc/host/tables.cpp")]
+_DEPS = _SRCS + [os.path.join(_ROOT, "airwave_amd/csrc/device", f) for f in ("tile_ols.hpp", "cplx.hpp")] + [
+    os.path.join(_ROOT, "airwave_amd/csrc/host/tables.hpp")]
+_lib = None
+
+fp = ctypes.POINTER(ctypes.c_float)
+ip = ctypes.POINTER(ctypes.c_int32)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(d) for d in _DEPS):
+            subprocess.run(["g++", "-std=c++20", "-O2", "-pthread", "-shared", "-fPIC", "-o", _LIB] + _SRCS, check=True)
+        _lib = ctypes.CDLL(_LIB)
+        _lib.emu_fused_ols.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
+                                       ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
+        _lib.emu_fft_small.argtypes = [fp, ctypes.c_int, ctypes.c_int]
+    return _lib
+
+
+def fused_ols(x, tracks, left_track, right_track, hop=None, hist=None):
+    """x: [streams][frames][C] float32 -> [streams][frames][2]."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    S, F, C = x.shape
+    tr = np.ascontiguousarray(tracks, dtype=np.float32)
+    lt = np.ascontiguousarray(left_track, dtype=np.int32)
+    rt = np.ascontiguousarray(right_track, dtype=np.int32)
+    if hop is None:
+        hop = 8192 - (tr.shape[1] - 1)
+    out = np.full((S, F, 2), np.nan, dtype=np.float32)
+    h = None
+    if hist is not None:
+        h = np.ascontiguousarray(hist, dtype=np.float32)
+        assert h.shape == (S, 8192 - hop, C)
+    rc = lib().emu_fused_ols(x.ctypes.data_as(fp), out.ctypes.data_as(fp), None if h is None else h.ctypes.data_as(fp),
+                             tr.ctypes.data_as(fp), tr.shape[0], tr.shape[1], C, lt.ctypes.data_as(ip),
+                             rt.ctypes.data_as(ip), F, S, hop)
+    assert rc == 0
+    return out
+
+
+def fft_small(v, inverse=False):
+    a = np.ascontiguousarray(np.asarray(v, dtype=np.complex64)).view(np.float32).copy()
+    assert lib().emu_fft_small(a.ctypes.data_as(fp), a.size // 2, int(inverse)) == 0
+    return a.view(np.complex64)

@@ -1,0 +1,102 @@
+// emu_harness.cpp — TEST-ONLY thread emulation of the HIP tile kernel.
+//
+// Compiles airwave_amd/csrc/device/tile_ols.hpp (the exact code the GPU runs) with g++ and
+// executes one workgroup as 512 std::threads: workgroup barriers are std::barrier(512),
+// wave-level syncs are std::barrier(64).  It exists so index math, twiddles and LDS hazards can
+// be checked on the CPU-only build container before spending GPU minutes.  It is NOT part of the
+// product library and nothing under airwave_amd/ links it.
+#include <barrier>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#include "../../airwave_amd/csrc/device/tile_ols.hpp"
+#include "../../airwave_amd/csrc/host/tables.hpp"
+
+namespace {
+
+struct EmuShared {
+    std::barrier<> wg{awk::kThreads};
+    std::vector<std::unique_ptr<std::barrier<>>> wave;
+    std::vector<awk::cf> lds;
+    EmuShared() : lds((size_t)2 * awk::kBufElems) {
+        for (int w = 0; w < awk::kThreads / 64; ++w) wave.emplace_back(new std::barrier<>(64));
+    }
+};
+
+struct EmuCtx {
+    int tid_;
+    EmuShared *sh;
+    int tid() const { return tid_; }
+    int lane() const { return tid_ & 63; }
+    int wave() const { return tid_ >> 6; }
+    awk::cf *lds() const { return sh->lds.data(); }
+    void barrier() const { sh->wg.arrive_and_wait(); }
+    void wave_sync() const { sh->wave[tid_ >> 6]->arrive_and_wait(); }
+};
+
+}  // namespace
+
+extern "C" {
+
+// Builds tables + twiddles on the host and runs every tile of every stream through the emulated
+// workgroup.  Layouts as TileParams.  hist may be NULL (zeros).
+int emu_fused_ols(const float *in, float *out, const float *hist, const float *tracks, int n_tracks,
+                  int taps, int n_channels, const int32_t *left_track, const int32_t *right_track,
+                  long long frames, int n_streams, int hop) {
+    using namespace awk;
+    if (hop <= 0 || hop > kN - (taps - 1)) return -1;
+    awh::Twiddles tw;
+    std::vector<cf2> tab;
+    awh::build_twiddles(tw);
+    awh::build_pair_tables(tracks, n_tracks, taps, n_channels, left_track, right_track, 0, taps, tab);
+    std::vector<float> zero_hist;
+    TileParams p{};
+    p.in = in; p.out = out; p.tab = tab.data(); p.tw1 = tw.tw1.data(); p.twa = tw.twa.data(); p.twb = tw.twb.data();
+    p.frames = frames; p.n_channels = n_channels; p.n_pairs = (n_channels + 1) / 2;
+    p.hop = hop; p.hist_len = kN - hop;
+    p.tiles_per_stream = (int)((frames + hop - 1) / hop);
+    if (!hist) {
+        zero_hist.assign((size_t)n_streams * p.hist_len * n_channels, 0.f);
+        hist = zero_hist.data();
+    }
+    p.hist = hist;
+    EmuShared sh;
+    for (int s = 0; s < n_streams; ++s) {
+        for (int tile = 0; tile < p.tiles_per_stream; ++tile) {
+            std::vector<std::thread> th;
+            th.reserve(kThreads);
+            for (int t = 0; t < kThreads; ++t)
+                th.emplace_back([&, t]() {
+                    EmuCtx ctx{t, &sh};
+                    tile_fused_ols<EmuCtx, 0>(ctx, p, s, tile);
+                });
+            for (auto &x : th) x.join();
+        }
+    }
+    return 0;
+}
+
+// Butterfly unit checks: n in {4, 8, 16}; data is [n] complex interleaved, in place.
+int emu_fft_small(float *data, int n, int inverse) {
+    using namespace awk;
+    if (n == 4) {
+        cf a = mk(data[0], data[1]), b = mk(data[2], data[3]), c = mk(data[4], data[5]), d = mk(data[6], data[7]);
+        if (inverse) fft4<true>(a, b, c, d); else fft4<false>(a, b, c, d);
+        cf r[4] = {a, b, c, d};
+        std::memcpy(data, r, sizeof(r));
+    } else if (n == 8) {
+        cf v[8]; std::memcpy(v, data, sizeof(v));
+        if (inverse) fft8<true>(v); else fft8<false>(v);
+        std::memcpy(data, v, sizeof(v));
+    } else if (n == 16) {
+        cf v[16]; std::memcpy(v, data, sizeof(v));
+        if (inverse) fft16<true>(v); else fft16<false>(v);
+        std::memcpy(data, v, sizeof(v));
+    } else return -1;
+    return 0;
+}
+
+}  // extern "C"

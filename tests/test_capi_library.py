@@ -1,0 +1,121 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/airwave_hip.h declares,
+fails loudly without a GPU, and its host-side data model agrees with the oracle restatement."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import airwave_amd as aw
+from airwave_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "airwave_hip.h")).read()
+    return sorted(set(re.findall(r"AW_API[^;]*?\b(aw_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    names = header_symbols()
+    assert len(names) >= 60
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/airwave_hip.h but not exported"
+    assert sorted(_capi.SIGNATURES) == names, "ctypes table and header disagree"
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(aw.AirwaveError) as ei:
+        aw.Context(0)
+    assert ei.value.name == "NO_DEVICE"
+
+
+def test_product_package_does_not_import_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "airwave_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                src = open(os.path.join(root, f), errors="replace").read()
+                assert "airwave_oracle" not in src.replace("oracle/airwave_oracle.h: orc_synth_value", "").replace(
+                    "oracle/airwave_oracle.h:orc_synth_value", ""), f
+
+
+def test_layouts_and_maps_match_oracle(oracle):
+    for n in [1, 2, 3, 6, 7, 8, 12, 14]:
+        lay = aw.InputLayout.detect(n)
+        assert lay.channels == oracle.layout_detect(n)
+        for ctor, ofn in [(aw.HRIRChannelMap.hesuvi14Channel, oracle.map_hesuvi14), (aw.HRIRChannelMap.hesuvi7Channel, oracle.map_hesuvi7),
+                          (aw.HRIRChannelMap.interleavedPairs, oracle.map_interleaved_pairs), (aw.HRIRChannelMap.splitBlocks, oracle.map_split_blocks)]:
+            m, om = ctor(lay), ofn(lay.channels)
+            assert len(m) == len(om)
+            for s in lay.channels:
+                assert m.getIndices(s) == om.get(s)
+    assert aw.InputLayout.detect(8).name == "7.1 Surround" and aw.InputLayout.detect(5).name == "5 Channel"
+
+
+def test_parse_text_matches_oracle(oracle, golden_dir):
+    texts = ["# c\n; c\n\nL = 0, 1\n  r=8 ,7\nSUB = 6, 13\nRL = 4, 5\nbogus\nX = 1\nY = 1, 2, 3\nMine = 2, 3\nC = a, 1\nL = 5, 6\r\nTFL=1,+2\rsl = -1, 3",
+             open(os.path.join(golden_dir, "hesuvi14_custom_map.txt")).read()]
+    for t in texts:
+        m, om = aw.HRIRChannelMap.parseHeSuViFormat(t), oracle.parse_hesuvi_format(t)
+        assert len(m) == len(om)
+        for k, v in om.items():
+            assert m.getIndices(k) == v
+
+
+def test_resolve_rules(oracle, golden_dir):
+    lay = aw.InputLayout.detect(12)
+    lt, rt = aw.HRIRChannelMap.hesuvi14Channel(lay).resolve(lay, 14)
+    assert lt.tolist() == [0, 8, 6, 6, 4, 12, 2, 10, -1, -1, -1, -1] and rt.tolist() == [1, 7, 13, 13, 5, 11, 3, 9, -1, -1, -1, -1]
+    with pytest.raises(aw.HRIRError) as e1:        # HRIRError.invalidChannelMapping
+        aw.HRIRChannelMap.hesuvi14Channel(aw.InputLayout.detect(2)).resolve(aw.InputLayout.detect(2), 2)
+    assert e1.value.name == "INVALID_CHANNEL_MAPPING" and "(8, 7) out of range for 2 channels" in str(e1.value)
+    with pytest.raises(aw.HRIRError) as e2:        # convolutionSetupFailed("No valid renderers created")
+        lay3 = aw.InputLayout.detect(3)
+        aw.HRIRChannelMap.hesuvi14Channel(lay3).resolve(lay3, 14)
+    assert e2.value.name == "CONVOLUTION_SETUP_FAILED"
+
+
+def test_wav_loader_matches_oracle(oracle, golden_dir, tmp_path):
+    for name in ["NeutralSH1.0.wav", "RoomSH1.0.wav", "StageSH1.0.wav"]:
+        p = os.path.join(golden_dir, "hrtf", name)
+        w, ow = aw.WAVLoader.load(p), oracle.wav_load(p)
+        assert (w.sample_rate, w.channel_count, w.frame_count) == (ow.sample_rate, ow.channel_count, ow.frame_count)
+        assert np.array_equal(w.audio_data, ow.audio_data)
+    from test_oracle_data_model import _write_wav
+    p = str(tmp_path / "x.wav")
+    cases = [(1, 16, 2, np.array([[0, 16384], [-32768, 32767], [1, -1]], dtype="<i2").tobytes(), False),
+             (1, 16, 8, np.arange(40, dtype="<i2").tobytes(), True),
+             (1, 32, 1, np.array([2 ** 30, -2 ** 31], dtype="<i4").tobytes(), False),
+             (1, 24, 1, bytes([0, 0, 0x40, 0, 0, 0x80, 0xFF, 0xFF, 0x7F]), False),
+             (3, 64, 2, np.array([0.25, -0.75, 1e-3, 3.0], dtype="<f8").tobytes(), False),
+             (1, 8, 1, bytes([0, 128, 255]), False)]
+    for tag, bits, ch, payload, ext in cases:
+        _write_wav(p, tag, bits, ch, payload, extensible=ext)
+        w, ow = aw.WAVLoader.load(p), oracle.wav_load(p)
+        assert np.array_equal(w.audio_data, ow.audio_data) and w.channel_count == ow.channel_count
+    _write_wav(p, 3, 32, 1, b"")
+    with pytest.raises(aw.WAVError) as e:
+        aw.WAVLoader.load(p)
+    assert e.value.name == "WAV_EMPTY_FILE"
+    _write_wav(p, 2, 4, 1, b"\x00" * 64)     # ADPCM
+    with pytest.raises(aw.WAVError) as e:
+        aw.WAVLoader.load(p)
+    assert e.value.name in ("WAV_UNSUPPORTED_FORMAT", "WAV_EMPTY_FILE")
+    with pytest.raises(aw.WAVError) as e:
+        aw.WAVLoader.load(str(tmp_path / "missing.wav"))
+    assert e.value.name == "WAV_FILE_READ"
+
+
+def test_resampler_matches_oracle(oracle):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(4320).astype(np.float32)
+    for fr, to in [(48000, 96000), (48000, 44100), (44100, 48000), (96000, 48000), (48000, 48000.004), (48000, 192000)]:
+        y, oy = aw.Resampler.resampleHighQuality(x, fr, to), oracle.resample_intended(x, fr, to)
+        assert y.size == oy.size == oracle.resample_output_count(x.size, fr, to) or abs(fr - to) < 0.01
+        assert np.array_equal(y, oy)

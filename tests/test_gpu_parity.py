@@ -1,0 +1,202 @@
+"""Parity of the HIP spatializer (through the C ABI) with the float64 goldens and the float32 CPU
+oracle.  Tolerance: BASELINE.json north_star, <= 1e-5 max error relative to the signal peak."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def aw():
+    import airwave_amd
+    return airwave_amd
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def wav(oracle, golden_dir, name):
+    return oracle.wav_load(os.path.join(golden_dir, "hrtf", name))
+
+
+@pytest.mark.parametrize("gold,wavname,speakers", [
+    ("cfg1_neutral_stereo.npz", "NeutralSH1.0.wav", 2),
+    ("cfg2_room_71.npz", "RoomSH1.0.wav", 8),
+    ("cfg3_stage_7spk.npz", "StageSH1.0.wav", ["FL", "FR", "FC", "BL", "BR", "SL", "SR"]),
+])
+def test_goldens_via_preset_activation(aw, oracle, golden_dir, gold, wavname, speakers):
+    g = load(golden_dir, gold)
+    layout = aw.InputLayout.detect(speakers) if isinstance(speakers, int) else aw.InputLayout(speakers, "custom")
+    mgr = aw.HRIRManager()
+    sp = mgr.activatePreset(os.path.join(golden_dir, "hrtf", wavname), 48000.0, layout)
+    assert mgr.isReady and sp.info()["path"] == 0 and sp.info()["hop"] == 8192 - 4319
+    x = oracle.synth_input(1, int(g["frames"]), len(layout.channels), seed=int(g["seed"]))
+    y = sp.process(x)
+    assert not np.isnan(y).any()
+    for ear in range(2):
+        assert oracle.peak_rel_error(y[0, :, ear], g["expected"][:, ear]) < TOL
+
+
+def test_custom_14ch_text_map(aw, oracle, golden_dir):
+    g = load(golden_dir, "cfg3_stage_14ch_custom.npz")
+    cmap = aw.HRIRChannelMap.parseHeSuViFormat(open(os.path.join(golden_dir, "hesuvi14_custom_map.txt")).read())
+    sp = aw.HRIRManager().activatePreset(os.path.join(golden_dir, "hrtf", "StageSH1.0.wav"), 48000.0,
+                                        aw.InputLayout.detect(14), hrirMap=cmap)
+    x = oracle.synth_input(1, int(g["frames"]), 14, seed=int(g["seed"]))
+    assert oracle.peak_rel_error(sp.process(x)[0], g["expected"]) < TOL
+
+
+@pytest.mark.parametrize("channels", [1, 2, 3, 5, 6, 7, 8, 12])
+def test_every_channel_count_matches_f32_oracle_and_truth(aw, oracle, golden_dir, channels):
+    w = wav(oracle, golden_dir, "RoomSH1.0.wav")
+    spk = oracle.layout_detect(channels)
+    if channels in (1, 3, 5, 7):
+        spk = oracle.layout_detect(8)[:channels]
+    tracks, lt, rt = oracle.assemble_tracks(w, spk)
+    frames = 9000
+    x = oracle.synth_input(2, frames, channels, seed=77)
+    sp = aw.Spatializer(aw.HRIR(tracks), lt, rt, n_streams=2)
+    y = sp.process(x)
+    yo = oracle.spatialize_f32(x, tracks, lt, rt)
+    for s in range(2):
+        ref = oracle.spatialize_f64(x[s], tracks, lt, rt)
+        assert oracle.peak_rel_error(y[s], ref) < TOL
+        assert oracle.peak_rel_error(y[s], yo[s]) < TOL
+
+
+@pytest.mark.parametrize("taps", [1, 2, 511, 512, 513, 4097, 6145])
+def test_hrir_lengths_on_the_fused_path(aw, oracle, taps):
+    h = oracle.synth_hrir(4, taps, seed=taps)
+    x = oracle.synth_input(1, 2 * (8192 - taps + 1) + 5, 2, seed=9)
+    sp = aw.Spatializer(aw.HRIR(h), [0, 2], [1, 3])
+    assert sp.info()["path"] == 0 and sp.info()["hop"] == 8192 - (taps - 1)
+    y = sp.process(x)
+    ref = oracle.spatialize_f64(x[0], h, [0, 2], [1, 3])
+    assert oracle.peak_rel_error(y[0], ref) < TOL
+
+
+def test_ragged_call_sizes_carry_state_exactly(aw, oracle, golden_dir):
+    """Any split of the timeline into calls gives the same samples as one call: the tail state is
+    carried like consecutive ConvolutionEngine.process calls (overlap + FDL, ConvolutionEngine.swift:237-264)."""
+    w = wav(oracle, golden_dir, "NeutralSH1.0.wav")
+    tracks, lt, rt = oracle.assemble_tracks(w, ["FL", "FR"])
+    x = oracle.synth_input(3, 12000, 2, seed=5)
+    hrir = aw.HRIR(tracks)
+    whole = aw.Spatializer(hrir, lt, rt, n_streams=3).process(x)
+    sp = aw.Spatializer(hrir, lt, rt, n_streams=3)
+    parts, pos = [], 0
+    for n in [1, 7, 512, 3873, 3874, 100, 2000, 1633]:
+        parts.append(sp.process(np.ascontiguousarray(x[:, pos:pos + n])))
+        pos += n
+    assert pos == 12000
+    chunked = np.concatenate(parts, axis=1)
+    assert np.max(np.abs(chunked - whole)) <= 2e-6 * np.abs(whole).max()
+    ref = oracle.spatialize_f64(x[1], tracks, lt, rt)
+    assert oracle.peak_rel_error(chunked[1], ref) < TOL
+    # reset() == fresh engine (ConvolutionEngine.swift:397-407)
+    sp.reset()
+    again = sp.process(np.ascontiguousarray(x[:, :5000]))
+    assert np.max(np.abs(again - whole[:, :5000])) <= 2e-6 * np.abs(whole).max()
+
+
+def test_unmapped_channels_are_skipped_and_errors_match(aw, oracle):
+    h = oracle.synth_hrir(4, 100, seed=1)
+    hrir = aw.HRIR(h)
+    x = oracle.synth_input(1, 3000, 3, seed=3)
+    y = aw.Spatializer(hrir, [0, -1, 2], [1, -1, 3]).process(x)          # HRIRManager.swift:370-372
+    ref = oracle.spatialize_f64(x[0], h, [0, -1, 2], [1, -1, 3])
+    assert oracle.peak_rel_error(y[0], ref) < TOL
+    with pytest.raises(aw.HRIRError) as e:
+        aw.Spatializer(hrir, [0, 4], [1, 2])                             # :375-379
+    assert e.value.name == "INVALID_CHANNEL_MAPPING"
+    with pytest.raises(aw.HRIRError) as e:
+        aw.Spatializer(hrir, [-1, -1], [-1, -1])                         # :420-422
+    assert e.value.name == "CONVOLUTION_SETUP_FAILED"
+
+
+def test_planar_plugin_entry_and_passthrough(aw, oracle, golden_dir):
+    mgr = aw.HRIRManager()
+    l = oracle.synth_input(1, 700, 1, seed=1)[0, :, 0]
+    r = oracle.synth_input(1, 700, 1, seed=2)[0, :, 0]
+    pl, pr = mgr.process(l, r)                                           # passthrough, HRIRManager.swift:550-559
+    assert np.array_equal(pl, l) and np.array_equal(pr, r)
+    ml, mr = mgr.process(l, None)
+    assert np.array_equal(ml, l) and np.array_equal(mr, l)
+    mgr.activatePreset(os.path.join(golden_dir, "hrtf", "NeutralSH1.0.wav"), 48000.0, aw.InputLayout.detect(2))
+    w = wav(oracle, golden_dir, "NeutralSH1.0.wav")
+    tracks, lt, rt = oracle.assemble_tracks(w, ["FL", "FR"])
+    ol, orr = mgr.process(l, r)
+    ref = oracle.spatialize_f64(np.stack([l, r], 1), tracks, lt, rt)
+    assert oracle.peak_rel_error(np.stack([ol, orr], 1), ref) < TOL
+    mgr.resetConvolutionState()
+    ol2, orr2 = mgr.process(l, None)                                     # mono duplication
+    ref2 = oracle.spatialize_f64(np.stack([l, l], 1), tracks, lt, rt)
+    assert oracle.peak_rel_error(np.stack([ol2, orr2], 1), ref2) < TOL
+
+
+def test_resampled_hrir_activation(aw, oracle, golden_dir):
+    # cfg 4/5: HRIR resampled to the device rate (HRIRManager.swift:389-403)
+    w = wav(oracle, golden_dir, "StageSH1.0.wav")
+    for rate in (44100.0, 96000.0):
+        sp = aw.HRIRManager().activatePreset(os.path.join(golden_dir, "hrtf", "StageSH1.0.wav"), rate, aw.InputLayout.detect(2))
+        tracks, lt, rt = oracle.assemble_tracks(w, ["FL", "FR"], target_rate=rate)
+        x = oracle.synth_input(1, 6000, 2, seed=4)
+        if sp.info()["path"] != 0:
+            pytest.skip("partitioned path")
+        ref = oracle.spatialize_f64(x[0], tracks, lt, rt)
+        assert oracle.peak_rel_error(sp.process(x)[0], ref) < TOL
+
+
+def test_device_synth_fill_is_the_oracle_generator(aw, oracle):
+    ctx = aw.default_context()
+    S, F, C = 3, 1000, 7
+    d = ctx.alloc(S * F * C * 4)
+    ctx.synth_fill(d, S, F, C, seed=oracle.SYNTH_SEED, first_stream=5)
+    got = np.zeros((S, F, C), dtype=np.float32)
+    ctx.d2h(got, d)
+    ctx.free(d)
+    assert np.array_equal(got, oracle.synth_input(S, F, C, seed=oracle.SYNTH_SEED, first_stream=5))
+
+
+def test_full_size_properties_cfg2(aw, oracle, golden_dir):
+    """BASELINE cfg 2 at full size (128 streams x 10 s x 8 ch) through device buffers:
+    (a) sampled streams match the float64 truth on a window, (b) linearity: spatialize(a*x) == a*spatialize(x),
+    (c) every stream is processed (checksum of checksums vs per-stream recomputation of 4 streams)."""
+    import torch
+    S, F, C = 128, 480000, 8
+    ctx = aw.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    w = wav(oracle, golden_dir, "RoomSH1.0.wav")
+    tracks, lt, rt = oracle.assemble_tracks(w, oracle.layout_detect(8))
+    sp = aw.Spatializer(aw.HRIR(tracks, ctx=ctx), lt, rt, n_streams=S, ctx=ctx)
+    x = torch.empty((S, F, C), dtype=torch.float32, device="cuda")
+    ctx.synth_fill(x.data_ptr(), S, F, C, seed=oracle.SYNTH_SEED)
+    y = torch.empty((S, F, 2), dtype=torch.float32, device="cuda")
+    sp.process_device(x.data_ptr(), y.data_ptr(), F)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    # (a) truth on the first 12000 frames and on the last 3000 frames of three streams
+    for s in (0, 63, 127):
+        xs = x[s, :12000].cpu().numpy()
+        assert np.array_equal(xs, oracle.synth_input(1, 12000, C, first_stream=s)[0])
+        ref = oracle.spatialize_f64(xs, tracks, lt, rt)
+        assert oracle.peak_rel_error(y[s, :12000].cpu().numpy(), ref) < TOL
+        tail_in = x[s, F - 3000 - 4319:].cpu().numpy()
+        ref_tail = oracle.spatialize_f64(tail_in, tracks, lt, rt)[4319:]
+        assert oracle.peak_rel_error(y[s, F - 3000:].cpu().numpy(), ref_tail) < TOL
+    # (b) linearity on the whole batch
+    sp.reset()
+    x.mul_(-0.5)
+    y2 = torch.empty_like(y)
+    sp.process_device(x.data_ptr(), y2.data_ptr(), F)
+    torch.cuda.synchronize()
+    peak = float(y.abs().max())
+    assert float((y2 + 0.5 * y).abs().max()) <= 2e-6 * peak
+    # (c) per-stream energy is non-trivial everywhere (no stream skipped or duplicated)
+    e = (y.double() ** 2).sum(dim=(1, 2))
+    assert float(e.min()) > 0.25 * float(e.max())
+    assert len(set(np.round(e.cpu().numpy(), 6).tolist())) == S
