@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# PyTorch-ROCm bundles its own HIP runtime; when both live in one process torch must be loaded
+# first (INTEGRATION.md "Coexisting with PyTorch").  Tests use torch only for device tensors.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
