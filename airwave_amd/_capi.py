@@ -8,7 +8,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libairwave_hip.so")
+LIB_PATH = os.environ.get("AIRWAVE_HIP_LIBRARY") or os.path.join(HERE, "libairwave_hip.so")
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
@@ -47,6 +47,7 @@ SIGNATURES = {
     "aw_spatializer_info": (_I64, [_V, _I32]),
     "aw_spatializer_set_profiling": (_I32, [_V, _I32]),
     "aw_spatializer_kernel_time": (_I32, [_V, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_char_p)]),
+    "aw_spatializer_debug_stamps": (_I32, [_V, ctypes.POINTER(ctypes.c_uint64), _I64, ctypes.POINTER(ctypes.c_int64)]),
     "aw_engine_create": (_I32, [_V, c_float_p, _I32, _I32, c_void_pp]),
     "aw_engine_destroy": (None, [_V]),
     "aw_engine_process": (_I32, [_V, c_float_p, c_float_p]),

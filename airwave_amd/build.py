@@ -43,11 +43,22 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, stamps: bool = False, defines=(), suffix: str = "") -> str:
+    """stamps=True builds the DIAGNOSTIC variant (phase time stamps, -DAW_STAMPS=1) as
+    libairwave_hip_stamps.so; `defines` + `suffix` build tuning variants (libairwave_hip_<suffix>.so)
+    for A/B runs.  Variants are never loaded unless AIRWAVE_HIP_LIBRARY points at them."""
+    global OUT, OBJ
+    defines = list(defines)
+    if stamps:
+        suffix = suffix or "stamps"
+        defines.append("AW_STAMPS=1")
+    if suffix:
+        OUT = os.path.join(HERE, f"libairwave_hip_{suffix}.so")
+        OBJ = os.path.join(HERE, f"_build_{suffix}")
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     common = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"--offload-arch={ARCH}",
-              "-Wall", "-Wno-unused-result", "-ffp-contract=fast"]
+              "-Wall", "-Wno-unused-result", "-ffp-contract=fast"] + [f"-D{d}" for d in defines]
     objs = []
     for src in SOURCES:
         spath = os.path.join(CSRC, src)
@@ -67,4 +78,6 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    sfx = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--suffix=")), "")
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, stamps="--stamps" in sys.argv, defines=defs, suffix=sfx))

@@ -7,14 +7,53 @@
 
 namespace awk {
 
+#ifndef AW_STAGGER_SLOTS
+#define AW_STAGGER_SLOTS 0       // s_sleep argument (x64 cycles) for waves 4-7 after a barrier; 0 = off
+#endif
+#ifndef AW_STAMPS
+#define AW_STAMPS 0
+#endif
+
 struct GpuCtx {
     cf *lds_;
+    unsigned long long *dbg_;
+    // Phase stamps (diagnostic build only: -DAW_STAMPS=1; never in the shipped kernel).  Thread 0
+    // of the workgroup records s_memtime into a buffer nothing else reads.
+    __device__ __forceinline__ void stamp(int i) const {
+#if AW_STAMPS
+        if (threadIdx.x == 0 && dbg_) {
+            unsigned long long tm;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm)::"memory");
+            dbg_[i] = tm;
+        }
+#else
+        (void)i;
+#endif
+    }
     __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
     __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
     // wave id as a provably wave-uniform (SGPR) value: row bases become scalar
     __device__ __forceinline__ int wave() const { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
     __device__ __forceinline__ cf *lds() const { return lds_; }
     __device__ __forceinline__ void barrier() const { __syncthreads(); }
+    // Phase offset between the two waves of each SIMD (waves w and w+4): the younger half idles a
+    // little after a barrier so that its LDS-exchange phases fall into the older half's butterfly
+    // phases instead of colliding with them (MI355X_MICROARCH "Two waves per SIMD", item 9).
+    __device__ __forceinline__ void stagger(int wave, int slots) const {
+        (void)slots;
+#if AW_STAGGER_SLOTS > 0
+        // one opaque asm statement: a real branch here splits the block and wrecks register allocation
+        asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 1f\n\ts_sleep %1\n1:" ::"s"(wave), "n"(AW_STAGGER_SLOTS) : "scc");
+#else
+        (void)wave;
+#endif
+    }
+    // Hides a value's provenance from the optimiser (no instruction emitted): stops LICM/CSE from
+    // keeping re-computable values live across the whole tile.
+    __device__ __forceinline__ cf opaque(cf v) const {
+        asm volatile("" : "+v"(v.x), "+v"(v.y));
+        return v;
+    }
     // Exchanges inside one wave need no s_barrier: a wave's LDS instructions execute in issue
     // order.  The fences only stop the compiler from moving LDS accesses across the exchange.
     __device__ __forceinline__ void wave_sync() const {
@@ -33,31 +72,43 @@ __device__ __forceinline__ long long xcd_remap(long long bid, long long nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int CS>
+template <int CS, int NP>
 __global__ void __launch_bounds__(kThreads) aw_fused_ols_kernel(TileParams p, long long nwg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    GpuCtx ctx{reinterpret_cast<cf *>(smem)};
+    GpuCtx ctx{reinterpret_cast<cf *>(smem), p.dbg ? p.dbg + (long long)blockIdx.x * kStamps : nullptr};
     const long long id = xcd_remap((long long)blockIdx.x, nwg);
     const long long stream = id / p.tiles_per_stream;
     const int tile = (int)(id % p.tiles_per_stream);
-    tile_fused_ols<GpuCtx, CS>(ctx, p, stream, tile);
+    tile_fused_ols<GpuCtx, CS, NP>(ctx, p, stream, tile);
 }
 
+// Variants: <CS, NP> = <vector-load channel count or 0, compile-time pair count or 0 (generic)>
+#define AW_FOR_EACH_VARIANT(X) X(8, 4) X(2, 1) X(4, 2) X(0, 4) X(0, 2) X(0, 0)
+
 hipError_t prepare_kernels() {
-    hipError_t e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<0>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<8>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    hipError_t e = hipSuccess;
+#define AW_SET_ATTR(CS, NP)                                                                          \
+    if (e == hipSuccess)                                                                             \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<CS, NP>),        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    AW_FOR_EACH_VARIANT(AW_SET_ATTR)
+#undef AW_SET_ATTR
     return e;
 }
 
+static int pick_variant(int C) {       // index into the variant list above
+    if (C == 8) return 0;
+    if (C == 2) return 1;
+    if (C == 4) return 2;
+    if (C == 7) return 3;
+    if (C == 3) return 4;
+    return 5;
+}
+
 const char *fused_ols_kernel_name(int n_channels) {
-    return n_channels == 8 ? "aw_fused_ols_kernel<8>" : n_channels == 2 ? "aw_fused_ols_kernel<2>" : "aw_fused_ols_kernel<0>";
+    static const char *names[] = {"aw_fused_ols_kernel<8, 4>", "aw_fused_ols_kernel<2, 1>", "aw_fused_ols_kernel<4, 2>",
+                                  "aw_fused_ols_kernel<0, 4>", "aw_fused_ols_kernel<0, 2>", "aw_fused_ols_kernel<0, 0>"};
+    return names[pick_variant(n_channels)];
 }
 
 hipError_t launch_fused_ols(const TileParams &p, int n_streams, hipStream_t stream) {
@@ -65,12 +116,14 @@ hipError_t launch_fused_ols(const TileParams &p, int n_streams, hipStream_t stre
     if (nwg <= 0) return hipSuccess;
     if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
     const dim3 grid((unsigned)nwg), block(kThreads);
-    if (p.n_channels == 8)
-        hipLaunchKernelGGL(aw_fused_ols_kernel<8>, grid, block, kLdsBytes, stream, p, nwg);
-    else if (p.n_channels == 2)
-        hipLaunchKernelGGL(aw_fused_ols_kernel<2>, grid, block, kLdsBytes, stream, p, nwg);
-    else
-        hipLaunchKernelGGL(aw_fused_ols_kernel<0>, grid, block, kLdsBytes, stream, p, nwg);
+    switch (pick_variant(p.n_channels)) {
+        case 0: hipLaunchKernelGGL((aw_fused_ols_kernel<8, 4>), grid, block, kLdsBytes, stream, p, nwg); break;
+        case 1: hipLaunchKernelGGL((aw_fused_ols_kernel<2, 1>), grid, block, kLdsBytes, stream, p, nwg); break;
+        case 2: hipLaunchKernelGGL((aw_fused_ols_kernel<4, 2>), grid, block, kLdsBytes, stream, p, nwg); break;
+        case 3: hipLaunchKernelGGL((aw_fused_ols_kernel<0, 4>), grid, block, kLdsBytes, stream, p, nwg); break;
+        case 4: hipLaunchKernelGGL((aw_fused_ols_kernel<0, 2>), grid, block, kLdsBytes, stream, p, nwg); break;
+        default: hipLaunchKernelGGL((aw_fused_ols_kernel<0, 0>), grid, block, kLdsBytes, stream, p, nwg); break;
+    }
     return hipGetLastError();
 }
 

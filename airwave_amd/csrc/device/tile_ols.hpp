@@ -29,7 +29,8 @@
 //                         the inverse sub-FFT never leave the wave.
 //   inverse             : mirror image; last pass is the radix-16 across rows, so thread t
 //                         ends with output samples t + 512 j: coalesced stores.
-// One workgroup barrier per pair FFT (+1 for the inverse); LDS = 2 x [16][576] complex.
+// Two workgroup barriers per batch of two pairs (+1 for the inverse); LDS = 2 x [16][576]
+// complex exchange buffers + 4.5 KiB of sub-FFT twiddles.
 #pragma once
 #include "cplx.hpp"
 
@@ -41,7 +42,18 @@ constexpr int kRows = 16;         // radix of pass 1
 constexpr int kSub = 512;         // sub-FFT length = kN / kRows = kThreads
 constexpr int kRowStride = 576;   // complex elements per LDS row (512 + room for padded exchanges)
 constexpr int kBufElems = kRows * kRowStride;          // one exchange buffer
-constexpr int kLdsBytes = 2 * kBufElems * 8;           // 147456 B (<= 160 KiB)
+constexpr int kTwaElems = 8 * 64;                      // [ka][lane]  W_512^{lane ka}
+constexpr int kTwbElems = 8 * 8;                       // [kb][l0]    W_64^{l0 kb}
+constexpr int kLdsElems = 2 * kBufElems + kTwaElems + kTwbElems;
+constexpr int kLdsBytes = kLdsElems * 8;               // 152064 B (<= 160 KiB)
+#ifndef AW_PREFETCH_RAW_EARLY
+#define AW_PREFETCH_RAW_EARLY 0
+#endif
+constexpr bool kPrefetchRawEarly = AW_PREFETCH_RAW_EARLY != 0;
+#ifndef AW_TAB_EARLY
+#define AW_TAB_EARLY 0
+#endif
+constexpr bool kTabEarly = AW_TAB_EARLY != 0;                      // issue a pair's table loads before its sub-FFTs   // issue the next batch's frame loads before pair 1's sub-FFTs
 constexpr int kBatchCh = 4;       // input channels held in registers at once (two pairs)
 
 struct alignas(16) cf2 {          // one table entry: A[k], B[k]
@@ -53,16 +65,19 @@ struct TileParams {
     float *out;             // [stream][frames][2]
     const float *hist;      // [stream][hist_len][C]: the hist_len frames preceding in[...][0]
     const cf2 *tab;         // [pair][16][512] {A,B}, index k = k1 + 16 k2 stored at [k1][k2]
-    const cf *tw1;          // [512][16]: W_N^{t k1}      (pass-1 twiddles, one 128-B row per thread)
-    const cf *twa;          // [64][8]  : W_512^{lane ka} (sub-FFT pass A)
-    const cf *twb;          // [8][8]   : W_64^{l0 kb}    (sub-FFT pass B)
+    const cf *tw1;          // [512]  : W_N^t (pass-1 twiddle base; powers are formed in registers)
+    const cf *twa;          // [8][64]: W_512^{lane ka}, ka-major (sub-FFT pass A)
+    const cf *twb;          // [8][8] : W_64^{l0 kb}, kb-major   (sub-FFT pass B)
     long long frames;       // frames per stream in this call
     int n_channels;         // C
     int n_pairs;            // ceil(C / 2)
     int hop;                // new output frames per tile, hop <= N - (taps - 1)
     int hist_len;           // = N - hop
     int tiles_per_stream;   // ceil(frames / hop)
+    int stagger;            // tuning: waves 4-7 idle this many 64-cycle slots after each barrier (phase offset)
+    unsigned long long *dbg; // diagnostic builds only (AW_STAMPS): [workgroup][16] s_memtime stamps of wave 0
 };
+constexpr int kStamps = 16;
 
 // ---- per-wave ownership of rows -------------------------------------------------------------
 AW_HD int wave_row(int wave, int slot) {
@@ -70,41 +85,67 @@ AW_HD int wave_row(int wave, int slot) {
     return wave == 0 ? (slot == 0 ? 0 : 8) : (slot == 0 ? wave : 16 - wave);
 }
 
-// 512-point DFT over the lane dimension, one row held as a[j] = row[lane + 64 j].
-// On return a[kc] = X[lane + 64 kc].  `scr` points at this row's private 576-element scratch.
+// w^1 .. w^15 from w by a depth-4 product tree (no memory, 14 complex multiplies)
+AW_HD void tw_powers(cf w, cf (&pw)[16]) {
+    pw[0] = mk(1.f, 0.f);
+    pw[1] = w;
+    pw[2] = cmul(w, w);
+    pw[3] = cmul(pw[2], w);
+    pw[4] = cmul(pw[2], pw[2]);
+    pw[5] = cmul(pw[4], w);
+    pw[6] = cmul(pw[4], pw[2]);
+    pw[7] = cmul(pw[4], pw[3]);
+    pw[8] = cmul(pw[4], pw[4]);
+    pw[9] = cmul(pw[8], w);
+    pw[10] = cmul(pw[8], pw[2]);
+    pw[11] = cmul(pw[8], pw[3]);
+    pw[12] = cmul(pw[8], pw[4]);
+    pw[13] = cmul(pw[8], pw[5]);
+    pw[14] = cmul(pw[8], pw[6]);
+    pw[15] = cmul(pw[8], pw[7]);
+}
+
+// Two 512-point DFTs over the lane dimension at once (the wave's two rows; independent work
+// interleaved for ILP).  Row s is held as a[s][j] = row_s[lane + 64 j]; on return
+// a[s][kc] = X_s[lane + 64 kc].  scr0/scr1: the rows' private 576-element scratch.
 template <bool INV, class Ctx>
-AW_HD void sub_fft512(Ctx &ctx, cf (&a)[8], cf *scr, const TileParams &p, int lane) {
+AW_HD void sub_fft512x2(Ctx &ctx, cf (&a)[2][8], cf *scr0, cf *scr1, const cf *twa, const cf *twb, int lane) {
     // pass A: radix-8 over j -> ka, twiddle W_512^{lane ka}
-    fft8<INV>(a);
-    {
-        const cf *w = p.twa + lane * 8;
+    fft8<INV>(a[0]);
+    fft8<INV>(a[1]);
 #pragma unroll
-        for (int ka = 1; ka < 8; ++ka) a[ka] = twmul<INV>(a[ka], w[ka]);
+    for (int ka = 1; ka < 8; ++ka) {
+        const cf w = twa[ka * 64 + lane];
+        a[0][ka] = twmul<INV>(a[0][ka], w);
+        a[1][ka] = twmul<INV>(a[1][ka], w);
     }
     // exchange A: write [ka][lane] (row stride 72), read [ka'][l0' + 8 l1] with lane = l0' + 8 ka'
 #pragma unroll
-    for (int ka = 0; ka < 8; ++ka) scr[ka * 72 + lane] = a[ka];
+    for (int ka = 0; ka < 8; ++ka) { scr0[ka * 72 + lane] = a[0][ka]; scr1[ka * 72 + lane] = a[1][ka]; }
     ctx.wave_sync();
     const int l0 = lane & 7, kap = lane >> 3;
 #pragma unroll
-    for (int l1 = 0; l1 < 8; ++l1) a[l1] = scr[kap * 72 + l0 + 8 * l1];
+    for (int l1 = 0; l1 < 8; ++l1) { a[0][l1] = scr0[kap * 72 + l0 + 8 * l1]; a[1][l1] = scr1[kap * 72 + l0 + 8 * l1]; }
     ctx.wave_sync();
     // pass B: radix-8 over l1 -> kb, twiddle W_64^{l0 kb}
-    fft8<INV>(a);
-    {
-        const cf *w = p.twb + l0 * 8;
+    fft8<INV>(a[0]);
+    fft8<INV>(a[1]);
 #pragma unroll
-        for (int kb = 1; kb < 8; ++kb) a[kb] = twmul<INV>(a[kb], w[kb]);
+    for (int kb = 1; kb < 8; ++kb) {
+        const cf w = twb[kb * 8 + l0];
+        a[0][kb] = twmul<INV>(a[0][kb], w);
+        a[1][kb] = twmul<INV>(a[1][kb], w);
     }
     // exchange B: chunk (kb, ka') of 8 (+1 pad) elements indexed by l0; read by lane = ka'' + 8 kb''
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) scr[(kb * 8 + kap) * 9 + l0] = a[kb];
+    for (int kb = 0; kb < 8; ++kb) { scr0[(kb * 8 + kap) * 9 + l0] = a[0][kb]; scr1[(kb * 8 + kap) * 9 + l0] = a[1][kb]; }
     ctx.wave_sync();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = scr[lane * 9 + i];      // chunk index kb''*8 + ka'' == lane
+    for (int i = 0; i < 8; ++i) { a[0][i] = scr0[lane * 9 + i]; a[1][i] = scr1[lane * 9 + i]; }   // chunk kb''*8 + ka'' == lane
     ctx.wave_sync();
-    // pass C: radix-8 over l0 -> kc.  Now a[kc] = X[ka'' + 8 kb'' + 64 kc] = X[lane + 64 kc]
-    fft8<INV>(a);
+    // pass C: radix-8 over l0 -> kc.  Now a[s][kc] = X_s[ka'' + 8 kb'' + 64 kc] = X_s[lane + 64 kc]
+    fft8<INV>(a[0]);
+    fft8<INV>(a[1]);
 }
 
 // ---- the tile ----------------------------------------------------------------------------------
@@ -141,76 +182,103 @@ AW_HD void load_frame(const TileParams &p, const float *in_s, const float *hist_
     }
 }
 
-// pass 1 of one pair: radix-16 over the thread's 16 window samples, twiddle, scatter to rows.
-template <class Ctx>
-AW_HD void pair_pass1(const TileParams &p, cf (&x)[16], cf *buf, int t) {
-    fft16<false>(x);
-    {
-        const cf *w = p.tw1 + t * 16;
+// Register batch: 16 frames x 4 channels (two pairs) per thread.
+template <int CS>
+AW_HD void load_batch(const TileParams &p, const float *in_s, const float *hist_s, long long f0, int t, int c0,
+                      float (&raw)[16][kBatchCh]) {
+#ifdef AW_ABL_NORAW      // timing ablation only (wrong results): no input traffic
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) x[k1] = cmul(x[k1], w[k1]);
-    }
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int c = 0; c < kBatchCh; ++c) raw[j][c] = 0.001f * (t + j) + c0 + c + (float)f0;
+    return;
+#endif
+#pragma unroll
+    for (int j = 0; j < 16; ++j) load_frame<CS>(p, in_s, hist_s, f0 + t + 512 * j, raw[j], c0);
+}
+
+// pass 1 of one pair: radix-16 over the thread's 16 window samples, twiddle, scatter to rows.
+AW_HD void pair_pass1(cf (&x)[16], const cf (&pw)[16], cf *buf, int t) {
+    fft16<false>(x);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) x[k1] = cmul(x[k1], pw[k1]);
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) buf[k1 * kRowStride + t] = x[k1];
 }
 
+// This lane's 16 table entries of one pair (issued early; consumed after the sub-FFTs).
+AW_HD void load_tab(const TileParams &p, int pair, int wave, int lane, cf2 (&tab)[2][8]) {
+#ifdef AW_ABL_NOTAB      // timing ablation only (wrong results): no table traffic
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) { tab[s][kc].a = mk(1.0f + pair, 0.5f * lane); tab[s][kc].b = mk(0.25f * kc, 1.0f * wave); }
+    return;
+#endif
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const cf2 *row = p.tab + ((long long)pair * kN + wave_row(wave, s) * kSub + lane);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) tab[s][kc] = row[64 * kc];
+    }
+}
+
 // Per wave: the two 512-point sub-FFTs of its rows, then W += Z A + conj(Z[N-k]) B.
 template <class Ctx>
-AW_HD void pair_subfft_cmac(Ctx &ctx, const TileParams &p, cf *buf, int pair, int lane, int wave, cf (&wacc)[2][8]) {
+AW_HD void pair_subfft_cmac(Ctx &ctx, const TileParams &p, int pair, cf *buf, const cf *twa, const cf *twb,
+                            cf2 (&tab)[2][8], int lane, int wave, cf (&wacc)[2][8]) {
+    cf *row0 = buf + wave_row(wave, 0) * kRowStride;
+    cf *row1 = buf + wave_row(wave, 1) * kRowStride;
     cf z[2][8];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        cf *row = buf + wave_row(wave, s) * kRowStride;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) z[s][j] = row[lane + 64 * j];
-    }
+    for (int j = 0; j < 8; ++j) { z[0][j] = row0[lane + 64 * j]; z[1][j] = row1[lane + 64 * j]; }
     ctx.wave_sync();
-#pragma unroll
-    for (int s = 0; s < 2; ++s) sub_fft512<false>(ctx, z[s], buf + wave_row(wave, s) * kRowStride, p, lane);
+    sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
+    if (!kTabEarly) load_tab(p, pair, wave, lane, tab);
     // publish Z rows inside the wave, then CMAC against the partner bins
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        cf *row = buf + wave_row(wave, s) * kRowStride;
-#pragma unroll
-        for (int kc = 0; kc < 8; ++kc) row[lane + 64 * kc] = z[s][kc];
-    }
+    for (int kc = 0; kc < 8; ++kc) { row0[lane + 64 * kc] = z[0][kc]; row1[lane + 64 * kc] = z[1][kc]; }
     ctx.wave_sync();
-    const cf2 *tab = p.tab + (long long)pair * kN;
+    // partner of bin (k1, k2): row (16 - k1) & 15 (the wave's other row; itself for k1 in {0, 8}),
+    // column (512 - k2) & 511 for k1 == 0, else 511 - k2.
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const int k1 = wave_row(wave, s);
+        const cf *prow = (wave == 0) ? (s == 0 ? row0 : row1) : (s == 0 ? row1 : row0);
+        const int bidx = 511 - lane + ((wave == 0 && s == 0) ? 1 : 0);
 #pragma unroll
         for (int kc = 0; kc < 8; ++kc) {
-            const int k2 = lane + 64 * kc;
-            const int k = k1 + 16 * k2;
-            const int kk = (kN - k) & (kN - 1);
-            const cf zp = buf[(kk & 15) * kRowStride + (kk >> 4)];
-            const cf2 ab = tab[k1 * kSub + k2];
-            wacc[s][kc] = cfma(z[s][kc], ab.a, wacc[s][kc]);
-            wacc[s][kc] = cfmac(zp, ab.b, wacc[s][kc]);
+            int idx = bidx - 64 * kc;
+            if (kc == 0) idx &= 511;                       // only (row 0, lane 0, kc 0) wraps: 512 -> 0
+            const cf zp = prow[idx];
+            wacc[s][kc] = cfma(z[s][kc], tab[s][kc].a, wacc[s][kc]);
+            wacc[s][kc] = cfmac(zp, tab[s][kc].b, wacc[s][kc]);
         }
     }
     ctx.wave_sync();    // partner reads done before this wave reuses its rows as scratch
 }
 
-// Register batch: 16 frames x 4 channels (two pairs) per thread.
-template <int CS>
-AW_HD void load_batch(const TileParams &p, const float *in_s, const float *hist_s, long long f0, int t, int c0,
-                      float (&raw)[16][kBatchCh]) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) load_frame<CS>(p, in_s, hist_s, f0 + t + 512 * j, raw[j], c0);
-}
-
-template <class Ctx, int CS>
+// NP: compile-time pair count (straight-line schedule, no phis around the prefetches); NP = 0 is
+// the generic variant: a runtime loop over batches that always processes two pairs (a phantom
+// pair has all-zero input, so whatever table it multiplies contributes nothing).
+template <class Ctx, int CS, int NP>
 AW_HD void tile_fused_ols(Ctx &ctx, const TileParams &p, long long stream, int tile) {
     const int t = ctx.tid();
     const int lane = ctx.lane(), wave = ctx.wave();
     cf *buf0 = ctx.lds();
+    cf *buf1 = buf0 + kBufElems;
+    cf *twa = buf1 + kBufElems;        // LDS copies of the sub-FFT twiddles
+    cf *twb = twa + kTwaElems;
     const int Cn = CS > 0 ? CS : p.n_channels;
     const float *in_s = p.in + stream * p.frames * Cn;
     const float *hist_s = p.hist + stream * (long long)p.hist_len * Cn;
-    cf *buf1 = buf0 + kBufElems;
     const long long f0 = (long long)tile * p.hop - p.hist_len;     // frame of window position 0
+
+    ctx.stamp(0);
+    float raw[16][kBatchCh];
+    load_batch<CS>(p, in_s, hist_s, f0, t, 0, raw);
+    const cf w1 = p.tw1[t];
+    twa[t] = p.twa[t];                                   // 512 entries, one per thread
+    if (t < kTwbElems) twb[t] = p.twb[t];                // visible after the first barrier below
 
     cf wacc[2][8];
 #pragma unroll
@@ -218,53 +286,69 @@ AW_HD void tile_fused_ols(Ctx &ctx, const TileParams &p, long long stream, int t
 #pragma unroll
         for (int i = 0; i < 8; ++i) wacc[s][i] = mk(0.f, 0.f);
 
-    // Schedule per batch of two pairs (4 barriers per tile at C = 8):
-    //   pass 1 of both pairs -> buf0, buf1 ; issue the NEXT batch's global loads (their latency
-    //   hides under the sub-FFTs; the lines were touched by this batch a moment ago: L2 hits) ;
-    //   barrier ; per-wave sub-FFTs + CMAC on buf0 then buf1.
-    float raw[16][kBatchCh];
-    load_batch<CS>(p, in_s, hist_s, f0, t, 0, raw);
-    for (int pair0 = 0; pair0 < p.n_pairs; pair0 += 2) {
-        const bool two = pair0 + 1 < p.n_pairs;          // uniform across the workgroup
+    // Schedule per batch of two pairs:
+    //   pass 1 of both pairs -> buf0, buf1 ; issue pair 0's table loads ; barrier ;
+    //   sub-FFTs + CMAC of pair 0 ; issue pair 1's table loads and the NEXT batch's frame loads
+    //   (their latency hides under pair 1's sub-FFTs) ; sub-FFTs + CMAC of pair 1.
+    const int n_pairs = NP > 0 ? NP : p.n_pairs;
+    auto batch = [&](int pair0, bool two, bool more) {
         if (pair0 > 0) ctx.barrier();                    // every wave is done reading buf0/buf1
+        ctx.stamp(pair0 > 0 ? 6 : 1);
         {
+            cf pw[16];
+            tw_powers(ctx.opaque(w1), pw);       // opaque: keep the 15 powers out of long-lived registers
             cf x[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][0], raw[j][1]);
-            pair_pass1<Ctx>(p, x, buf0, t);
-        }
-        if (two) {
-            cf x[16];
+            pair_pass1(x, pw, buf0, t);
+            if (two) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][2], raw[j][3]);
-            pair_pass1<Ctx>(p, x, buf1, t);
+                for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][2], raw[j][3]);
+                pair_pass1(x, pw, buf1, t);
+            }
         }
-        if (pair0 + 2 < p.n_pairs) load_batch<CS>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
+        cf2 tab[2][8];
+        if (kTabEarly) load_tab(p, pair0, wave, lane, tab);
+        ctx.stamp(pair0 > 0 ? 7 : 2);
         ctx.barrier();
-        pair_subfft_cmac(ctx, p, buf0, pair0, lane, wave, wacc);
-        if (two) pair_subfft_cmac(ctx, p, buf1, pair0 + 1, lane, wave, wacc);
+        ctx.stagger(wave, p.stagger);
+        ctx.stamp(pair0 > 0 ? 8 : 3);
+        pair_subfft_cmac(ctx, p, pair0, buf0, twa, twb, tab, lane, wave, wacc);
+        ctx.stamp(pair0 > 0 ? 9 : 4);
+        const int pair1 = (NP > 0 || pair0 + 1 < n_pairs) ? pair0 + 1 : pair0;   // phantom: any valid table
+        if (two && kTabEarly) load_tab(p, pair1, wave, lane, tab);
+        if (kPrefetchRawEarly && more) load_batch<CS>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
+        if (two) pair_subfft_cmac(ctx, p, pair1, buf1, twa, twb, tab, lane, wave, wacc);
+        if (!kPrefetchRawEarly && more) load_batch<CS>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
+        ctx.stamp(pair0 > 0 ? 10 : 5);
+    };
+    if constexpr (NP > 0) {
+#pragma unroll
+        for (int b = 0; b < (NP + 1) / 2; ++b) batch(2 * b, 2 * b + 1 < NP, 2 * b + 2 < NP);
+    } else {
+        for (int pair0 = 0; pair0 < n_pairs; pair0 += 2) batch(pair0, true, pair0 + 2 < n_pairs);
     }
 
     // ---- inverse: per-wave 512-point inverse sub-FFTs of W (scratch = own rows of buf0, which
     // only this wave touches until the barrier), exchange, radix-16 across rows ----
+    {
+        cf *row0 = buf0 + wave_row(wave, 0) * kRowStride;
+        cf *row1 = buf0 + wave_row(wave, 1) * kRowStride;
+        sub_fft512x2<true>(ctx, wacc, row0, row1, twa, twb, lane);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) sub_fft512<true>(ctx, wacc[s], buf0 + wave_row(wave, s) * kRowStride, p, lane);
-    // other waves may still be reading their partner rows of buf1/buf0 for the CMAC: they only
-    // read rows they own, and this wave only writes rows it owns.
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        cf *row = buf0 + wave_row(wave, s) * kRowStride;
-#pragma unroll
-        for (int kc = 0; kc < 8; ++kc) row[lane + 64 * kc] = wacc[s][kc];
+        for (int kc = 0; kc < 8; ++kc) { row0[lane + 64 * kc] = wacc[0][kc]; row1[lane + 64 * kc] = wacc[1][kc]; }
     }
+    ctx.stamp(11);
     ctx.barrier();
+    ctx.stamp(12);
     cf y[16];
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) y[k1] = buf0[k1 * kRowStride + t];
     {
-        const cf *w = p.tw1 + t * 16;
+        cf pw[16];
+        tw_powers(ctx.opaque(w1), pw);
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) y[k1] = cmulc(y[k1], w[k1]);
+        for (int k1 = 1; k1 < 16; ++k1) y[k1] = cmulc(y[k1], pw[k1]);
     }
     fft16<true>(y);
     // ---- store the valid part of the window: positions m >= N - hop, frames < p.frames ----
@@ -275,6 +359,7 @@ AW_HD void tile_fused_ols(Ctx &ctx, const TileParams &p, long long stream, int t
         if (m >= p.hist_len && f < p.frames)
             *reinterpret_cast<cf *>(p.out + ((long long)stream * p.frames + f) * 2) = y[j];
     }
+    ctx.stamp(13);
 }
 
 }  // namespace awk

@@ -34,15 +34,14 @@ static awk::cf unit(double num, double den) {   // exp(-2 pi i num / den)
 }
 
 void build_twiddles(Twiddles &tw) {
-    tw.tw1.resize(512 * 16);
-    for (int t = 0; t < 512; ++t)
-        for (int k1 = 0; k1 < 16; ++k1) tw.tw1[t * 16 + k1] = unit((double)t * k1, awk::kN);
-    tw.twa.resize(64 * 8);
-    for (int l = 0; l < 64; ++l)
-        for (int ka = 0; ka < 8; ++ka) tw.twa[l * 8 + ka] = unit((double)l * ka, 512.0);
-    tw.twb.resize(8 * 8);
-    for (int l0 = 0; l0 < 8; ++l0)
-        for (int kb = 0; kb < 8; ++kb) tw.twb[l0 * 8 + kb] = unit((double)l0 * kb, 64.0);
+    tw.tw1.resize(512);
+    for (int t = 0; t < 512; ++t) tw.tw1[t] = unit((double)t, awk::kN);
+    tw.twa.resize(awk::kTwaElems);
+    for (int ka = 0; ka < 8; ++ka)
+        for (int l = 0; l < 64; ++l) tw.twa[ka * 64 + l] = unit((double)l * ka, 512.0);
+    tw.twb.resize(awk::kTwbElems);
+    for (int kb = 0; kb < 8; ++kb)
+        for (int l0 = 0; l0 < 8; ++l0) tw.twb[kb * 8 + l0] = unit((double)l0 * kb, 64.0);
 }
 
 void build_pair_tables(const float *tracks, int n_tracks, int taps, int n_channels,

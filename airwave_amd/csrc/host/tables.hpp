@@ -11,7 +11,7 @@
 
 namespace awh {
 
-// Per-thread / per-lane twiddle rows (see TileParams): tw1[512][16], twa[64][8], twb[8][8].
+// Twiddle tables (see TileParams): tw1[512] = W_N^t, twa[8][64] (ka-major), twb[8][8] (kb-major).
 struct Twiddles {
     std::vector<awk::cf> tw1, twa, twb;
 };

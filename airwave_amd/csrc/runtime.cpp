@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -254,6 +255,7 @@ void aw_spatializer_destroy(aw_spatializer *sp) {
     for (int i = 0; i < 2; ++i)
         if (sp->d_hist[i]) (void)hipFree(sp->d_hist[i]);
     if (sp->d_spec) (void)hipFree(sp->d_spec);
+    if (sp->d_dbg) (void)hipFree(sp->d_dbg);
     if (sp->d_stage_in) (void)hipFree(sp->d_stage_in);
     if (sp->d_stage_out) (void)hipFree(sp->d_stage_out);
     if (sp->k0) (void)hipEventDestroy(sp->k0);
@@ -316,6 +318,24 @@ int32_t aw_spatializer_kernel_time(aw_spatializer *sp, double *avg_ms, const cha
     return n;
 }
 
+aw_status aw_spatializer_debug_stamps(aw_spatializer *sp, uint64_t *host_out, int64_t capacity_words,
+                                      int64_t *n_workgroups) {
+    if (!sp || !host_out || !n_workgroups) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+#if defined(AW_STAMPS) && AW_STAMPS
+    const int64_t words = (int64_t)sp->dbg_nwg * awk::kStamps;
+    if (!sp->d_dbg || words <= 0) return fail(AW_ERR_INVALID_ARGUMENT, "no launch recorded");
+    if (capacity_words < words) return fail(AW_ERR_INVALID_ARGUMENT, "capacity too small");
+    AW_HIP_TRY(hipStreamSynchronize(sp->ctx->stream));
+    AW_HIP_TRY(hipMemcpy(host_out, sp->d_dbg, (size_t)words * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    *n_workgroups = sp->dbg_nwg;
+    return AW_OK;
+#else
+    (void)capacity_words;
+    *n_workgroups = 0;
+    return fail(AW_ERR_INVALID_ARGUMENT, "library not built with AW_STAMPS");
+#endif
+}
+
 static aw_status sp_process_fused(aw_spatializer *sp, const float *in, float *out, int64_t frames) {
     awk::TileParams p{};
     p.in = in; p.out = out; p.hist = sp->d_hist[sp->hist_cur];
@@ -323,6 +343,26 @@ static aw_status sp_process_fused(aw_spatializer *sp, const float *in, float *ou
     p.frames = frames; p.n_channels = sp->n_channels; p.n_pairs = sp->n_pairs;
     p.hop = sp->hop; p.hist_len = sp->hist_len;
     p.tiles_per_stream = (int)((frames + sp->hop - 1) / sp->hop);
+    p.dbg = nullptr;
+    {
+        const char *e = getenv("AW_STAGGER");      // tuning knob, default from the measured sweep
+        p.stagger = e ? atoi(e) : 0;
+    }
+#if defined(AW_STAMPS) && AW_STAMPS
+    {
+        const long long nwg = (long long)sp->n_streams * p.tiles_per_stream;
+        const size_t need = (size_t)nwg * awk::kStamps;
+        if (sp->dbg_cap < need) {
+            if (sp->d_dbg) AW_HIP_TRY(hipFree(sp->d_dbg));
+            sp->d_dbg = nullptr; sp->dbg_cap = 0;
+            AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sp->d_dbg), need * sizeof(unsigned long long)));
+            sp->dbg_cap = need;
+        }
+        AW_HIP_TRY(hipMemsetAsync(sp->d_dbg, 0, need * sizeof(unsigned long long), sp->ctx->stream));
+        sp->dbg_nwg = nwg;
+        p.dbg = sp->d_dbg;
+    }
+#endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (sp->profiling) {
         e0 = sp_get_event(sp); e1 = sp_get_event(sp);

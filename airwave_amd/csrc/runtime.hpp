@@ -52,6 +52,9 @@ struct aw_spatializer {
     // host-entry staging (grow-only)
     float *d_stage_in = nullptr, *d_stage_out = nullptr;
     size_t stage_in_cap = 0, stage_out_cap = 0;   // floats
+    unsigned long long *d_dbg = nullptr;   // AW_STAMPS diagnostic builds only
+    size_t dbg_cap = 0;                     // words
+    long long dbg_nwg = 0;
     // profiling of the dominant kernel
     bool profiling = false;
     hipEvent_t k0 = nullptr, k1 = nullptr;

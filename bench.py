@@ -47,6 +47,25 @@ def load_hrir(name: str, taps: int):
     return h.astype(np.float32), "synthetic 14-track exp-decay noise"
 
 
+def measured_traffic(S: int, F: int, C: int):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC profile
+    of this same workload (profiles/*/summary.json, made by tools/profile_round.sh: separate --pmc
+    passes, read bytes from TCC_EA0_RDREQ_{32,64,128}B because FETCH_SIZE counts a 128-B request
+    as 64 B on gfx950).  PMC counters cannot be collected from inside this process, so this is the
+    last committed measurement, or None when the workload differs / no profile exists."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "summary.json"))):
+        try:
+            d = json.load(open(path))
+            cfg = d["bench"]["config"]
+            if (cfg["streams_per_gpu"], cfg["frames_per_stream"], cfg["input_channels"]) == (S, F, C) and "traffic_bytes_per_launch" in d:
+                best = (path, d["traffic_bytes_per_launch"])
+        except Exception:
+            continue
+    return best
+
+
 def cpu_baseline(x_host, tracks, lt, rt, frames: int):
     """Times the CPU oracle (float32 restatement of the reference algorithm: B=512, one engine per
     (channel, ear), per-ear forward FFTs) on the host cores, on a bounded sample of the same input."""
@@ -147,6 +166,7 @@ def main() -> None:
         alg_bytes = bytes_per_frame * S * F              # per launch of the dominant kernel
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         info = sp.info()
+        tr = measured_traffic(S, F, C)
         result = {
             "metric": "stereo frames/sec @48kHz, 14ch HeSuVi HRIR",
             "value": frames_total / elapsed_max,
@@ -169,7 +189,8 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": tr[1]["total"] if tr else None,
+                "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC)", "traffic_source": os.path.relpath(tr[0], ROOT) if tr else None,
                 "kernel": kernel_name, "kernel_avg_ms": kernel_ms, "launches_timed": n_launch,
                 "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_frame": bytes_per_frame,
             },

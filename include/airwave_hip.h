@@ -115,6 +115,12 @@ AW_API int64_t aw_spatializer_info(const aw_spatializer *sp, int32_t what);
 AW_API aw_status aw_spatializer_set_profiling(aw_spatializer *sp, int32_t enabled);
 AW_API int32_t aw_spatializer_kernel_time(aw_spatializer *sp, double *avg_ms, const char **kernel_name);
 
+/* Diagnostic builds only (library compiled with -DAW_STAMPS=1, see tools/stamps.py): copies the
+ * per-workgroup phase time stamps of the last fused-kernel launch to host_out as
+ * [workgroup][16] uint64 shader-clock values.  The shipped library returns AW_ERR_INVALID_ARGUMENT. */
+AW_API aw_status aw_spatializer_debug_stamps(aw_spatializer *sp, uint64_t *host_out, int64_t capacity_words,
+                                             int64_t *n_workgroups);
+
 /* ---- mono engine: ConvolutionEngine (ConvolutionEngine.swift:14-408) ---------------------------
  * init?(hrirSamples:blockSize:) :68 / process(input:output:) :232 / processAndAccumulate :388 /
  * reset() :397.  HOST buffers of exactly block_size frames. */

@@ -24,12 +24,12 @@ def lib():
             subprocess.run(["g++", "-std=c++20", "-O2", "-pthread", "-shared", "-fPIC", "-o", _LIB] + _SRCS, check=True)
         _lib = ctypes.CDLL(_LIB)
         _lib.emu_fused_ols.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
-                                       ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
+                                       ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _lib.emu_fft_small.argtypes = [fp, ctypes.c_int, ctypes.c_int]
     return _lib
 
 
-def fused_ols(x, tracks, left_track, right_track, hop=None, hist=None):
+def fused_ols(x, tracks, left_track, right_track, hop=None, hist=None, variant=1):
     """x: [streams][frames][C] float32 -> [streams][frames][2]."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     S, F, C = x.shape
@@ -45,7 +45,7 @@ def fused_ols(x, tracks, left_track, right_track, hop=None, hist=None):
         assert h.shape == (S, 8192 - hop, C)
     rc = lib().emu_fused_ols(x.ctypes.data_as(fp), out.ctypes.data_as(fp), None if h is None else h.ctypes.data_as(fp),
                              tr.ctypes.data_as(fp), tr.shape[0], tr.shape[1], C, lt.ctypes.data_as(ip),
-                             rt.ctypes.data_as(ip), F, S, hop)
+                             rt.ctypes.data_as(ip), F, S, hop, variant)
     assert rc == 0
     return out
 

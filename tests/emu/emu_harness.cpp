@@ -21,7 +21,7 @@ struct EmuShared {
     std::barrier<> wg{awk::kThreads};
     std::vector<std::unique_ptr<std::barrier<>>> wave;
     std::vector<awk::cf> lds;
-    EmuShared() : lds((size_t)2 * awk::kBufElems) {
+    EmuShared() : lds((size_t)awk::kLdsElems) {
         for (int w = 0; w < awk::kThreads / 64; ++w) wave.emplace_back(new std::barrier<>(64));
     }
 };
@@ -33,6 +33,9 @@ struct EmuCtx {
     int lane() const { return tid_ & 63; }
     int wave() const { return tid_ >> 6; }
     awk::cf *lds() const { return sh->lds.data(); }
+    awk::cf opaque(awk::cf v) const { return v; }
+    void stamp(int) const {}
+    void stagger(int, int) const {}
     void barrier() const { sh->wg.arrive_and_wait(); }
     void wave_sync() const { sh->wave[tid_ >> 6]->arrive_and_wait(); }
 };
@@ -45,7 +48,7 @@ extern "C" {
 // workgroup.  Layouts as TileParams.  hist may be NULL (zeros).
 int emu_fused_ols(const float *in, float *out, const float *hist, const float *tracks, int n_tracks,
                   int taps, int n_channels, const int32_t *left_track, const int32_t *right_track,
-                  long long frames, int n_streams, int hop) {
+                  long long frames, int n_streams, int hop, int variant) {
     using namespace awk;
     if (hop <= 0 || hop > kN - (taps - 1)) return -1;
     awh::Twiddles tw;
@@ -71,7 +74,12 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
             for (int t = 0; t < kThreads; ++t)
                 th.emplace_back([&, t]() {
                     EmuCtx ctx{t, &sh};
-                    tile_fused_ols<EmuCtx, 0>(ctx, p, s, tile);
+                    if (variant == 1 && n_channels == 8) tile_fused_ols<EmuCtx, 8, 4>(ctx, p, s, tile);
+                    else if (variant == 1 && n_channels == 2) tile_fused_ols<EmuCtx, 2, 1>(ctx, p, s, tile);
+                    else if (variant == 1 && n_channels == 7) tile_fused_ols<EmuCtx, 0, 4>(ctx, p, s, tile);
+                    else if (variant == 1 && n_channels == 3) tile_fused_ols<EmuCtx, 0, 2>(ctx, p, s, tile);
+                    else if (variant == 1 && n_channels == 4) tile_fused_ols<EmuCtx, 4, 2>(ctx, p, s, tile);
+                    else tile_fused_ols<EmuCtx, 0, 0>(ctx, p, s, tile);
                 });
             for (auto &x : th) x.join();
         }

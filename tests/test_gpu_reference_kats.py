@@ -132,7 +132,11 @@ def test_underflow_silence_and_mono_duplication(aw):
     ul, ur = run(p, 3, 0.5, 0.5)
     assert ul.tolist() == [0, 0, 0] and ur.tolist() == ul.tolist()
     l, r = run(p, 512, 0.5, 0.5)
-    assert np.array_equal(l, r)
+    # The reference asserts bitwise L == R here because its two ears are two identical engines.
+    # The HIP engine computes both ears as the real/imaginary parts of ONE complex transform, so
+    # equal-by-construction ears agree to rounding (1e-6 of peak), not bitwise (DESIGN.md "Deviations").
+    assert np.max(np.abs(l - r)) <= 1e-6 * np.max(np.abs(l))
+    assert np.all(np.abs(l - 0.5) < 1e-4)
 
 
 def test_canaries_remain_unchanged(aw):
