@@ -82,6 +82,22 @@ __global__ void __launch_bounds__(kThreads) aw_fused_ols_kernel(TileParams p, lo
     tile_fused_ols<GpuCtx, CS, NP>(ctx, p, stream, tile);
 }
 
+template <int CS>
+__global__ void __launch_bounds__(kThreads) aw_part_forward_kernel(TileParams p, long long nwg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
+    const long long id = xcd_remap((long long)blockIdx.x, nwg);
+    const int n_windows = p.n_blocks + p.partitions - 1;
+    tile_part_forward<GpuCtx, CS>(ctx, p, id / n_windows, (int)(id % n_windows));
+}
+
+__global__ void __launch_bounds__(kThreads) aw_part_cmac_ifft_kernel(TileParams p, long long nwg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
+    const long long id = xcd_remap((long long)blockIdx.x, nwg);
+    tile_part_cmac_inverse<GpuCtx>(ctx, p, id / p.n_blocks, (int)(id % p.n_blocks));
+}
+
 // Variants: <CS, NP> = <vector-load channel count or 0, compile-time pair count or 0 (generic)>
 #define AW_FOR_EACH_VARIANT(X) X(8, 4) X(2, 1) X(4, 2) X(0, 4) X(0, 2) X(0, 0)
 
@@ -93,6 +109,15 @@ hipError_t prepare_kernels() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     AW_FOR_EACH_VARIANT(AW_SET_ATTR)
 #undef AW_SET_ATTR
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_forward_kernel<8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_forward_kernel<0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_cmac_ifft_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     return e;
 }
 
@@ -124,6 +149,25 @@ hipError_t launch_fused_ols(const TileParams &p, int n_streams, hipStream_t stre
         case 4: hipLaunchKernelGGL((aw_fused_ols_kernel<0, 2>), grid, block, kLdsBytes, stream, p, nwg); break;
         default: hipLaunchKernelGGL((aw_fused_ols_kernel<0, 0>), grid, block, kLdsBytes, stream, p, nwg); break;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_part_forward(const TileParams &p, int n_streams, hipStream_t stream) {
+    const long long nwg = (long long)n_streams * (p.n_blocks + p.partitions - 1);
+    if (nwg <= 0) return hipSuccess;
+    if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (p.n_channels == 8)
+        hipLaunchKernelGGL(aw_part_forward_kernel<8>, dim3((unsigned)nwg), dim3(kThreads), kLdsBytes, stream, p, nwg);
+    else
+        hipLaunchKernelGGL(aw_part_forward_kernel<0>, dim3((unsigned)nwg), dim3(kThreads), kLdsBytes, stream, p, nwg);
+    return hipGetLastError();
+}
+
+hipError_t launch_part_cmac_ifft(const TileParams &p, int n_streams, hipStream_t stream) {
+    const long long nwg = (long long)n_streams * p.n_blocks;
+    if (nwg <= 0) return hipSuccess;
+    if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(aw_part_cmac_ifft_kernel, dim3((unsigned)nwg), dim3(kThreads), kLdsBytes, stream, p, nwg);
     return hipGetLastError();
 }
 

@@ -74,6 +74,11 @@ struct TileParams {
     int hop;                // new output frames per tile, hop <= N - (taps - 1)
     int hist_len;           // = N - hop
     int tiles_per_stream;   // ceil(frames / hop)
+    // partitioned (long-HRIR) path only:
+    cf *spec;               // [stream][window][pair][16][512] input-window spectra (scratch)
+    int partitions;         // P = ceil(taps / hop); tables are [partition][pair][N]
+    int n_blocks;           // output blocks of `hop` frames per stream in this call
+    int first_valid;        // first window position that is stored (N - hop)
     int stagger;            // tuning: waves 4-7 idle this many 64-cycle slots after each barrier (phase offset)
     unsigned long long *dbg; // diagnostic builds only (AW_STAMPS): [workgroup][16] s_memtime stamps of wave 0
 };
@@ -257,6 +262,44 @@ AW_HD void pair_subfft_cmac(Ctx &ctx, const TileParams &p, int pair, cf *buf, co
     ctx.wave_sync();    // partner reads done before this wave reuses its rows as scratch
 }
 
+// Inverse half of a tile: per-wave 512-point inverse sub-FFTs of W (scratch = the wave's own rows
+// of buf0, which only it touches until the barrier), exchange, radix-16 across rows, then store
+// window positions m >= first_valid whose frame f0 + m lies inside the call.
+template <class Ctx>
+AW_HD void tile_inverse_store(Ctx &ctx, const TileParams &p, cf (&wacc)[2][8], cf *buf0, const cf *twa, const cf *twb,
+                              cf w1, long long stream, long long f0, int first_valid) {
+    const int t = ctx.tid();
+    const int lane = ctx.lane(), wave = ctx.wave();
+    {
+        cf *row0 = buf0 + wave_row(wave, 0) * kRowStride;
+        cf *row1 = buf0 + wave_row(wave, 1) * kRowStride;
+        sub_fft512x2<true>(ctx, wacc, row0, row1, twa, twb, lane);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) { row0[lane + 64 * kc] = wacc[0][kc]; row1[lane + 64 * kc] = wacc[1][kc]; }
+    }
+    ctx.stamp(11);
+    ctx.barrier();
+    ctx.stamp(12);
+    cf y[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) y[k1] = buf0[k1 * kRowStride + t];
+    {
+        cf pw[16];
+        tw_powers(ctx.opaque(w1), pw);
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) y[k1] = cmulc(y[k1], pw[k1]);
+    }
+    fft16<true>(y);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int m = t + 512 * j;
+        const long long f = f0 + m;
+        if (m >= first_valid && f < p.frames)
+            *reinterpret_cast<cf *>(p.out + ((long long)stream * p.frames + f) * 2) = y[j];
+    }
+    ctx.stamp(13);
+}
+
 // NP: compile-time pair count (straight-line schedule, no phis around the prefetches); NP = 0 is
 // the generic variant: a runtime loop over batches that always processes two pairs (a phantom
 // pair has all-zero input, so whatever table it multiplies contributes nothing).
@@ -329,37 +372,115 @@ AW_HD void tile_fused_ols(Ctx &ctx, const TileParams &p, long long stream, int t
         for (int pair0 = 0; pair0 < n_pairs; pair0 += 2) batch(pair0, true, pair0 + 2 < n_pairs);
     }
 
-    // ---- inverse: per-wave 512-point inverse sub-FFTs of W (scratch = own rows of buf0, which
-    // only this wave touches until the barrier), exchange, radix-16 across rows ----
-    {
-        cf *row0 = buf0 + wave_row(wave, 0) * kRowStride;
-        cf *row1 = buf0 + wave_row(wave, 1) * kRowStride;
-        sub_fft512x2<true>(ctx, wacc, row0, row1, twa, twb, lane);
+    tile_inverse_store(ctx, p, wacc, buf0, twa, twb, w1, stream, f0, p.hist_len);
+}
+
+// ---- partitioned path (taps too long for one window: Y[b] = sum_q X[b-q] . H_q, the same
+// frequency-domain delay line as ConvolutionEngine.swift:256-350 with B = N/2 = 4096) -----------
+// Kernel 1: spectra of one input window for every pair -> global scratch.
+template <class Ctx, int CS>
+AW_HD void tile_part_forward(Ctx &ctx, const TileParams &p, long long stream, int widx) {
+    const int t = ctx.tid();
+    const int lane = ctx.lane(), wave = ctx.wave();
+    cf *buf0 = ctx.lds();
+    cf *buf1 = buf0 + kBufElems;
+    cf *twa = buf1 + kBufElems;
+    cf *twb = twa + kTwaElems;
+    const int Cn = CS > 0 ? CS : p.n_channels;
+    const float *in_s = p.in + stream * p.frames * Cn;
+    const float *hist_s = p.hist + stream * (long long)p.hist_len * Cn;
+    const long long f0 = ((long long)widx - p.partitions) * p.hop;      // window widx covers blocks (widx-P, widx-P+1)
+    const int n_windows = p.n_blocks + p.partitions - 1;
+    cf *spec_w = p.spec + ((stream * n_windows + widx) * p.n_pairs) * (long long)kN;
+
+    float raw[16][kBatchCh];
+    load_batch<CS>(p, in_s, hist_s, f0, t, 0, raw);
+    const cf w1 = p.tw1[t];
+    twa[t] = p.twa[t];
+    if (t < kTwbElems) twb[t] = p.twb[t];
+
+    for (int pair0 = 0; pair0 < p.n_pairs; pair0 += 2) {
+        const bool more = pair0 + 2 < p.n_pairs;
+        if (pair0 > 0) ctx.barrier();
+        {
+            cf pw[16];
+            tw_powers(ctx.opaque(w1), pw);
+            cf x[16];
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc) { row0[lane + 64 * kc] = wacc[0][kc]; row1[lane + 64 * kc] = wacc[1][kc]; }
+            for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][0], raw[j][1]);
+            pair_pass1(x, pw, buf0, t);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][2], raw[j][3]);
+            pair_pass1(x, pw, buf1, t);
+        }
+        ctx.barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (pair0 + h >= p.n_pairs) break;            // uniform
+            cf *buf = h == 0 ? buf0 : buf1;
+            cf *row0 = buf + wave_row(wave, 0) * kRowStride;
+            cf *row1 = buf + wave_row(wave, 1) * kRowStride;
+            cf z[2][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { z[0][j] = row0[lane + 64 * j]; z[1][j] = row1[lane + 64 * j]; }
+            ctx.wave_sync();
+            sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
+            cf *dst = spec_w + (long long)(pair0 + h) * kN;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) dst[wave_row(wave, s) * kSub + lane + 64 * kc] = z[s][kc];
+        }
+        if (more) load_batch<CS>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
     }
-    ctx.stamp(11);
-    ctx.barrier();
-    ctx.stamp(12);
-    cf y[16];
+}
+
+// Kernel 2: one output block: W = sum over partitions and pairs, inverse, store the last hop frames.
+template <class Ctx>
+AW_HD void tile_part_cmac_inverse(Ctx &ctx, const TileParams &p, long long stream, int block) {
+    const int t = ctx.tid();
+    const int lane = ctx.lane(), wave = ctx.wave();
+    cf *buf0 = ctx.lds();
+    cf *twa = buf0 + 2 * kBufElems;
+    cf *twb = twa + kTwaElems;
+    const cf w1 = p.tw1[t];
+    twa[t] = p.twa[t];
+    if (t < kTwbElems) twb[t] = p.twb[t];
+    ctx.barrier();                                        // twiddles visible (the forward path has its own barrier)
+    const int n_windows = p.n_blocks + p.partitions - 1;
+
+    cf wacc[2][8];
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) y[k1] = buf0[k1 * kRowStride + t];
-    {
-        cf pw[16];
-        tw_powers(ctx.opaque(w1), pw);
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) y[k1] = cmulc(y[k1], pw[k1]);
+        for (int i = 0; i < 8; ++i) wacc[s][i] = mk(0.f, 0.f);
+
+    for (int q = 0; q < p.partitions; ++q) {
+        const int widx = block + (p.partitions - 1) - q;              // window that partition q reads
+        const cf *spec_w = p.spec + ((stream * n_windows + widx) * p.n_pairs) * (long long)kN;
+        for (int pair = 0; pair < p.n_pairs; ++pair) {
+            const cf *zs = spec_w + (long long)pair * kN;
+            const cf2 *tab = p.tab + ((long long)q * p.n_pairs + pair) * kN;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int k1 = wave_row(wave, s);
+                const int pk1 = (16 - k1) & 15;                       // partner row
+                const int bidx = 511 - lane + (k1 == 0 ? 1 : 0);
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) {
+                    int idx = bidx - 64 * kc;
+                    if (kc == 0) idx &= 511;
+                    const cf z = zs[k1 * kSub + lane + 64 * kc];
+                    const cf zp = zs[pk1 * kSub + idx];
+                    const cf2 ab = tab[k1 * kSub + lane + 64 * kc];
+                    wacc[s][kc] = cfma(z, ab.a, wacc[s][kc]);
+                    wacc[s][kc] = cfmac(zp, ab.b, wacc[s][kc]);
+                }
+            }
+        }
     }
-    fft16<true>(y);
-    // ---- store the valid part of the window: positions m >= N - hop, frames < p.frames ----
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int m = t + 512 * j;
-        const long long f = f0 + m;
-        if (m >= p.hist_len && f < p.frames)
-            *reinterpret_cast<cf *>(p.out + ((long long)stream * p.frames + f) * 2) = y[j];
-    }
-    ctx.stamp(13);
+    const long long f0 = ((long long)block - 1) * p.hop;             // window of block b: frames [(b-1)B, (b+1)B)
+    tile_inverse_store(ctx, p, wacc, buf0, twa, twb, w1, stream, f0, p.first_valid);
 }
 
 }  // namespace awk

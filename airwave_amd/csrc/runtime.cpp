@@ -376,13 +376,56 @@ static aw_status sp_process_fused(aw_spatializer *sp, const float *in, float *ou
     return AW_OK;
 }
 
+static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, float *out, int64_t frames) {
+    const int N = awk::kN, B = sp->hop, P = sp->partitions;
+    const int n_blocks = (int)((frames + B - 1) / B);
+    const long long n_windows = (long long)n_blocks + P - 1;
+    const size_t per_stream = (size_t)n_windows * sp->n_pairs * N;          // complex elements
+    size_t budget_mb = 6144;
+    if (const char *e = getenv("AW_SPEC_SCRATCH_MB")) budget_mb = (size_t)atoll(e);
+    long long chunk = (long long)((budget_mb << 20) / (per_stream * sizeof(awk::cf)));
+    if (chunk < 1) chunk = 1;
+    if (chunk > sp->n_streams) chunk = sp->n_streams;
+    const size_t need = per_stream * (size_t)chunk;
+    if (sp->spec_capacity < need) {
+        if (sp->d_spec) AW_HIP_TRY(hipFree(sp->d_spec));
+        sp->d_spec = nullptr; sp->spec_capacity = 0;
+        AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sp->d_spec), need * sizeof(awk::cf)));
+        sp->spec_capacity = need;
+    }
+    for (long long s0 = 0; s0 < sp->n_streams; s0 += chunk) {
+        const int ns = (int)std::min<long long>(chunk, sp->n_streams - s0);
+        awk::TileParams p{};
+        p.in = in + (size_t)s0 * frames * sp->n_channels;
+        p.out = out + (size_t)s0 * frames * 2;
+        p.hist = sp->d_hist[sp->hist_cur] + (size_t)s0 * sp->hist_len * sp->n_channels;
+        p.tab = sp->d_tab; p.tw1 = sp->ctx->d_tw1; p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb;
+        p.frames = frames; p.n_channels = sp->n_channels; p.n_pairs = sp->n_pairs;
+        p.hop = B; p.hist_len = sp->hist_len; p.tiles_per_stream = n_blocks;
+        p.spec = sp->d_spec; p.partitions = P; p.n_blocks = n_blocks; p.first_valid = N - B;
+        p.stagger = 0; p.dbg = nullptr;
+        AW_HIP_TRY(awk::launch_part_forward(p, ns, sp->ctx->stream));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (sp->profiling) {
+            e0 = sp_get_event(sp); e1 = sp_get_event(sp);
+            AW_HIP_TRY(hipEventRecord(e0, sp->ctx->stream));
+        }
+        AW_HIP_TRY(awk::launch_part_cmac_ifft(p, ns, sp->ctx->stream));
+        if (sp->profiling) {
+            AW_HIP_TRY(hipEventRecord(e1, sp->ctx->stream));
+            sp->pending.emplace_back(e0, e1);
+        }
+    }
+    return AW_OK;
+}
+
 aw_status aw_spatializer_process(aw_spatializer *sp, const float *in, float *out, int64_t frames) {
     if (!sp || !in || !out) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     if (frames <= 0) return frames == 0 ? AW_OK : fail(AW_ERR_INVALID_ARGUMENT, "frames must be >= 0");
     AW_HIP_TRY(hipSetDevice(sp->ctx->device));
     aw_status st = AW_OK;
     if (sp->path == 0) st = sp_process_fused(sp, in, out, frames);
-    else return fail(AW_ERR_CONVOLUTION_SETUP_FAILED, "partitioned (long-tap) path is not built in this revision");
+    else st = sp_process_partitioned(sp, in, out, frames);
     if (st != AW_OK) return st;
     // carry the convolution tail: next call's history = last hist_len frames of (history ++ input)
     float *h_old = sp->d_hist[sp->hist_cur], *h_new = sp->d_hist[sp->hist_cur ^ 1];

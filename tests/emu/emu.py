@@ -25,6 +25,8 @@ def lib():
         _lib = ctypes.CDLL(_LIB)
         _lib.emu_fused_ols.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
                                        ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        _lib.emu_partitioned.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
+                                         ctypes.c_longlong, ctypes.c_int]
         _lib.emu_fft_small.argtypes = [fp, ctypes.c_int, ctypes.c_int]
     return _lib
 
@@ -46,6 +48,22 @@ def fused_ols(x, tracks, left_track, right_track, hop=None, hist=None, variant=1
     rc = lib().emu_fused_ols(x.ctypes.data_as(fp), out.ctypes.data_as(fp), None if h is None else h.ctypes.data_as(fp),
                              tr.ctypes.data_as(fp), tr.shape[0], tr.shape[1], C, lt.ctypes.data_as(ip),
                              rt.ctypes.data_as(ip), F, S, hop, variant)
+    assert rc == 0
+    return out
+
+
+def partitioned(x, tracks, left_track, right_track, hist=None):
+    """Long-HRIR path (hop 4096, P = ceil(taps/4096) partitions)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    S, F, C = x.shape
+    tr = np.ascontiguousarray(tracks, dtype=np.float32)
+    lt = np.ascontiguousarray(left_track, dtype=np.int32)
+    rt = np.ascontiguousarray(right_track, dtype=np.int32)
+    out = np.full((S, F, 2), np.nan, dtype=np.float32)
+    h = None if hist is None else np.ascontiguousarray(hist, dtype=np.float32)
+    rc = lib().emu_partitioned(x.ctypes.data_as(fp), out.ctypes.data_as(fp), None if h is None else h.ctypes.data_as(fp),
+                               tr.ctypes.data_as(fp), tr.shape[0], tr.shape[1], C, lt.ctypes.data_as(ip),
+                               rt.ctypes.data_as(ip), F, S)
     assert rc == 0
     return out
 

@@ -87,6 +87,45 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
     return 0;
 }
 
+// Partitioned (long-HRIR) path: kernel 1 (window spectra) then kernel 2 (CMAC over partitions + inverse).
+int emu_partitioned(const float *in, float *out, const float *hist, const float *tracks, int n_tracks, int taps,
+                    int n_channels, const int32_t *left_track, const int32_t *right_track, long long frames,
+                    int n_streams) {
+    using namespace awk;
+    const int B = kN / 2, P = (taps + B - 1) / B;
+    awh::Twiddles tw;
+    awh::build_twiddles(tw);
+    std::vector<cf2> tab, all;
+    for (int q = 0; q < P; ++q) {
+        awh::build_pair_tables(tracks, n_tracks, taps, n_channels, left_track, right_track, q * B, B, tab);
+        all.insert(all.end(), tab.begin(), tab.end());
+    }
+    TileParams p{};
+    p.in = in; p.out = out; p.tab = all.data(); p.tw1 = tw.tw1.data(); p.twa = tw.twa.data(); p.twb = tw.twb.data();
+    p.frames = frames; p.n_channels = n_channels; p.n_pairs = (n_channels + 1) / 2;
+    p.hop = B; p.hist_len = P * B; p.partitions = P; p.n_blocks = (int)((frames + B - 1) / B);
+    p.tiles_per_stream = p.n_blocks; p.first_valid = kN - B;
+    const int n_windows = p.n_blocks + P - 1;
+    std::vector<float> zero_hist;
+    if (!hist) { zero_hist.assign((size_t)n_streams * p.hist_len * n_channels, 0.f); hist = zero_hist.data(); }
+    p.hist = hist;
+    std::vector<cf> spec((size_t)n_streams * n_windows * p.n_pairs * kN);
+    p.spec = spec.data();
+    EmuShared sh;
+    auto run = [&](auto fn, int count) {
+        for (int s = 0; s < n_streams; ++s)
+            for (int i = 0; i < count; ++i) {
+                std::vector<std::thread> th;
+                th.reserve(kThreads);
+                for (int t = 0; t < kThreads; ++t) th.emplace_back([&, t]() { EmuCtx ctx{t, &sh}; fn(ctx, s, i); });
+                for (auto &x : th) x.join();
+            }
+    };
+    run([&](EmuCtx &ctx, int s, int w) { tile_part_forward<EmuCtx, 0>(ctx, p, s, w); }, n_windows);
+    run([&](EmuCtx &ctx, int s, int b) { tile_part_cmac_inverse<EmuCtx>(ctx, p, s, b); }, p.n_blocks);
+    return 0;
+}
+
 // Butterfly unit checks: n in {4, 8, 16}; data is [n] complex interleaved, in place.
 int emu_fft_small(float *data, int n, int inverse) {
     using namespace awk;

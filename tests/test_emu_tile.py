@@ -47,3 +47,13 @@ def test_emulated_tile_history_carry(oracle):
     hist[0] = x[0, 700 - (8192 - hop):700]      # the last hist_len frames before the second call
     y2 = emu.fused_ols(x[:, 700:], h, [0, 1], [1, 0], hop=hop, hist=hist)
     assert oracle.peak_rel_error(y2[0], ref[700:]) < TOL
+
+
+def test_emulated_partitioned_long_hrir(oracle, golden_dir):
+    # cfg 3 golden: synthetic 32768-tap HRIR (P = 8 partitions of 4096), 7 speakers
+    g = np.load(os.path.join(golden_dir, "cfg3_longtap_7spk.npz"))
+    h = oracle.synth_hrir(14, int(g["hrir_taps"]), seed=int(g["hrir_seed"]))
+    x = oracle.synth_input(1, int(g["frames"]), 7, seed=int(g["seed"]))
+    y = emu.partitioned(x, h, g["left_track"], g["right_track"])
+    assert not np.isnan(y).any()
+    assert oracle.peak_rel_error(y[0], g["expected"]) < TOL

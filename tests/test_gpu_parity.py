@@ -146,8 +146,6 @@ def test_resampled_hrir_activation(aw, oracle, golden_dir):
         sp = aw.HRIRManager().activatePreset(os.path.join(golden_dir, "hrtf", "StageSH1.0.wav"), rate, aw.InputLayout.detect(2))
         tracks, lt, rt = oracle.assemble_tracks(w, ["FL", "FR"], target_rate=rate)
         x = oracle.synth_input(1, 6000, 2, seed=4)
-        if sp.info()["path"] != 0:
-            pytest.skip("partitioned path")
         ref = oracle.spatialize_f64(x[0], tracks, lt, rt)
         assert oracle.peak_rel_error(sp.process(x)[0], ref) < TOL
 
@@ -200,3 +198,37 @@ def test_full_size_properties_cfg2(aw, oracle, golden_dir):
     e = (y.double() ** 2).sum(dim=(1, 2))
     assert float(e.min()) > 0.25 * float(e.max())
     assert len(set(np.round(e.cpu().numpy(), 6).tolist())) == S
+
+
+def test_long_tap_partitioned_path(aw, oracle, golden_dir):
+    """cfg 3: 32768-tap synthetic HRIR -> partitioned path (8 partitions of 4096 frames), golden truth."""
+    g = load(golden_dir, "cfg3_longtap_7spk.npz")
+    h = oracle.synth_hrir(14, int(g["hrir_taps"]), seed=int(g["hrir_seed"]))
+    sp = aw.Spatializer(aw.HRIR(h), g["left_track"], g["right_track"])
+    info = sp.info()
+    assert info["path"] == 1 and info["partitions"] == 8 and info["hop"] == 4096
+    x = oracle.synth_input(1, int(g["frames"]), 7, seed=int(g["seed"]))
+    assert oracle.peak_rel_error(sp.process(x)[0], g["expected"]) < TOL
+
+
+@pytest.mark.parametrize("taps,channels", [(6146, 2), (8640, 8), (12289, 5)])
+def test_partitioned_path_lengths_chunks_and_state(aw, oracle, taps, channels, monkeypatch):
+    """96 kHz-class HRIRs (cfg 4: 4320 taps resampled x2 = 8640) and stream chunking of the scratch."""
+    monkeypatch.setenv("AW_SPEC_SCRATCH_MB", "3")          # forces several stream chunks
+    h = oracle.synth_hrir(14, taps, seed=taps)
+    lt = np.array([0, 8, 6, 6, 4, 12, 2, 10][:channels], dtype=np.int32)
+    rt = np.array([1, 7, 13, 13, 5, 11, 3, 9][:channels], dtype=np.int32)
+    S, F = 3, 10000
+    x = oracle.synth_input(S, F, channels, seed=21)
+    sp = aw.Spatializer(aw.HRIR(h), lt, rt, n_streams=S)
+    assert sp.info()["path"] == 1
+    whole = sp.process(x)
+    for s in range(S):
+        assert oracle.peak_rel_error(whole[s], oracle.spatialize_f64(x[s], h, lt, rt)) < TOL
+    sp.reset()
+    parts, pos = [], 0
+    for n in [1, 4095, 4097, 1000, 807]:
+        parts.append(sp.process(np.ascontiguousarray(x[:, pos:pos + n])))
+        pos += n
+    assert pos == F
+    assert np.max(np.abs(np.concatenate(parts, axis=1) - whole)) <= 3e-6 * np.abs(whole).max()
