@@ -115,6 +115,7 @@ def main() -> None:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import airwave_amd as aw
+    from airwave_amd.sharding import aggregate_throughput, weak_shard
 
     wl = dict(WORKLOADS[args.workload])
     S = args.streams or wl["streams"]
@@ -130,7 +131,8 @@ def main() -> None:
 
     x = torch.empty((S, F, C), dtype=torch.float32, device="cuda")
     y = torch.empty((S, F, 2), dtype=torch.float32, device="cuda")
-    ctx.synth_fill(x.data_ptr(), S, F, C, seed=0xA17AE, first_stream=rank * S)   # stream ids are global
+    first_stream, _ = weak_shard(S, world, rank)                                  # stream ids are global
+    ctx.synth_fill(x.data_ptr(), S, F, C, seed=0xA17AE, first_stream=first_stream)
     torch.cuda.synchronize()
 
     def step():
@@ -153,12 +155,8 @@ def main() -> None:
     n_launch, kernel_ms, kernel_name = sp.kernel_time()
     sp.set_profiling(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    fr = torch.tensor([float(S) * F * args.steps], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)      # RCCL over xGMI: the only collective of the run
-        dist.all_reduce(fr, op=dist.ReduceOp.SUM)
-    elapsed_max, frames_total = float(t.item()), float(fr.item())
+    # RCCL over xGMI: the only collective of the run (sum of frames, max of elapsed)
+    frames_total, elapsed_max, _ = aggregate_throughput(float(S) * F * args.steps, elapsed, device="cuda")
 
     if rank == 0:
         finite = bool(torch.isfinite(y[:, -4096:]).all().item())

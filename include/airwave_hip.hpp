@@ -1,0 +1,116 @@
+// airwave_hip.hpp — header-only C++ mirror of the reference's Swift types over the C ABI
+// (include/airwave_hip.h).  Same names and call shapes as ConvolutionEngine.swift /
+// RealtimeAudioProcessor.swift / HRIRManager.swift so that C++ hosts (and the ABI replay harness in
+// tests/harness/) read like the reference.  Errors surface as aw::Error (status + message);
+// the failable initialiser `init?` becomes `ConvolutionEngine::make` returning nullptr.
+#pragma once
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "airwave_hip.h"
+
+namespace aw {
+
+struct Error : std::runtime_error {
+    aw_status status;
+    Error(aw_status s, const std::string &m) : std::runtime_error(std::string(aw_status_string(s)) + ": " + m), status(s) {}
+};
+inline void check(aw_status s) {
+    if (s != AW_OK) throw Error(s, aw_last_error_message());
+}
+
+class Context {
+  public:
+    explicit Context(int device = 0) { check(aw_context_create(device, &h_)); }
+    Context(int device, void *hip_stream) { check(aw_context_create_on_stream(device, hip_stream, &h_)); }
+    ~Context() { aw_context_destroy(h_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    aw_context *get() const { return h_; }
+    void synchronize() { check(aw_context_synchronize(h_)); }
+  private:
+    aw_context *h_ = nullptr;
+};
+
+// ConvolutionEngine.swift:14-408
+class ConvolutionEngine {
+  public:
+    // init?(hrirSamples:blockSize:)  :68 — nullptr instead of nil
+    static std::unique_ptr<ConvolutionEngine> make(Context &ctx, const std::vector<float> &hrirSamples, int blockSize = 512) {
+        aw_engine *e = nullptr;
+        if (aw_engine_create(ctx.get(), hrirSamples.data(), (int32_t)hrirSamples.size(), blockSize, &e) != AW_OK) return nullptr;
+        return std::unique_ptr<ConvolutionEngine>(new ConvolutionEngine(e));
+    }
+    ~ConvolutionEngine() { aw_engine_destroy(h_); }
+    void process(const float *input, float *output) { check(aw_engine_process(h_, input, output)); }                  // :232
+    // process(input:output:frameCount:) :370 — silently ignores a wrong count, like the reference
+    void process(const std::vector<float> &input, std::vector<float> &output, int frameCount = -1) {
+        const int count = frameCount < 0 ? blockSize() : frameCount;
+        const aw_status s = aw_engine_process_n(h_, input.data(), output.data(), count);
+        if (s != AW_OK && s != AW_ERR_BLOCK_SIZE_MISMATCH) check(s);
+    }
+    void processAndAccumulate(const float *input, float *outputAccumulator) {                                      // :388
+        check(aw_engine_process_accumulate(h_, input, outputAccumulator));
+    }
+    void reset() { check(aw_engine_reset(h_)); }                                                                   // :397
+    int blockSize() const { return aw_engine_block_size(h_); }
+  private:
+    explicit ConvolutionEngine(aw_engine *e) : h_(e) {}
+    aw_engine *h_;
+};
+
+class HRIR {
+  public:
+    HRIR(Context &ctx, const float *tracks, int nTracks, int taps, double sampleRate) {
+        check(aw_hrir_create(ctx.get(), tracks, nTracks, taps, sampleRate, &h_));
+    }
+    ~HRIR() { aw_hrir_destroy(h_); }
+    HRIR(const HRIR &) = delete;
+    aw_hrir *get() const { return h_; }
+  private:
+    aw_hrir *h_ = nullptr;
+};
+
+// The batch engine network (HRIRManager.RendererState + processPendingBlock, generalised to N speakers)
+class Spatializer {
+  public:
+    Spatializer(Context &ctx, const HRIR &hrir, const std::vector<int32_t> &leftTrack, const std::vector<int32_t> &rightTrack,
+                int nStreams = 1) {
+        check(aw_spatializer_create(ctx.get(), hrir.get(), (int32_t)leftTrack.size(), leftTrack.data(), rightTrack.data(),
+                                    nStreams, 0, &h_));
+    }
+    explicit Spatializer(aw_spatializer *adopt) : h_(adopt) {}
+    ~Spatializer() { aw_spatializer_destroy(h_); }
+    Spatializer(const Spatializer &) = delete;
+    void processDevice(const float *in, float *out, int64_t frames) { check(aw_spatializer_process(h_, in, out, frames)); }
+    void processHost(const float *in, float *out, int64_t frames) { check(aw_spatializer_process_host(h_, in, out, frames)); }
+    // StereoAudioProcessing.process  AudioPipeline.swift:3-11
+    void process(const float *inputLeft, const float *inputRight, float *outputLeft, float *outputRight, int frameCount) {
+        check(aw_spatializer_process_planar(h_, inputLeft, inputRight, outputLeft, outputRight, frameCount));
+    }
+    void reset() { check(aw_spatializer_reset(h_)); }
+    aw_spatializer *get() const { return h_; }
+  private:
+    aw_spatializer *h_ = nullptr;
+};
+
+// RealtimeAudioProcessor.swift:11-191
+class RealtimeAudioProcessor {
+  public:
+    RealtimeAudioProcessor(Context &ctx, const HRIR &hrir, const std::vector<int32_t> &leftTrack,
+                           const std::vector<int32_t> &rightTrack, int blockSize = 512, int maxFramesPerCallback = 4096) {
+        check(aw_realtime_create(ctx.get(), hrir.get(), (int32_t)leftTrack.size(), leftTrack.data(), rightTrack.data(), blockSize,
+                                 maxFramesPerCallback, &h_));
+    }
+    ~RealtimeAudioProcessor() { aw_realtime_destroy(h_); }
+    void process(const float *inputLeft, const float *inputRight, float *leftOutput, float *rightOutput, int frameCount) {   // :77
+        check(aw_realtime_process(h_, inputLeft, inputRight, leftOutput, rightOutput, frameCount));
+    }
+    void reset() { check(aw_realtime_reset(h_)); }                                                                            // :121
+  private:
+    aw_realtime *h_ = nullptr;
+};
+
+}  // namespace aw

@@ -1,0 +1,63 @@
+"""World-size-2 (gloo, CPU) coverage of the N>1 path: stream sharding, global stream ids for the
+synthetic input, and the final {sum frames, max elapsed} aggregate that bench.py performs over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from airwave_amd.sharding import aggregate_throughput, shard_streams, weak_shard
+
+
+def test_shard_partition_is_exact():
+    for total in [0, 1, 7, 128, 1024, 8192]:
+        for world in [1, 2, 3, 8]:
+            parts = [shard_streams(total, world, r) for r in range(world)]
+            assert parts[0][0] == 0 and sum(c for _, c in parts) == total
+            for (f0, c0), (f1, _) in zip(parts, parts[1:]):
+                assert f0 + c0 == f1
+            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+    assert weak_shard(128, 8, 3) == (384, 128)
+    with pytest.raises(ValueError):
+        shard_streams(10, 2, 2)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import airwave_oracle as orc
+    first, count = weak_shard(3, world, rank)
+    x = orc.synth_input(count, 64, 2, first_stream=first)        # global stream ids
+    frames, elapsed, rate = aggregate_throughput(float(count * 64), 0.5 + rank)
+    checksum = torch.tensor([float(np.abs(x).sum())], dtype=torch.float64)
+    dist.all_reduce(checksum)
+    q.put((rank, first, count, frames, elapsed, rate, float(checksum.item())))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_aggregate_like_bench():
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [0, 3]
+    for r in res:
+        assert r[3] == 2 * 3 * 64 and r[4] == 1.5 and abs(r[5] - 384 / 1.5) < 1e-9
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import airwave_oracle as orc
+    whole = float(np.abs(orc.synth_input(6, 64, 2)).sum())
+    assert abs(res[0][6] - whole) < 1e-6 * whole      # the two shards are exactly the single-process batch
