@@ -72,14 +72,19 @@ __device__ __forceinline__ long long xcd_remap(long long bid, long long nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int CS, int NP>
+// INTERIOR = true : tiles [tile_lo, tile_hi) of every stream (window inside the call's input)
+// INTERIOR = false: the remaining boundary tiles (history at the start, zero fill at the end)
+template <int CS, int NP, bool INTERIOR>
 __global__ void __launch_bounds__(kThreads) aw_fused_ols_kernel(TileParams p, long long nwg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GpuCtx ctx{reinterpret_cast<cf *>(smem), p.dbg ? p.dbg + (long long)blockIdx.x * kStamps : nullptr};
     const long long id = xcd_remap((long long)blockIdx.x, nwg);
-    const long long stream = id / p.tiles_per_stream;
-    const int tile = (int)(id % p.tiles_per_stream);
-    tile_fused_ols<GpuCtx, CS, NP>(ctx, p, stream, tile);
+    const int per = INTERIOR ? p.tile_hi - p.tile_lo : p.tiles_per_stream - (p.tile_hi - p.tile_lo);
+    const long long stream = id / per;
+    int tile = (int)(id % per);
+    if (INTERIOR) tile += p.tile_lo;
+    else if (tile >= p.tile_lo) tile += p.tile_hi - p.tile_lo;
+    tile_fused_ols<GpuCtx, CS, NP, INTERIOR>(ctx, p, stream, tile);
 }
 
 template <int CS>
@@ -105,7 +110,10 @@ hipError_t prepare_kernels() {
     hipError_t e = hipSuccess;
 #define AW_SET_ATTR(CS, NP)                                                                          \
     if (e == hipSuccess)                                                                             \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<CS, NP>),        \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<CS, NP, true>),  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);              \
+    if (e == hipSuccess)                                                                             \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<CS, NP, false>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     AW_FOR_EACH_VARIANT(AW_SET_ATTR)
 #undef AW_SET_ATTR
@@ -131,24 +139,40 @@ static int pick_variant(int C) {       // index into the variant list above
 }
 
 const char *fused_ols_kernel_name(int n_channels) {
-    static const char *names[] = {"aw_fused_ols_kernel<8, 4>", "aw_fused_ols_kernel<2, 1>", "aw_fused_ols_kernel<4, 2>",
-                                  "aw_fused_ols_kernel<0, 4>", "aw_fused_ols_kernel<0, 2>", "aw_fused_ols_kernel<0, 0>"};
+    static const char *names[] = {"aw_fused_ols_kernel<8, 4, true>", "aw_fused_ols_kernel<2, 1, true>",
+                                  "aw_fused_ols_kernel<4, 2, true>", "aw_fused_ols_kernel<0, 4, true>",
+                                  "aw_fused_ols_kernel<0, 2, true>", "aw_fused_ols_kernel<0, 0, true>"};
     return names[pick_variant(n_channels)];
 }
 
-hipError_t launch_fused_ols(const TileParams &p, int n_streams, hipStream_t stream) {
-    const long long nwg = (long long)n_streams * p.tiles_per_stream;
-    if (nwg <= 0) return hipSuccess;
-    if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
+template <bool INTERIOR>
+static void launch_variant(const TileParams &p, long long nwg, hipStream_t stream) {
     const dim3 grid((unsigned)nwg), block(kThreads);
     switch (pick_variant(p.n_channels)) {
-        case 0: hipLaunchKernelGGL((aw_fused_ols_kernel<8, 4>), grid, block, kLdsBytes, stream, p, nwg); break;
-        case 1: hipLaunchKernelGGL((aw_fused_ols_kernel<2, 1>), grid, block, kLdsBytes, stream, p, nwg); break;
-        case 2: hipLaunchKernelGGL((aw_fused_ols_kernel<4, 2>), grid, block, kLdsBytes, stream, p, nwg); break;
-        case 3: hipLaunchKernelGGL((aw_fused_ols_kernel<0, 4>), grid, block, kLdsBytes, stream, p, nwg); break;
-        case 4: hipLaunchKernelGGL((aw_fused_ols_kernel<0, 2>), grid, block, kLdsBytes, stream, p, nwg); break;
-        default: hipLaunchKernelGGL((aw_fused_ols_kernel<0, 0>), grid, block, kLdsBytes, stream, p, nwg); break;
+        case 0: hipLaunchKernelGGL((aw_fused_ols_kernel<8, 4, INTERIOR>), grid, block, kLdsBytes, stream, p, nwg); break;
+        case 1: hipLaunchKernelGGL((aw_fused_ols_kernel<2, 1, INTERIOR>), grid, block, kLdsBytes, stream, p, nwg); break;
+        case 2: hipLaunchKernelGGL((aw_fused_ols_kernel<4, 2, INTERIOR>), grid, block, kLdsBytes, stream, p, nwg); break;
+        case 3: hipLaunchKernelGGL((aw_fused_ols_kernel<0, 4, INTERIOR>), grid, block, kLdsBytes, stream, p, nwg); break;
+        case 4: hipLaunchKernelGGL((aw_fused_ols_kernel<0, 2, INTERIOR>), grid, block, kLdsBytes, stream, p, nwg); break;
+        default: hipLaunchKernelGGL((aw_fused_ols_kernel<0, 0, INTERIOR>), grid, block, kLdsBytes, stream, p, nwg); break;
     }
+}
+
+// Two launches: the interior tiles (fast uniform addressing) and the few boundary tiles per stream.
+hipError_t launch_fused_ols(const TileParams &p_in, int n_streams, hipStream_t stream) {
+    TileParams p = p_in;
+    // tile i is interior iff  i*hop - hist_len >= 0  and  i*hop - hist_len + N <= frames
+    long long lo = (p.hist_len + p.hop - 1) / p.hop;
+    long long hi = (p.frames - kN + p.hist_len) >= 0 ? (p.frames - kN + p.hist_len) / p.hop + 1 : 0;
+    if (hi > p.tiles_per_stream) hi = p.tiles_per_stream;
+    if (hi < lo) hi = lo;
+    if (lo > p.tiles_per_stream) { lo = p.tiles_per_stream; hi = lo; }
+    p.tile_lo = (int)lo; p.tile_hi = (int)hi;
+    const long long n_int = (long long)n_streams * (hi - lo);
+    const long long n_bnd = (long long)n_streams * (p.tiles_per_stream - (hi - lo));
+    if (n_int > 0x7fffffffLL || n_bnd > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (n_int > 0) launch_variant<true>(p, n_int, stream);
+    if (n_bnd > 0) launch_variant<false>(p, n_bnd, stream);
     return hipGetLastError();
 }
 

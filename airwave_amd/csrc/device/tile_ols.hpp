@@ -47,7 +47,7 @@ constexpr int kTwbElems = 8 * 8;                       // [kb][l0]    W_64^{l0 k
 constexpr int kLdsElems = 2 * kBufElems + kTwaElems + kTwbElems;
 constexpr int kLdsBytes = kLdsElems * 8;               // 152064 B (<= 160 KiB)
 #ifndef AW_PREFETCH_RAW_EARLY
-#define AW_PREFETCH_RAW_EARLY 0
+#define AW_PREFETCH_RAW_EARLY 1
 #endif
 constexpr bool kPrefetchRawEarly = AW_PREFETCH_RAW_EARLY != 0;
 #ifndef AW_TAB_EARLY
@@ -68,12 +68,14 @@ struct TileParams {
     const cf *tw1;          // [512]  : W_N^t (pass-1 twiddle base; powers are formed in registers)
     const cf *twa;          // [8][64]: W_512^{lane ka}, ka-major (sub-FFT pass A)
     const cf *twb;          // [8][8] : W_64^{l0 kb}, kb-major   (sub-FFT pass B)
+    const float *zeros;     // >= 64 floats of zeros: source of frames past the end of the call
     long long frames;       // frames per stream in this call
     int n_channels;         // C
     int n_pairs;            // ceil(C / 2)
     int hop;                // new output frames per tile, hop <= N - (taps - 1)
     int hist_len;           // = N - hop
     int tiles_per_stream;   // ceil(frames / hop)
+    int tile_lo, tile_hi;   // tiles [tile_lo, tile_hi) of every stream are INTERIOR (window inside the input)
     // partitioned (long-HRIR) path only:
     cf *spec;               // [stream][window][pair][16][512] input-window spectra (scratch)
     int partitions;         // P = ceil(taps / hop); tables are [partition][pair][N]
@@ -164,42 +166,55 @@ template <int CS>
 AW_HD void load_frame(const TileParams &p, const float *in_s, const float *hist_s, long long f,
                       float (&dst)[kBatchCh], int c0) {
     // in_s / hist_s: this stream's first frame in the call input / history buffer.
-    // Branch-free: always load from a clamped, valid address, then zero what lies past the end.
+    // Branch-free and with NO arithmetic on the loaded data: frames before the call come from the
+    // history buffer, frames past the end from a page of zeros, so the 16 loads of a batch have no
+    // consumers until pass 1 and all stay in flight together (a select on the loaded value made
+    // hipcc reuse one destination register and serialise the loads: 16 exposed round trips).
     const int C = CS > 0 ? CS : p.n_channels;
     const bool before = f < 0;                         // f >= -hist_len by construction
     const bool past = f >= p.frames;
-    const float *base = before ? hist_s : in_s;
-    long long idx = before ? (long long)p.hist_len + f : (past ? p.frames - 1 : f);
-    const float *src = base + idx * C;
+    const float *src = before ? hist_s + ((long long)p.hist_len + f) * C : (past ? p.zeros : in_s + f * C);
     if constexpr (CS > 0 && CS % 4 == 0) {
         const f4 v = *reinterpret_cast<const f4 *>(src + c0);
-        dst[0] = past ? 0.f : v.x; dst[1] = past ? 0.f : v.y; dst[2] = past ? 0.f : v.z; dst[3] = past ? 0.f : v.w;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
     } else if constexpr (CS == 2) {
         const f2 v = *reinterpret_cast<const f2 *>(src);
-        dst[0] = past ? 0.f : v.x; dst[1] = past ? 0.f : v.y; dst[2] = 0.0f; dst[3] = 0.0f;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = 0.0f; dst[3] = 0.0f;
     } else {
 #pragma unroll
         for (int c = 0; c < kBatchCh; ++c) {
             const int ch = c0 + c;
-            const float v = src[ch < C ? ch : C - 1];
-            dst[c] = (!past && ch < C) ? v : 0.0f;
+            const float *q = ch < C ? src + ch : p.zeros;      // padding channels of the last batch read zeros
+            dst[c] = *q;
         }
     }
 }
 
 // Register batch: 16 frames x 4 channels (two pairs) per thread.
-template <int CS>
+// INTERIOR tiles (window entirely inside the call's input: every tile but the first one or two
+// and the last of a stream) use wave-uniform frame bases + one per-lane offset, which hipcc turns
+// into scalar-base global loads: no per-frame address registers, no clamping arithmetic.
+template <int CS, bool INTERIOR>
 AW_HD void load_batch(const TileParams &p, const float *in_s, const float *hist_s, long long f0, int t, int c0,
                       float (&raw)[16][kBatchCh]) {
-#ifdef AW_ABL_NORAW      // timing ablation only (wrong results): no input traffic
+    if constexpr (INTERIOR && CS > 0) {
+        const float *lane_base = in_s + f0 * CS + c0;          // uniform
+        const int lane_off = t * CS;                            // per lane, 32-bit
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
+        for (int j = 0; j < 16; ++j) {
+            const float *src = lane_base + (long long)j * 512 * CS + lane_off;
+            if constexpr (CS % 4 == 0) {
+                const f4 v = *reinterpret_cast<const f4 *>(src);
+                raw[j][0] = v.x; raw[j][1] = v.y; raw[j][2] = v.z; raw[j][3] = v.w;
+            } else {
+                const f2 v = *reinterpret_cast<const f2 *>(src);
+                raw[j][0] = v.x; raw[j][1] = v.y; raw[j][2] = 0.f; raw[j][3] = 0.f;
+            }
+        }
+    } else {
 #pragma unroll
-        for (int c = 0; c < kBatchCh; ++c) raw[j][c] = 0.001f * (t + j) + c0 + c + (float)f0;
-    return;
-#endif
-#pragma unroll
-    for (int j = 0; j < 16; ++j) load_frame<CS>(p, in_s, hist_s, f0 + t + 512 * j, raw[j], c0);
+        for (int j = 0; j < 16; ++j) load_frame<CS>(p, in_s, hist_s, f0 + t + 512 * j, raw[j], c0);
+    }
 }
 
 // pass 1 of one pair: radix-16 over the thread's 16 window samples, twiddle, scatter to rows.
@@ -303,7 +318,7 @@ AW_HD void tile_inverse_store(Ctx &ctx, const TileParams &p, cf (&wacc)[2][8], c
 // NP: compile-time pair count (straight-line schedule, no phis around the prefetches); NP = 0 is
 // the generic variant: a runtime loop over batches that always processes two pairs (a phantom
 // pair has all-zero input, so whatever table it multiplies contributes nothing).
-template <class Ctx, int CS, int NP>
+template <class Ctx, int CS, int NP, bool INTERIOR>
 AW_HD void tile_fused_ols(Ctx &ctx, const TileParams &p, long long stream, int tile) {
     const int t = ctx.tid();
     const int lane = ctx.lane(), wave = ctx.wave();
@@ -318,7 +333,7 @@ AW_HD void tile_fused_ols(Ctx &ctx, const TileParams &p, long long stream, int t
 
     ctx.stamp(0);
     float raw[16][kBatchCh];
-    load_batch<CS>(p, in_s, hist_s, f0, t, 0, raw);
+    load_batch<CS, INTERIOR>(p, in_s, hist_s, f0, t, 0, raw);
     const cf w1 = p.tw1[t];
     twa[t] = p.twa[t];                                   // 512 entries, one per thread
     if (t < kTwbElems) twb[t] = p.twb[t];                // visible after the first barrier below
@@ -360,9 +375,9 @@ AW_HD void tile_fused_ols(Ctx &ctx, const TileParams &p, long long stream, int t
         ctx.stamp(pair0 > 0 ? 9 : 4);
         const int pair1 = (NP > 0 || pair0 + 1 < n_pairs) ? pair0 + 1 : pair0;   // phantom: any valid table
         if (two && kTabEarly) load_tab(p, pair1, wave, lane, tab);
-        if (kPrefetchRawEarly && more) load_batch<CS>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
+        if (kPrefetchRawEarly && more) load_batch<CS, INTERIOR>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
         if (two) pair_subfft_cmac(ctx, p, pair1, buf1, twa, twb, tab, lane, wave, wacc);
-        if (!kPrefetchRawEarly && more) load_batch<CS>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
+        if (!kPrefetchRawEarly && more) load_batch<CS, INTERIOR>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
         ctx.stamp(pair0 > 0 ? 10 : 5);
     };
     if constexpr (NP > 0) {
@@ -394,7 +409,7 @@ AW_HD void tile_part_forward(Ctx &ctx, const TileParams &p, long long stream, in
     cf *spec_w = p.spec + ((stream * n_windows + widx) * p.n_pairs) * (long long)kN;
 
     float raw[16][kBatchCh];
-    load_batch<CS>(p, in_s, hist_s, f0, t, 0, raw);
+    load_batch<CS, false>(p, in_s, hist_s, f0, t, 0, raw);
     const cf w1 = p.tw1[t];
     twa[t] = p.twa[t];
     if (t < kTwbElems) twb[t] = p.twb[t];
@@ -431,7 +446,7 @@ AW_HD void tile_part_forward(Ctx &ctx, const TileParams &p, long long stream, in
 #pragma unroll
                 for (int kc = 0; kc < 8; ++kc) dst[wave_row(wave, s) * kSub + lane + 64 * kc] = z[s][kc];
         }
-        if (more) load_batch<CS>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
+        if (more) load_batch<CS, false>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
     }
 }
 

@@ -86,6 +86,8 @@ static aw_status context_create_impl(int32_t device, void *ext_stream, bool use_
     if (e == hipSuccess) e = upload(tw.tw1, &c->d_tw1);
     if (e == hipSuccess) e = upload(tw.twa, &c->d_twa);
     if (e == hipSuccess) e = upload(tw.twb, &c->d_twb);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_zeros), 4096);
+    if (e == hipSuccess) e = hipMemset(c->d_zeros, 0, 4096);
     if (e != hipSuccess) {
         aw_context_destroy(c);
         return awr::hip_fail(e, "context setup");
@@ -105,6 +107,7 @@ void aw_context_destroy(aw_context *c) {
     if (c->d_tw1) (void)hipFree(c->d_tw1);
     if (c->d_twa) (void)hipFree(c->d_twa);
     if (c->d_twb) (void)hipFree(c->d_twb);
+    if (c->d_zeros) (void)hipFree(c->d_zeros);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -339,7 +342,7 @@ aw_status aw_spatializer_debug_stamps(aw_spatializer *sp, uint64_t *host_out, in
 static aw_status sp_process_fused(aw_spatializer *sp, const float *in, float *out, int64_t frames) {
     awk::TileParams p{};
     p.in = in; p.out = out; p.hist = sp->d_hist[sp->hist_cur];
-    p.tab = sp->d_tab; p.tw1 = sp->ctx->d_tw1; p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb;
+    p.tab = sp->d_tab; p.tw1 = sp->ctx->d_tw1; p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb; p.zeros = sp->ctx->d_zeros;
     p.frames = frames; p.n_channels = sp->n_channels; p.n_pairs = sp->n_pairs;
     p.hop = sp->hop; p.hist_len = sp->hist_len;
     p.tiles_per_stream = (int)((frames + sp->hop - 1) / sp->hop);
@@ -399,7 +402,7 @@ static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, flo
         p.in = in + (size_t)s0 * frames * sp->n_channels;
         p.out = out + (size_t)s0 * frames * 2;
         p.hist = sp->d_hist[sp->hist_cur] + (size_t)s0 * sp->hist_len * sp->n_channels;
-        p.tab = sp->d_tab; p.tw1 = sp->ctx->d_tw1; p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb;
+        p.tab = sp->d_tab; p.tw1 = sp->ctx->d_tw1; p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb; p.zeros = sp->ctx->d_zeros;
         p.frames = frames; p.n_channels = sp->n_channels; p.n_pairs = sp->n_pairs;
         p.hop = B; p.hist_len = sp->hist_len; p.tiles_per_stream = n_blocks;
         p.spec = sp->d_spec; p.partitions = P; p.n_blocks = n_blocks; p.first_valid = N - B;

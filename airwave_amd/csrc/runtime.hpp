@@ -29,6 +29,7 @@ struct aw_context {
     bool owns_stream = false;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     awk::cf *d_tw1 = nullptr, *d_twa = nullptr, *d_twb = nullptr;   // twiddle rows (FFTSetupManager analogue)
+    float *d_zeros = nullptr;                                       // page of zeros (frames past the end of a call)
 };
 
 struct aw_hrir {

@@ -17,6 +17,8 @@
 
 namespace {
 
+alignas(16) float g_zeros[1024] = {0};
+
 struct EmuShared {
     std::barrier<> wg{awk::kThreads};
     std::vector<std::unique_ptr<std::barrier<>>> wave;
@@ -57,7 +59,7 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
     awh::build_pair_tables(tracks, n_tracks, taps, n_channels, left_track, right_track, 0, taps, tab);
     std::vector<float> zero_hist;
     TileParams p{};
-    p.in = in; p.out = out; p.tab = tab.data(); p.tw1 = tw.tw1.data(); p.twa = tw.twa.data(); p.twb = tw.twb.data();
+    p.in = in; p.out = out; p.tab = tab.data(); p.tw1 = tw.tw1.data(); p.twa = tw.twa.data(); p.twb = tw.twb.data(); p.zeros = g_zeros;
     p.frames = frames; p.n_channels = n_channels; p.n_pairs = (n_channels + 1) / 2;
     p.hop = hop; p.hist_len = kN - hop;
     p.tiles_per_stream = (int)((frames + hop - 1) / hop);
@@ -69,17 +71,20 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
     EmuShared sh;
     for (int s = 0; s < n_streams; ++s) {
         for (int tile = 0; tile < p.tiles_per_stream; ++tile) {
+            const long long w0 = (long long)tile * p.hop - p.hist_len;
+            const bool interior = w0 >= 0 && w0 + kN <= p.frames;
             std::vector<std::thread> th;
             th.reserve(kThreads);
             for (int t = 0; t < kThreads; ++t)
                 th.emplace_back([&, t]() {
                     EmuCtx ctx{t, &sh};
-                    if (variant == 1 && n_channels == 8) tile_fused_ols<EmuCtx, 8, 4>(ctx, p, s, tile);
-                    else if (variant == 1 && n_channels == 2) tile_fused_ols<EmuCtx, 2, 1>(ctx, p, s, tile);
-                    else if (variant == 1 && n_channels == 7) tile_fused_ols<EmuCtx, 0, 4>(ctx, p, s, tile);
-                    else if (variant == 1 && n_channels == 3) tile_fused_ols<EmuCtx, 0, 2>(ctx, p, s, tile);
-                    else if (variant == 1 && n_channels == 4) tile_fused_ols<EmuCtx, 4, 2>(ctx, p, s, tile);
-                    else tile_fused_ols<EmuCtx, 0, 0>(ctx, p, s, tile);
+                    if (variant == 1 && n_channels == 8 && interior) tile_fused_ols<EmuCtx, 8, 4, true>(ctx, p, s, tile);
+                    else if (variant == 1 && n_channels == 8) tile_fused_ols<EmuCtx, 8, 4, false>(ctx, p, s, tile);
+                    else if (variant == 1 && n_channels == 2) tile_fused_ols<EmuCtx, 2, 1, false>(ctx, p, s, tile);
+                    else if (variant == 1 && n_channels == 7) tile_fused_ols<EmuCtx, 0, 4, false>(ctx, p, s, tile);
+                    else if (variant == 1 && n_channels == 3) tile_fused_ols<EmuCtx, 0, 2, false>(ctx, p, s, tile);
+                    else if (variant == 1 && n_channels == 4) tile_fused_ols<EmuCtx, 4, 2, false>(ctx, p, s, tile);
+                    else tile_fused_ols<EmuCtx, 0, 0, false>(ctx, p, s, tile);
                 });
             for (auto &x : th) x.join();
         }
@@ -101,7 +106,7 @@ int emu_partitioned(const float *in, float *out, const float *hist, const float 
         all.insert(all.end(), tab.begin(), tab.end());
     }
     TileParams p{};
-    p.in = in; p.out = out; p.tab = all.data(); p.tw1 = tw.tw1.data(); p.twa = tw.twa.data(); p.twb = tw.twb.data();
+    p.in = in; p.out = out; p.tab = all.data(); p.tw1 = tw.tw1.data(); p.twa = tw.twa.data(); p.twb = tw.twb.data(); p.zeros = g_zeros;
     p.frames = frames; p.n_channels = n_channels; p.n_pairs = (n_channels + 1) / 2;
     p.hop = B; p.hist_len = P * B; p.partitions = P; p.n_blocks = (int)((frames + B - 1) / B);
     p.tiles_per_stream = p.n_blocks; p.first_valid = kN - B;
