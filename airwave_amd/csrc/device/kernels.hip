@@ -10,6 +10,9 @@ namespace awk {
 #ifndef AW_STAGGER_SLOTS
 #define AW_STAGGER_SLOTS 0       // s_sleep argument (x64 cycles) for waves 4-7 after a barrier; 0 = off
 #endif
+#ifndef AW_LDS_NO_READ2
+#define AW_LDS_NO_READ2 0
+#endif
 #ifndef AW_STAMPS
 #define AW_STAMPS 0
 #endif
@@ -46,6 +49,20 @@ struct GpuCtx {
         asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 1f\n\ts_sleep %1\n1:" ::"s"(wave), "n"(AW_STAGGER_SLOTS) : "scc");
 #else
         (void)wave;
+#endif
+    }
+    // LDS read of one complex value as a single ds_read_b64.  AW_LDS_NO_READ2: volatile 64-bit
+    // access, which keeps hipcc from fusing neighbours into ds_read2_b64 / ds_read2st64_b64
+    // (measured 8.3 cycles per wave-instruction against 2 x 2.6 for two ds_read_b64, tools/ubench/lds_rate.hip).
+    __device__ __forceinline__ cf ld(const cf *p) const {
+#if AW_LDS_NO_READ2
+        const unsigned long long v = *reinterpret_cast<const volatile unsigned long long *>(p);
+        cf r;
+        r.x = __uint_as_float((unsigned)v);
+        r.y = __uint_as_float((unsigned)(v >> 32));
+        return r;
+#else
+        return *p;
 #endif
     }
     // Hides a value's provenance from the optimiser (no instruction emitted): stops LICM/CSE from

@@ -53,7 +53,8 @@ constexpr bool kPrefetchRawEarly = AW_PREFETCH_RAW_EARLY != 0;
 #ifndef AW_TAB_EARLY
 #define AW_TAB_EARLY 0
 #endif
-constexpr bool kTabEarly = AW_TAB_EARLY != 0;                      // issue a pair's table loads before its sub-FFTs   // issue the next batch's frame loads before pair 1's sub-FFTs
+constexpr bool kTabEarly0 = (AW_TAB_EARLY & 1) != 0;   // first pair of a batch: table loads issued before the barrier
+constexpr bool kTabEarly1 = (AW_TAB_EARLY & 2) != 0;   // second pair: issued right after the first pair's CMAC   // issue the next batch's frame loads before pair 1's sub-FFTs
 constexpr int kBatchCh = 4;       // input channels held in registers at once (two pairs)
 
 struct alignas(16) cf2 {          // one table entry: A[k], B[k]
@@ -122,7 +123,7 @@ AW_HD void sub_fft512x2(Ctx &ctx, cf (&a)[2][8], cf *scr0, cf *scr1, const cf *t
     fft8<INV>(a[1]);
 #pragma unroll
     for (int ka = 1; ka < 8; ++ka) {
-        const cf w = twa[ka * 64 + lane];
+        const cf w = ctx.ld(twa + ka * 64 + lane);
         a[0][ka] = twmul<INV>(a[0][ka], w);
         a[1][ka] = twmul<INV>(a[1][ka], w);
     }
@@ -132,14 +133,14 @@ AW_HD void sub_fft512x2(Ctx &ctx, cf (&a)[2][8], cf *scr0, cf *scr1, const cf *t
     ctx.wave_sync();
     const int l0 = lane & 7, kap = lane >> 3;
 #pragma unroll
-    for (int l1 = 0; l1 < 8; ++l1) { a[0][l1] = scr0[kap * 72 + l0 + 8 * l1]; a[1][l1] = scr1[kap * 72 + l0 + 8 * l1]; }
+    for (int l1 = 0; l1 < 8; ++l1) { a[0][l1] = ctx.ld(scr0 + kap * 72 + l0 + 8 * l1); a[1][l1] = ctx.ld(scr1 + kap * 72 + l0 + 8 * l1); }
     ctx.wave_sync();
     // pass B: radix-8 over l1 -> kb, twiddle W_64^{l0 kb}
     fft8<INV>(a[0]);
     fft8<INV>(a[1]);
 #pragma unroll
     for (int kb = 1; kb < 8; ++kb) {
-        const cf w = twb[kb * 8 + l0];
+        const cf w = ctx.ld(twb + kb * 8 + l0);
         a[0][kb] = twmul<INV>(a[0][kb], w);
         a[1][kb] = twmul<INV>(a[1][kb], w);
     }
@@ -148,7 +149,7 @@ AW_HD void sub_fft512x2(Ctx &ctx, cf (&a)[2][8], cf *scr0, cf *scr1, const cf *t
     for (int kb = 0; kb < 8; ++kb) { scr0[(kb * 8 + kap) * 9 + l0] = a[0][kb]; scr1[(kb * 8 + kap) * 9 + l0] = a[1][kb]; }
     ctx.wave_sync();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { a[0][i] = scr0[lane * 9 + i]; a[1][i] = scr1[lane * 9 + i]; }   // chunk kb''*8 + ka'' == lane
+    for (int i = 0; i < 8; ++i) { a[0][i] = ctx.ld(scr0 + lane * 9 + i); a[1][i] = ctx.ld(scr1 + lane * 9 + i); }   // chunk kb''*8 + ka'' == lane
     ctx.wave_sync();
     // pass C: radix-8 over l0 -> kc.  Now a[s][kc] = X_s[ka'' + 8 kb'' + 64 kc] = X_s[lane + 64 kc]
     fft8<INV>(a[0]);
@@ -246,15 +247,15 @@ AW_HD void load_tab(const TileParams &p, int pair, int wave, int lane, cf2 (&tab
 // Per wave: the two 512-point sub-FFTs of its rows, then W += Z A + conj(Z[N-k]) B.
 template <class Ctx>
 AW_HD void pair_subfft_cmac(Ctx &ctx, const TileParams &p, int pair, cf *buf, const cf *twa, const cf *twb,
-                            cf2 (&tab)[2][8], int lane, int wave, cf (&wacc)[2][8]) {
+                            cf2 (&tab)[2][8], int lane, int wave, cf (&wacc)[2][8], bool tab_loaded) {
     cf *row0 = buf + wave_row(wave, 0) * kRowStride;
     cf *row1 = buf + wave_row(wave, 1) * kRowStride;
     cf z[2][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { z[0][j] = row0[lane + 64 * j]; z[1][j] = row1[lane + 64 * j]; }
+    for (int j = 0; j < 8; ++j) { z[0][j] = ctx.ld(row0 + lane + 64 * j); z[1][j] = ctx.ld(row1 + lane + 64 * j); }
     ctx.wave_sync();
     sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
-    if (!kTabEarly) load_tab(p, pair, wave, lane, tab);
+    if (!tab_loaded) load_tab(p, pair, wave, lane, tab);
     // publish Z rows inside the wave, then CMAC against the partner bins
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc) { row0[lane + 64 * kc] = z[0][kc]; row1[lane + 64 * kc] = z[1][kc]; }
@@ -269,7 +270,7 @@ AW_HD void pair_subfft_cmac(Ctx &ctx, const TileParams &p, int pair, cf *buf, co
         for (int kc = 0; kc < 8; ++kc) {
             int idx = bidx - 64 * kc;
             if (kc == 0) idx &= 511;                       // only (row 0, lane 0, kc 0) wraps: 512 -> 0
-            const cf zp = prow[idx];
+            const cf zp = ctx.ld(prow + idx);
             wacc[s][kc] = cfma(z[s][kc], tab[s][kc].a, wacc[s][kc]);
             wacc[s][kc] = cfmac(zp, tab[s][kc].b, wacc[s][kc]);
         }
@@ -297,7 +298,7 @@ AW_HD void tile_inverse_store(Ctx &ctx, const TileParams &p, cf (&wacc)[2][8], c
     ctx.stamp(12);
     cf y[16];
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) y[k1] = buf0[k1 * kRowStride + t];
+    for (int k1 = 0; k1 < 16; ++k1) y[k1] = ctx.ld(buf0 + k1 * kRowStride + t);
     {
         cf pw[16];
         tw_powers(ctx.opaque(w1), pw);
@@ -366,17 +367,17 @@ AW_HD void tile_fused_ols(Ctx &ctx, const TileParams &p, long long stream, int t
             }
         }
         cf2 tab[2][8];
-        if (kTabEarly) load_tab(p, pair0, wave, lane, tab);
+        if (kTabEarly0) load_tab(p, pair0, wave, lane, tab);
         ctx.stamp(pair0 > 0 ? 7 : 2);
         ctx.barrier();
         ctx.stagger(wave, p.stagger);
         ctx.stamp(pair0 > 0 ? 8 : 3);
-        pair_subfft_cmac(ctx, p, pair0, buf0, twa, twb, tab, lane, wave, wacc);
+        pair_subfft_cmac(ctx, p, pair0, buf0, twa, twb, tab, lane, wave, wacc, kTabEarly0);
         ctx.stamp(pair0 > 0 ? 9 : 4);
         const int pair1 = (NP > 0 || pair0 + 1 < n_pairs) ? pair0 + 1 : pair0;   // phantom: any valid table
-        if (two && kTabEarly) load_tab(p, pair1, wave, lane, tab);
+        if (two && kTabEarly1) load_tab(p, pair1, wave, lane, tab);
         if (kPrefetchRawEarly && more) load_batch<CS, INTERIOR>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
-        if (two) pair_subfft_cmac(ctx, p, pair1, buf1, twa, twb, tab, lane, wave, wacc);
+        if (two) pair_subfft_cmac(ctx, p, pair1, buf1, twa, twb, tab, lane, wave, wacc, kTabEarly1);
         if (!kPrefetchRawEarly && more) load_batch<CS, INTERIOR>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
         ctx.stamp(pair0 > 0 ? 10 : 5);
     };
@@ -437,7 +438,7 @@ AW_HD void tile_part_forward(Ctx &ctx, const TileParams &p, long long stream, in
             cf *row1 = buf + wave_row(wave, 1) * kRowStride;
             cf z[2][8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { z[0][j] = row0[lane + 64 * j]; z[1][j] = row1[lane + 64 * j]; }
+            for (int j = 0; j < 8; ++j) { z[0][j] = ctx.ld(row0 + lane + 64 * j); z[1][j] = ctx.ld(row1 + lane + 64 * j); }
             ctx.wave_sync();
             sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
             cf *dst = spec_w + (long long)(pair0 + h) * kN;
