@@ -91,6 +91,10 @@ template <bool INV, int M> AW_HD cf mul_w16(cf a) {
 
 // 16-point DFT, natural order in/out (4x4 decomposition).
 template <bool INV> AW_HD void fft16(cf (&v)[16]) {
+#ifdef AW_ABL_NOFFT      // timing ablation only (wrong results): butterflies removed, data flow kept
+    v[0] = v[0] + v[15];
+    return;
+#endif
     // F_{n0}[k0] = fft4 over n1 of v[4 n1 + n0]
     fft4<INV>(v[0], v[4], v[8], v[12]);
     fft4<INV>(v[1], v[5], v[9], v[13]);

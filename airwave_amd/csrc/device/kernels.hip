@@ -20,17 +20,25 @@ namespace awk {
 struct GpuCtx {
     cf *lds_;
     unsigned long long *dbg_;
-    // Phase stamps (diagnostic build only: -DAW_STAMPS=1; never in the shipped kernel).  Thread 0
-    // of the workgroup records s_memtime into a buffer nothing else reads.
-    __device__ __forceinline__ void stamp(int i) const {
+    // Phase stamps (diagnostic build only: -DAW_STAMPS=1; never in the shipped kernel).  Every wave
+    // reads the shader clock into SGPRs (uniform, no VGPRs, no branches in the timed code); thread 0
+    // stores them once at the end into a buffer nothing else reads.
 #if AW_STAMPS
-        if (threadIdx.x == 0 && dbg_) {
-            unsigned long long tm;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm)::"memory");
-            dbg_[i] = tm;
-        }
+    unsigned long long st_[kStamps];
+#endif
+    __device__ __forceinline__ void stamp(int i) {
+#if AW_STAMPS
+        unsigned long long tm;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm)::"memory");
+        st_[i] = tm;
 #else
         (void)i;
+#endif
+    }
+    __device__ __forceinline__ void flush_stamps() {
+#if AW_STAMPS
+        if (threadIdx.x == 0 && dbg_)
+            for (int i = 0; i < kStamps; ++i) dbg_[i] = st_[i];
 #endif
     }
     __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
@@ -189,7 +197,11 @@ hipError_t launch_fused_ols(const TileParams &p_in, int n_streams, hipStream_t s
     const long long n_bnd = (long long)n_streams * (p.tiles_per_stream - (hi - lo));
     if (n_int > 0x7fffffffLL || n_bnd > 0x7fffffffLL) return hipErrorInvalidValue;
     if (n_int > 0) launch_variant<true>(p, n_int, stream);
-    if (n_bnd > 0) launch_variant<false>(p, n_bnd, stream);
+    if (n_bnd > 0) {
+        TileParams pb = p;
+        pb.dbg = nullptr;                 // diagnostic stamps describe the interior launch only
+        launch_variant<false>(pb, n_bnd, stream);
+    }
     return hipGetLastError();
 }
 

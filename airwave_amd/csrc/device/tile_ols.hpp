@@ -314,6 +314,7 @@ AW_HD void tile_inverse_store(Ctx &ctx, const TileParams &p, cf (&wacc)[2][8], c
             *reinterpret_cast<cf *>(p.out + ((long long)stream * p.frames + f) * 2) = y[j];
     }
     ctx.stamp(13);
+    ctx.flush_stamps();
 }
 
 // NP: compile-time pair count (straight-line schedule, no phis around the prefetches); NP = 0 is

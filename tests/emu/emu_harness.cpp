@@ -37,6 +37,7 @@ struct EmuCtx {
     awk::cf *lds() const { return sh->lds.data(); }
     awk::cf opaque(awk::cf v) const { return v; }
     void stamp(int) const {}
+    void flush_stamps() const {}
     awk::cf ld(const awk::cf *p) const { return *p; }
     void stagger(int, int) const {}
     void barrier() const { sh->wg.arrive_and_wait(); }
