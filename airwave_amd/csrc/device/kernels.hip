@@ -5,6 +5,8 @@
 // utility kernels (history carry, synthetic fill, planar<->interleaved).
 #include "kernels.hpp"
 
+#include <cstdlib>
+
 namespace awk {
 
 #ifndef AW_STAGGER_SLOTS
@@ -35,9 +37,10 @@ struct GpuCtx {
         (void)i;
 #endif
     }
+    int stamp_thread_ = 0;
     __device__ __forceinline__ void flush_stamps() {
 #if AW_STAMPS
-        if (threadIdx.x == 0 && dbg_)
+        if ((int)threadIdx.x == stamp_thread_ && dbg_)
             for (int i = 0; i < kStamps; ++i) dbg_[i] = st_[i];
 #endif
     }
@@ -75,6 +78,10 @@ struct GpuCtx {
     }
     // Hides a value's provenance from the optimiser (no instruction emitted): stops LICM/CSE from
     // keeping re-computable values live across the whole tile.
+    __device__ __forceinline__ int opaque_i(int v) const {
+        asm volatile("" : "+v"(v));
+        return v;
+    }
     __device__ __forceinline__ cf opaque(cf v) const {
         asm volatile("" : "+v"(v.x), "+v"(v.y));
         return v;
@@ -100,16 +107,21 @@ __device__ __forceinline__ long long xcd_remap(long long bid, long long nwg) {
 // INTERIOR = true : tiles [tile_lo, tile_hi) of every stream (window inside the call's input)
 // INTERIOR = false: the remaining boundary tiles (history at the start, zero fill at the end)
 template <int CS, int NP, bool INTERIOR>
-__global__ void __launch_bounds__(kThreads) aw_fused_ols_kernel(TileParams p, long long nwg) {
+__global__ void __launch_bounds__(kThreads) aw_fused_ols_kernel(TileParams p, long long n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GpuCtx ctx{reinterpret_cast<cf *>(smem), p.dbg ? p.dbg + (long long)blockIdx.x * kStamps : nullptr};
-    const long long id = xcd_remap((long long)blockIdx.x, nwg);
-    const int per = INTERIOR ? p.tile_hi - p.tile_lo : p.tiles_per_stream - (p.tile_hi - p.tile_lo);
-    const long long stream = id / per;
-    int tile = (int)(id % per);
-    if (INTERIOR) tile += p.tile_lo;
-    else if (tile >= p.tile_lo) tile += p.tile_hi - p.tile_lo;
-    tile_fused_ols<GpuCtx, CS, NP, INTERIOR>(ctx, p, stream, tile);
+    ctx.stamp_thread_ = p.stagger;          // diagnostic builds: which thread's wave is recorded
+    // Persistent workgroups, XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so
+    // blockIdx % 8 labels the XCD group.  Each group owns a contiguous eighth of the tile list and
+    // its workgroups walk it interleaved, so the ~32 tiles in flight on one XCD are consecutive
+    // tiles of a stream: their overlapping input windows meet in that XCD's L2 (speed only).
+    const long long g = gridDim.x, b = blockIdx.x;
+    const long long xcd = b % 8, slot = b / 8;
+    const long long per_xcd_wg = (g - xcd + 7) / 8;                       // workgroups in this group
+    const long long q = n_tiles / 8, r = n_tiles % 8;
+    const long long lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const long long hi = lo + (xcd < r ? q + 1 : q);
+    tiles_fused_ols<GpuCtx, CS, NP, INTERIOR>(ctx, p, lo + slot, per_xcd_wg, hi);
 }
 
 template <int CS>
@@ -128,11 +140,20 @@ __global__ void __launch_bounds__(kThreads) aw_part_cmac_ifft_kernel(TileParams 
     tile_part_cmac_inverse<GpuCtx>(ctx, p, id / p.n_blocks, (int)(id % p.n_blocks));
 }
 
+static int g_persistent_wgs = 256;      // one resident workgroup per CU (152 KB LDS each)
+
 // Variants: <CS, NP> = <vector-load channel count or 0, compile-time pair count or 0 (generic)>
 #define AW_FOR_EACH_VARIANT(X) X(8, 4) X(2, 1) X(4, 2) X(0, 4) X(0, 2) X(0, 0)
 
 hipError_t prepare_kernels() {
     hipError_t e = hipSuccess;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            g_persistent_wgs = cus;
+        if (const char *e2 = getenv("AW_PERSISTENT_WGS")) g_persistent_wgs = atoi(e2) > 0 ? atoi(e2) : g_persistent_wgs;
+    }
 #define AW_SET_ATTR(CS, NP)                                                                          \
     if (e == hipSuccess)                                                                             \
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<CS, NP, true>),  \
@@ -172,7 +193,7 @@ const char *fused_ols_kernel_name(int n_channels) {
 
 template <bool INTERIOR>
 static void launch_variant(const TileParams &p, long long nwg, hipStream_t stream) {
-    const dim3 grid((unsigned)nwg), block(kThreads);
+    const dim3 grid((unsigned)(nwg < g_persistent_wgs ? nwg : g_persistent_wgs)), block(kThreads);
     switch (pick_variant(p.n_channels)) {
         case 0: hipLaunchKernelGGL((aw_fused_ols_kernel<8, 4, INTERIOR>), grid, block, kLdsBytes, stream, p, nwg); break;
         case 1: hipLaunchKernelGGL((aw_fused_ols_kernel<2, 1, INTERIOR>), grid, block, kLdsBytes, stream, p, nwg); break;

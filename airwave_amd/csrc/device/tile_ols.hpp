@@ -278,21 +278,23 @@ AW_HD void pair_subfft_cmac(Ctx &ctx, const TileParams &p, int pair, cf *buf, co
     ctx.wave_sync();    // partner reads done before this wave reuses its rows as scratch
 }
 
-// Inverse half of a tile: per-wave 512-point inverse sub-FFTs of W (scratch = the wave's own rows
-// of buf0, which only it touches until the barrier), exchange, radix-16 across rows, then store
-// window positions m >= first_valid whose frame f0 + m lies inside the call.
+// Inverse half of a tile, part 1: per-wave 512-point inverse sub-FFTs of W (scratch = the wave's
+// own rows of buf0, which only it touches until the barrier), results published row-wise.
 template <class Ctx>
-AW_HD void tile_inverse_store(Ctx &ctx, const TileParams &p, cf (&wacc)[2][8], cf *buf0, const cf *twa, const cf *twb,
-                              cf w1, long long stream, long long f0, int first_valid) {
-    const int t = ctx.tid();
+AW_HD void tile_inverse_rows(Ctx &ctx, cf (&wacc)[2][8], cf *buf0, const cf *twa, const cf *twb) {
     const int lane = ctx.lane(), wave = ctx.wave();
-    {
-        cf *row0 = buf0 + wave_row(wave, 0) * kRowStride;
-        cf *row1 = buf0 + wave_row(wave, 1) * kRowStride;
-        sub_fft512x2<true>(ctx, wacc, row0, row1, twa, twb, lane);
+    cf *row0 = buf0 + wave_row(wave, 0) * kRowStride;
+    cf *row1 = buf0 + wave_row(wave, 1) * kRowStride;
+    sub_fft512x2<true>(ctx, wacc, row0, row1, twa, twb, lane);
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc) { row0[lane + 64 * kc] = wacc[0][kc]; row1[lane + 64 * kc] = wacc[1][kc]; }
-    }
+    for (int kc = 0; kc < 8; ++kc) { row0[lane + 64 * kc] = wacc[0][kc]; row1[lane + 64 * kc] = wacc[1][kc]; }
+}
+
+// Part 2: barrier, radix-16 across rows, then store window positions m >= first_valid whose
+// frame f0 + m lies inside the call.
+template <class Ctx>
+AW_HD void tile_inverse_final(Ctx &ctx, const TileParams &p, cf *buf0, cf w1, int t, long long stream, long long f0,
+                              int first_valid) {
     ctx.stamp(11);
     ctx.barrier();
     ctx.stamp(12);
@@ -320,25 +322,57 @@ AW_HD void tile_inverse_store(Ctx &ctx, const TileParams &p, cf (&wacc)[2][8], c
 // NP: compile-time pair count (straight-line schedule, no phis around the prefetches); NP = 0 is
 // the generic variant: a runtime loop over batches that always processes two pairs (a phantom
 // pair has all-zero input, so whatever table it multiplies contributes nothing).
+// Persistent form: the workgroup walks tiles first, first + step, ... < end (ids in the launch's
+// tile order, see tile_of()).  The next tile's first frame batch is issued before the inverse of
+// the current one, so its HBM latency (measured ~10 k cycles when exposed at tile start, 18 % of a
+// tile) hides under the inverse transform, and no workgroup launch gap separates tiles.
+struct TileId { long long stream; int tile; };
+
+template <bool INTERIOR>
+AW_HD TileId tile_of(const TileParams &p, long long id) {
+    const unsigned per = (unsigned)(INTERIOR ? p.tile_hi - p.tile_lo : p.tiles_per_stream - (p.tile_hi - p.tile_lo));
+    TileId r;
+    const unsigned q = (unsigned)id / per;               // tile ids fit 31 bits (checked at launch): 32-bit divide
+    r.stream = q;
+    int tile = (int)((unsigned)id - q * per);
+    if (INTERIOR) tile += p.tile_lo;
+    else if (tile >= p.tile_lo) tile += p.tile_hi - p.tile_lo;
+    r.tile = tile;
+    return r;
+}
+
 template <class Ctx, int CS, int NP, bool INTERIOR>
-AW_HD void tile_fused_ols(Ctx &ctx, const TileParams &p, long long stream, int tile) {
-    const int t = ctx.tid();
-    const int lane = ctx.lane(), wave = ctx.wave();
+AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long long step, long long end) {
+    const int t0 = ctx.tid();
+    int t = t0, lane = ctx.lane();
+    const int wave = ctx.wave();
     cf *buf0 = ctx.lds();
     cf *buf1 = buf0 + kBufElems;
     cf *twa = buf1 + kBufElems;        // LDS copies of the sub-FFT twiddles
     cf *twb = twa + kTwaElems;
     const int Cn = CS > 0 ? CS : p.n_channels;
-    const float *in_s = p.in + stream * p.frames * Cn;
-    const float *hist_s = p.hist + stream * (long long)p.hist_len * Cn;
-    const long long f0 = (long long)tile * p.hop - p.hist_len;     // frame of window position 0
-
-    ctx.stamp(0);
-    float raw[16][kBatchCh];
-    load_batch<CS, INTERIOR>(p, in_s, hist_s, f0, t, 0, raw);
+    if (first >= end) return;
     const cf w1 = p.tw1[t];
     twa[t] = p.twa[t];                                   // 512 entries, one per thread
     if (t < kTwbElems) twb[t] = p.twb[t];                // visible after the first barrier below
+
+    float raw[16][kBatchCh];
+    {
+        const TileId id0 = tile_of<INTERIOR>(p, first);
+        load_batch<CS, INTERIOR>(p, p.in + id0.stream * p.frames * Cn, p.hist + id0.stream * (long long)p.hist_len * Cn,
+                                 (long long)id0.tile * p.hop - p.hist_len, t, 0, raw);
+    }
+    for (long long id = first; id < end; id += step) {
+    // Per-iteration opaque thread index: keeps lane-dependent addresses from being hoisted out of
+    // the tile loop and held live across it.
+    t = ctx.opaque_i(t0);
+    lane = t & 63;
+    const TileId cur = tile_of<INTERIOR>(p, id);
+    const long long stream = cur.stream;
+    const float *in_s = p.in + stream * p.frames * Cn;
+    const float *hist_s = p.hist + stream * (long long)p.hist_len * Cn;
+    const long long f0 = (long long)cur.tile * p.hop - p.hist_len;     // frame of window position 0
+    ctx.stamp(0);
 
     cf wacc[2][8];
 #pragma unroll
@@ -389,7 +423,16 @@ AW_HD void tile_fused_ols(Ctx &ctx, const TileParams &p, long long stream, int t
         for (int pair0 = 0; pair0 < n_pairs; pair0 += 2) batch(pair0, true, pair0 + 2 < n_pairs);
     }
 
-    tile_inverse_store(ctx, p, wacc, buf0, twa, twb, w1, stream, f0, p.hist_len);
+    tile_inverse_rows(ctx, wacc, buf0, twa, twb);
+    {   // prefetch the next tile's first batch here, where few registers are live (unconditional:
+        // the last iteration re-reads its own batch; a branch would put phis on 64 registers)
+        const TileId nx = tile_of<INTERIOR>(p, id + step < end ? id + step : id);
+        load_batch<CS, INTERIOR>(p, p.in + nx.stream * p.frames * Cn, p.hist + nx.stream * (long long)p.hist_len * Cn,
+                                 (long long)nx.tile * p.hop - p.hist_len, t, 0, raw);
+    }
+    tile_inverse_final(ctx, p, buf0, w1, t, stream, f0, p.hist_len);
+    ctx.barrier();                                       // the final exchange has been read before buf0 is rewritten
+    }
 }
 
 // ---- partitioned path (taps too long for one window: Y[b] = sum_q X[b-q] . H_q, the same
@@ -497,7 +540,8 @@ AW_HD void tile_part_cmac_inverse(Ctx &ctx, const TileParams &p, long long strea
         }
     }
     const long long f0 = ((long long)block - 1) * p.hop;             // window of block b: frames [(b-1)B, (b+1)B)
-    tile_inverse_store(ctx, p, wacc, buf0, twa, twb, w1, stream, f0, p.first_valid);
+    tile_inverse_rows(ctx, wacc, buf0, twa, twb);
+    tile_inverse_final(ctx, p, buf0, w1, t, stream, f0, p.first_valid);
 }
 
 }  // namespace awk

@@ -348,7 +348,7 @@ static aw_status sp_process_fused(aw_spatializer *sp, const float *in, float *ou
     p.tiles_per_stream = (int)((frames + sp->hop - 1) / sp->hop);
     p.dbg = nullptr;
     {
-        const char *e = getenv("AW_STAGGER");      // tuning knob, default from the measured sweep
+        const char *e = getenv("AW_STAMP_THREAD");      // tuning knob, default from the measured sweep
         p.stagger = e ? atoi(e) : 0;
     }
 #if defined(AW_STAMPS) && AW_STAMPS

@@ -36,6 +36,7 @@ struct EmuCtx {
     int wave() const { return tid_ >> 6; }
     awk::cf *lds() const { return sh->lds.data(); }
     awk::cf opaque(awk::cf v) const { return v; }
+    int opaque_i(int v) const { return v; }
     void stamp(int) const {}
     void flush_stamps() const {}
     awk::cf ld(const awk::cf *p) const { return *p; }
@@ -70,27 +71,44 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
         hist = zero_hist.data();
     }
     p.hist = hist;
+    // same interior/boundary split as awk::launch_fused_ols
+    long long lo = (p.hist_len + p.hop - 1) / p.hop;
+    long long hi = (p.frames - kN + p.hist_len) >= 0 ? (p.frames - kN + p.hist_len) / p.hop + 1 : 0;
+    if (hi > p.tiles_per_stream) hi = p.tiles_per_stream;
+    if (hi < lo) hi = lo;
+    if (lo > p.tiles_per_stream) { lo = p.tiles_per_stream; hi = lo; }
+    p.tile_lo = (int)lo; p.tile_hi = (int)hi;
     EmuShared sh;
-    for (int s = 0; s < n_streams; ++s) {
-        for (int tile = 0; tile < p.tiles_per_stream; ++tile) {
-            const long long w0 = (long long)tile * p.hop - p.hist_len;
-            const bool interior = w0 >= 0 && w0 + kN <= p.frames;
+    // emulate a persistent launch with a few workgroups, each walking several tiles
+    auto run = [&](bool interior, long long n_tiles) {
+        const long long G = n_tiles < 3 ? n_tiles : 3;
+        for (long long g = 0; g < G; ++g) {
             std::vector<std::thread> th;
             th.reserve(kThreads);
             for (int t = 0; t < kThreads; ++t)
                 th.emplace_back([&, t]() {
                     EmuCtx ctx{t, &sh};
-                    if (variant == 1 && n_channels == 8 && interior) tile_fused_ols<EmuCtx, 8, 4, true>(ctx, p, s, tile);
-                    else if (variant == 1 && n_channels == 8) tile_fused_ols<EmuCtx, 8, 4, false>(ctx, p, s, tile);
-                    else if (variant == 1 && n_channels == 2) tile_fused_ols<EmuCtx, 2, 1, false>(ctx, p, s, tile);
-                    else if (variant == 1 && n_channels == 7) tile_fused_ols<EmuCtx, 0, 4, false>(ctx, p, s, tile);
-                    else if (variant == 1 && n_channels == 3) tile_fused_ols<EmuCtx, 0, 2, false>(ctx, p, s, tile);
-                    else if (variant == 1 && n_channels == 4) tile_fused_ols<EmuCtx, 4, 2, false>(ctx, p, s, tile);
-                    else tile_fused_ols<EmuCtx, 0, 0, false>(ctx, p, s, tile);
+                    if (interior) {
+                        if (variant == 1 && n_channels == 8) tiles_fused_ols<EmuCtx, 8, 4, true>(ctx, p, g, G, n_tiles);
+                        else if (variant == 1 && n_channels == 2) tiles_fused_ols<EmuCtx, 2, 1, true>(ctx, p, g, G, n_tiles);
+                        else if (variant == 1 && n_channels == 4) tiles_fused_ols<EmuCtx, 4, 2, true>(ctx, p, g, G, n_tiles);
+                        else if (variant == 1 && n_channels == 7) tiles_fused_ols<EmuCtx, 0, 4, true>(ctx, p, g, G, n_tiles);
+                        else if (variant == 1 && n_channels == 3) tiles_fused_ols<EmuCtx, 0, 2, true>(ctx, p, g, G, n_tiles);
+                        else tiles_fused_ols<EmuCtx, 0, 0, true>(ctx, p, g, G, n_tiles);
+                    } else {
+                        if (variant == 1 && n_channels == 8) tiles_fused_ols<EmuCtx, 8, 4, false>(ctx, p, g, G, n_tiles);
+                        else if (variant == 1 && n_channels == 2) tiles_fused_ols<EmuCtx, 2, 1, false>(ctx, p, g, G, n_tiles);
+                        else if (variant == 1 && n_channels == 4) tiles_fused_ols<EmuCtx, 4, 2, false>(ctx, p, g, G, n_tiles);
+                        else if (variant == 1 && n_channels == 7) tiles_fused_ols<EmuCtx, 0, 4, false>(ctx, p, g, G, n_tiles);
+                        else if (variant == 1 && n_channels == 3) tiles_fused_ols<EmuCtx, 0, 2, false>(ctx, p, g, G, n_tiles);
+                        else tiles_fused_ols<EmuCtx, 0, 0, false>(ctx, p, g, G, n_tiles);
+                    }
                 });
             for (auto &x : th) x.join();
         }
-    }
+    };
+    run(true, (long long)n_streams * (hi - lo));
+    run(false, (long long)n_streams * (p.tiles_per_stream - (hi - lo)));
     return 0;
 }
 
