@@ -15,6 +15,9 @@ namespace awk {
 #ifndef AW_LDS_NO_READ2
 #define AW_LDS_NO_READ2 0
 #endif
+#ifndef AW_SCHED_FENCE
+#define AW_SCHED_FENCE 0
+#endif
 #ifndef AW_STAMPS
 #define AW_STAMPS 0
 #endif
@@ -74,6 +77,13 @@ struct GpuCtx {
         return r;
 #else
         return *p;
+#endif
+    }
+    // Scheduling fence (no instruction): keeps hipcc from interleaving the two rows' butterflies,
+    // which doubles their temporaries at the register-pressure peak.
+    __device__ __forceinline__ void sched_fence() const {
+#if AW_SCHED_FENCE
+        __builtin_amdgcn_sched_barrier(0);
 #endif
     }
     // Hides a value's provenance from the optimiser (no instruction emitted): stops LICM/CSE from

@@ -85,7 +85,7 @@ struct TileParams {
     int stagger;            // tuning: waves 4-7 idle this many 64-cycle slots after each barrier (phase offset)
     unsigned long long *dbg; // diagnostic builds only (AW_STAMPS): [workgroup][16] s_memtime stamps of wave 0
 };
-constexpr int kStamps = 16;
+constexpr int kStamps = 32;
 
 // ---- per-wave ownership of rows -------------------------------------------------------------
 AW_HD int wave_row(int wave, int slot) {
@@ -118,15 +118,20 @@ AW_HD void tw_powers(cf w, cf (&pw)[16]) {
 // a[s][kc] = X_s[lane + 64 kc].  scr0/scr1: the rows' private 576-element scratch.
 template <bool INV, class Ctx>
 AW_HD void sub_fft512x2(Ctx &ctx, cf (&a)[2][8], cf *scr0, cf *scr1, const cf *twa, const cf *twb, int lane) {
+    constexpr int SB = INV ? 24 : 16;
+    ctx.stamp(SB + 0);
     // pass A: radix-8 over j -> ka, twiddle W_512^{lane ka}
     fft8<INV>(a[0]);
+    ctx.sched_fence();
     fft8<INV>(a[1]);
+    ctx.sched_fence();
 #pragma unroll
     for (int ka = 1; ka < 8; ++ka) {
         const cf w = ctx.ld(twa + ka * 64 + lane);
         a[0][ka] = twmul<INV>(a[0][ka], w);
         a[1][ka] = twmul<INV>(a[1][ka], w);
     }
+    ctx.stamp(SB + 1);
     // exchange A: write [ka][lane] (row stride 72), read [ka'][l0' + 8 l1] with lane = l0' + 8 ka'
 #pragma unroll
     for (int ka = 0; ka < 8; ++ka) { scr0[ka * 72 + lane] = a[0][ka]; scr1[ka * 72 + lane] = a[1][ka]; }
@@ -135,15 +140,19 @@ AW_HD void sub_fft512x2(Ctx &ctx, cf (&a)[2][8], cf *scr0, cf *scr1, const cf *t
 #pragma unroll
     for (int l1 = 0; l1 < 8; ++l1) { a[0][l1] = ctx.ld(scr0 + kap * 72 + l0 + 8 * l1); a[1][l1] = ctx.ld(scr1 + kap * 72 + l0 + 8 * l1); }
     ctx.wave_sync();
+    ctx.stamp(SB + 2);
     // pass B: radix-8 over l1 -> kb, twiddle W_64^{l0 kb}
     fft8<INV>(a[0]);
+    ctx.sched_fence();
     fft8<INV>(a[1]);
+    ctx.sched_fence();
 #pragma unroll
     for (int kb = 1; kb < 8; ++kb) {
         const cf w = ctx.ld(twb + kb * 8 + l0);
         a[0][kb] = twmul<INV>(a[0][kb], w);
         a[1][kb] = twmul<INV>(a[1][kb], w);
     }
+    ctx.stamp(SB + 3);
     // exchange B: chunk (kb, ka') of 8 (+1 pad) elements indexed by l0; read by lane = ka'' + 8 kb''
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) { scr0[(kb * 8 + kap) * 9 + l0] = a[0][kb]; scr1[(kb * 8 + kap) * 9 + l0] = a[1][kb]; }
@@ -151,9 +160,13 @@ AW_HD void sub_fft512x2(Ctx &ctx, cf (&a)[2][8], cf *scr0, cf *scr1, const cf *t
 #pragma unroll
     for (int i = 0; i < 8; ++i) { a[0][i] = ctx.ld(scr0 + lane * 9 + i); a[1][i] = ctx.ld(scr1 + lane * 9 + i); }   // chunk kb''*8 + ka'' == lane
     ctx.wave_sync();
+    ctx.stamp(SB + 4);
     // pass C: radix-8 over l0 -> kc.  Now a[s][kc] = X_s[ka'' + 8 kb'' + 64 kc] = X_s[lane + 64 kc]
     fft8<INV>(a[0]);
+    ctx.sched_fence();
     fft8<INV>(a[1]);
+    ctx.sched_fence();
+    ctx.stamp(SB + 5);
 }
 
 // ---- the tile ----------------------------------------------------------------------------------
@@ -256,6 +269,7 @@ AW_HD void pair_subfft_cmac(Ctx &ctx, const TileParams &p, int pair, cf *buf, co
     ctx.wave_sync();
     sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
     if (!tab_loaded) load_tab(p, pair, wave, lane, tab);
+    ctx.stamp(22);
     // publish Z rows inside the wave, then CMAC against the partner bins
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc) { row0[lane + 64 * kc] = z[0][kc]; row1[lane + 64 * kc] = z[1][kc]; }
@@ -276,6 +290,7 @@ AW_HD void pair_subfft_cmac(Ctx &ctx, const TileParams &p, int pair, cf *buf, co
         }
     }
     ctx.wave_sync();    // partner reads done before this wave reuses its rows as scratch
+    ctx.stamp(23);
 }
 
 // Inverse half of a tile, part 1: per-wave 512-point inverse sub-FFTs of W (scratch = the wave's

@@ -38,6 +38,7 @@ struct EmuCtx {
     awk::cf opaque(awk::cf v) const { return v; }
     int opaque_i(int v) const { return v; }
     void stamp(int) const {}
+    void sched_fence() const {}
     void flush_stamps() const {}
     awk::cf ld(const awk::cf *p) const { return *p; }
     void stagger(int, int) const {}

@@ -22,7 +22,7 @@ for _ in range(3):
     sp.process_device(x.data_ptr(), y.data_ptr(), F)
 torch.cuda.synchronize()
 nwg = S * ((F + sp.info()["hop"] - 1) // sp.info()["hop"])   # buffer is sized for all tiles; interior ones are filled
-buf = np.zeros((nwg, 16), dtype=np.uint64)
+buf = np.zeros((nwg, 32), dtype=np.uint64)
 n = ctypes.c_int64()
 st = _capi.load().aw_spatializer_debug_stamps(sp._h, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), buf.size, ctypes.byref(n))
 assert st == 0, _capi.load().aw_last_error_message()
@@ -38,3 +38,13 @@ for i, nm in enumerate(names):
     print(f"  {i:2d} {nm:34s} median {np.median(d[:, i]):8.0f}  mean {d[:, i].mean():8.0f}  share {d[:, i].mean()/tot.mean()*100:5.1f}%")
 # gap between consecutive workgroups on one CU cannot be seen here; compare sum with kernel time
 print("sum of tile cycles / 256 CUs:", tot.sum() / 256)
+
+inner = ["fwd: z read (before stamp16 not shown)", "fwd passA fft8x2+tw", "fwd exchA write/sync/read", "fwd passB", "fwd exchB", "fwd passC",
+         "", "tab load + publish (to 22..)", "", "inv passA", "inv exchA", "inv passB", "inv exchB", "inv passC"]
+def seg(a, b, name):
+    d2 = t[:, b] - t[:, a]
+    print(f"  [{a:2d}->{b:2d}] {name:40s} median {np.median(d2):8.0f}")
+print("last forward pair (p3) and inverse, detail:")
+seg(16, 17, "fwd pass A (2x fft8 + twiddles)"); seg(17, 18, "fwd exchange A"); seg(18, 19, "fwd pass B"); seg(19, 20, "fwd exchange B")
+seg(20, 21, "fwd pass C"); seg(21, 22, "table loads issue (+wait?)"); seg(22, 23, "publish + partner read + CMAC")
+seg(24, 25, "inv pass A"); seg(25, 26, "inv exchange A"); seg(26, 27, "inv pass B"); seg(27, 28, "inv exchange B"); seg(28, 29, "inv pass C")

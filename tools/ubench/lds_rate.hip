@@ -39,6 +39,14 @@ __global__ void __launch_bounds__(512) k_lds(float *out, int iters) {
         } else if (OP == 8) { // 16 x ds_bpermute_b32
             asm volatile(REP8("ds_bpermute_b32 v20, %0, v22\n ds_bpermute_b32 v21, %0, v23\n") "s_waitcnt lgkmcnt(0)\n" ::"v"(a4)
                          : "v20", "v21", "v22", "v23", "memory");
+        } else if (OP == 10) { // 16 x ds_read_b64 with EXEC = 0
+            asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b64 exec, 0\n"
+                         REP8("ds_read_b64 v[20:21], %0 offset:0\n ds_read_b64 v[22:23], %0 offset:4096\n")
+                         "s_waitcnt lgkmcnt(0)\n s_mov_b64 exec, s[20:21]\n" ::"v"(a8) : "v20", "v21", "v22", "v23", "s20", "s21", "memory");
+        } else if (OP == 11) { // 16 x ds_write_b64 with EXEC = 0
+            asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b64 exec, 0\n"
+                         REP8("ds_write_b64 %0, v[20:21] offset:0\n ds_write_b64 %0, v[22:23] offset:4096\n")
+                         "s_waitcnt lgkmcnt(0)\n s_mov_b64 exec, s[20:21]\n" ::"v"(a8) : "v20", "v21", "v22", "v23", "s20", "s21", "memory");
         } else if (OP == 9) { // 8 x ds_read2st64_b64
             asm volatile(REP8("ds_read2st64_b64 v[20:23], %0 offset0:0 offset1:8\n") "s_waitcnt lgkmcnt(0)\n" ::"v"(a8)
                          : "v20", "v21", "v22", "v23", "memory");
@@ -76,5 +84,7 @@ int main() {
     run<6>("16x ds_read_b32", 64, 16, out);
     run<7>("16x ds_write_b32", 64, 16, out);
     run<8>("16x ds_bpermute_b32", 64, 16, out);
+    run<10>("16x ds_read_b64 EXEC=0", 128, 16, out);
+    run<11>("16x ds_write_b64 EXEC=0", 128, 16, out);
     return 0;
 }
