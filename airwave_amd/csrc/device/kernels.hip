@@ -134,6 +134,8 @@ __global__ void __launch_bounds__(kThreads) aw_fused_ols_kernel(TileParams p, lo
     tiles_fused_ols<GpuCtx, CS, NP, INTERIOR>(ctx, p, lo + slot, per_xcd_wg, hi);
 }
 
+static int g_persistent_wgs = 256;      // one resident workgroup per CU (152 KB LDS each)
+
 template <int CS>
 __global__ void __launch_bounds__(kThreads) aw_part_forward_kernel(TileParams p, long long nwg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -150,10 +152,13 @@ __global__ void __launch_bounds__(kThreads) aw_part_cmac_ifft_kernel(TileParams 
     tile_part_cmac_inverse<GpuCtx>(ctx, p, id / p.n_blocks, (int)(id % p.n_blocks));
 }
 
-static int g_persistent_wgs = 256;      // one resident workgroup per CU (152 KB LDS each)
-
-// Variants: <CS, NP> = <vector-load channel count or 0, compile-time pair count or 0 (generic)>
-#define AW_FOR_EACH_VARIANT(X) X(8, 4) X(2, 1) X(4, 2) X(0, 4) X(0, 2) X(0, 0)
+// Kernel variants.  Vectorised interior kernels <CS, NP, true> exist for the channel counts whose
+// frames are whole float4s/float2s (2, 4, 8, 12, 16 channels: stereo ... 7.1.4 + 4); every other
+// case — the few boundary tiles of those, and all tiles of the other channel counts — runs the
+// generic-addressing kernels <0, NP, false> (NP = compile-time pair count 1..4; NP = 0 loops over
+// batches of two pairs at run time: more than 8 channels, where full unrolling only spills).
+#define AW_FOR_EACH_VEC(X) X(2, 1) X(4, 2) X(8, 4) X(12, 0) X(16, 0)
+#define AW_FOR_EACH_GEN(X) X(1) X(2) X(3) X(4) X(0)
 
 hipError_t prepare_kernels() {
     hipError_t e = hipSuccess;
@@ -164,15 +169,18 @@ hipError_t prepare_kernels() {
             g_persistent_wgs = cus;
         if (const char *e2 = getenv("AW_PERSISTENT_WGS")) g_persistent_wgs = atoi(e2) > 0 ? atoi(e2) : g_persistent_wgs;
     }
-#define AW_SET_ATTR(CS, NP)                                                                          \
+#define AW_SET_VEC(CS, NP)                                                                           \
     if (e == hipSuccess)                                                                             \
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<CS, NP, true>),  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);              \
-    if (e == hipSuccess)                                                                             \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<CS, NP, false>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    AW_FOR_EACH_VARIANT(AW_SET_ATTR)
-#undef AW_SET_ATTR
+#define AW_SET_GEN(NP)                                                                               \
+    if (e == hipSuccess)                                                                             \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<0, NP, false>),  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    AW_FOR_EACH_VEC(AW_SET_VEC)
+    AW_FOR_EACH_GEN(AW_SET_GEN)
+#undef AW_SET_VEC
+#undef AW_SET_GEN
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_forward_kernel<8>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
@@ -185,36 +193,45 @@ hipError_t prepare_kernels() {
     return e;
 }
 
-static int pick_variant(int C) {       // index into the variant list above
-    if (C == 8) return 0;
-    if (C == 2) return 1;
-    if (C == 4) return 2;
-    if (C == 7) return 3;
-    if (C == 3) return 4;
-    return 5;
-}
+static bool has_vec_variant(int C) { return C == 2 || C == 4 || C == 8 || C == 12 || C == 16; }
 
-const char *fused_ols_kernel_name(int n_channels) {
-    static const char *names[] = {"aw_fused_ols_kernel<8, 4, true>", "aw_fused_ols_kernel<2, 1, true>",
-                                  "aw_fused_ols_kernel<4, 2, true>", "aw_fused_ols_kernel<0, 4, true>",
-                                  "aw_fused_ols_kernel<0, 2, true>", "aw_fused_ols_kernel<0, 0, true>"};
-    return names[pick_variant(n_channels)];
-}
-
-template <bool INTERIOR>
-static void launch_variant(const TileParams &p, long long nwg, hipStream_t stream) {
-    const dim3 grid((unsigned)(nwg < g_persistent_wgs ? nwg : g_persistent_wgs)), block(kThreads);
-    switch (pick_variant(p.n_channels)) {
-        case 0: hipLaunchKernelGGL((aw_fused_ols_kernel<8, 4, INTERIOR>), grid, block, kLdsBytes, stream, p, nwg); break;
-        case 1: hipLaunchKernelGGL((aw_fused_ols_kernel<2, 1, INTERIOR>), grid, block, kLdsBytes, stream, p, nwg); break;
-        case 2: hipLaunchKernelGGL((aw_fused_ols_kernel<4, 2, INTERIOR>), grid, block, kLdsBytes, stream, p, nwg); break;
-        case 3: hipLaunchKernelGGL((aw_fused_ols_kernel<0, 4, INTERIOR>), grid, block, kLdsBytes, stream, p, nwg); break;
-        case 4: hipLaunchKernelGGL((aw_fused_ols_kernel<0, 2, INTERIOR>), grid, block, kLdsBytes, stream, p, nwg); break;
-        default: hipLaunchKernelGGL((aw_fused_ols_kernel<0, 0, INTERIOR>), grid, block, kLdsBytes, stream, p, nwg); break;
+const char *fused_ols_kernel_name(int C) {
+    switch (C) {
+        case 2: return "aw_fused_ols_kernel<2, 1, true>";
+        case 4: return "aw_fused_ols_kernel<4, 2, true>";
+        case 8: return "aw_fused_ols_kernel<8, 4, true>";
+        case 12: return "aw_fused_ols_kernel<12, 0, true>";
+        case 16: return "aw_fused_ols_kernel<16, 0, true>";
+        default: return "aw_fused_ols_kernel<0, NP, false>";
     }
 }
 
-// Two launches: the interior tiles (fast uniform addressing) and the few boundary tiles per stream.
+static dim3 persistent_grid(long long n_tiles) {
+    return dim3((unsigned)(n_tiles < g_persistent_wgs ? n_tiles : g_persistent_wgs));
+}
+
+static void launch_vec(const TileParams &p, long long n_tiles, hipStream_t stream) {
+    const dim3 grid = persistent_grid(n_tiles), block(kThreads);
+    switch (p.n_channels) {
+#define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_fused_ols_kernel<CS, NP, true>), grid, block, kLdsBytes, stream, p, n_tiles); break;
+        AW_FOR_EACH_VEC(AW_CASE)
+#undef AW_CASE
+        default: break;
+    }
+}
+
+static void launch_gen(const TileParams &p, long long n_tiles, hipStream_t stream) {
+    const dim3 grid = persistent_grid(n_tiles), block(kThreads);
+    const int np = p.n_pairs <= 4 ? p.n_pairs : 0;
+    switch (np) {
+#define AW_CASE(NP) case NP: hipLaunchKernelGGL((aw_fused_ols_kernel<0, NP, false>), grid, block, kLdsBytes, stream, p, n_tiles); break;
+        AW_FOR_EACH_GEN(AW_CASE)
+#undef AW_CASE
+        default: break;
+    }
+}
+
+// Interior tiles (window entirely inside the call's input) and boundary tiles are separate launches.
 hipError_t launch_fused_ols(const TileParams &p_in, int n_streams, hipStream_t stream) {
     TileParams p = p_in;
     // tile i is interior iff  i*hop - hist_len >= 0  and  i*hop - hist_len + N <= frames
@@ -223,15 +240,16 @@ hipError_t launch_fused_ols(const TileParams &p_in, int n_streams, hipStream_t s
     if (hi > p.tiles_per_stream) hi = p.tiles_per_stream;
     if (hi < lo) hi = lo;
     if (lo > p.tiles_per_stream) { lo = p.tiles_per_stream; hi = lo; }
+    if (!has_vec_variant(p.n_channels)) { lo = 0; hi = 0; }        // everything through the generic kernels
     p.tile_lo = (int)lo; p.tile_hi = (int)hi;
     const long long n_int = (long long)n_streams * (hi - lo);
     const long long n_bnd = (long long)n_streams * (p.tiles_per_stream - (hi - lo));
     if (n_int > 0x7fffffffLL || n_bnd > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (n_int > 0) launch_variant<true>(p, n_int, stream);
+    if (n_int > 0) launch_vec(p, n_int, stream);
     if (n_bnd > 0) {
         TileParams pb = p;
         pb.dbg = nullptr;                 // diagnostic stamps describe the interior launch only
-        launch_variant<false>(pb, n_bnd, stream);
+        launch_gen(pb, n_bnd, stream);
     }
     return hipGetLastError();
 }

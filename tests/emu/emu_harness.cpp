@@ -78,6 +78,8 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
     if (hi > p.tiles_per_stream) hi = p.tiles_per_stream;
     if (hi < lo) hi = lo;
     if (lo > p.tiles_per_stream) { lo = p.tiles_per_stream; hi = lo; }
+    const bool vec = n_channels == 2 || n_channels == 4 || n_channels == 8 || n_channels == 12 || n_channels == 16;
+    if (!vec || variant != 1) { lo = 0; hi = 0; }
     p.tile_lo = (int)lo; p.tile_hi = (int)hi;
     EmuShared sh;
     // emulate a persistent launch with a few workgroups, each walking several tiles
@@ -89,20 +91,23 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
             for (int t = 0; t < kThreads; ++t)
                 th.emplace_back([&, t]() {
                     EmuCtx ctx{t, &sh};
+                    // mirror of awk::launch_fused_ols' variant choice
                     if (interior) {
-                        if (variant == 1 && n_channels == 8) tiles_fused_ols<EmuCtx, 8, 4, true>(ctx, p, g, G, n_tiles);
-                        else if (variant == 1 && n_channels == 2) tiles_fused_ols<EmuCtx, 2, 1, true>(ctx, p, g, G, n_tiles);
-                        else if (variant == 1 && n_channels == 4) tiles_fused_ols<EmuCtx, 4, 2, true>(ctx, p, g, G, n_tiles);
-                        else if (variant == 1 && n_channels == 7) tiles_fused_ols<EmuCtx, 0, 4, true>(ctx, p, g, G, n_tiles);
-                        else if (variant == 1 && n_channels == 3) tiles_fused_ols<EmuCtx, 0, 2, true>(ctx, p, g, G, n_tiles);
-                        else tiles_fused_ols<EmuCtx, 0, 0, true>(ctx, p, g, G, n_tiles);
+                        switch (n_channels) {
+                            case 2: tiles_fused_ols<EmuCtx, 2, 1, true>(ctx, p, g, G, n_tiles); break;
+                            case 4: tiles_fused_ols<EmuCtx, 4, 2, true>(ctx, p, g, G, n_tiles); break;
+                            case 8: tiles_fused_ols<EmuCtx, 8, 4, true>(ctx, p, g, G, n_tiles); break;
+                            case 12: tiles_fused_ols<EmuCtx, 12, 0, true>(ctx, p, g, G, n_tiles); break;
+                            default: tiles_fused_ols<EmuCtx, 16, 0, true>(ctx, p, g, G, n_tiles); break;
+                        }
                     } else {
-                        if (variant == 1 && n_channels == 8) tiles_fused_ols<EmuCtx, 8, 4, false>(ctx, p, g, G, n_tiles);
-                        else if (variant == 1 && n_channels == 2) tiles_fused_ols<EmuCtx, 2, 1, false>(ctx, p, g, G, n_tiles);
-                        else if (variant == 1 && n_channels == 4) tiles_fused_ols<EmuCtx, 4, 2, false>(ctx, p, g, G, n_tiles);
-                        else if (variant == 1 && n_channels == 7) tiles_fused_ols<EmuCtx, 0, 4, false>(ctx, p, g, G, n_tiles);
-                        else if (variant == 1 && n_channels == 3) tiles_fused_ols<EmuCtx, 0, 2, false>(ctx, p, g, G, n_tiles);
-                        else tiles_fused_ols<EmuCtx, 0, 0, false>(ctx, p, g, G, n_tiles);
+                        switch (p.n_pairs <= 4 && variant == 1 ? p.n_pairs : 0) {
+                            case 1: tiles_fused_ols<EmuCtx, 0, 1, false>(ctx, p, g, G, n_tiles); break;
+                            case 2: tiles_fused_ols<EmuCtx, 0, 2, false>(ctx, p, g, G, n_tiles); break;
+                            case 3: tiles_fused_ols<EmuCtx, 0, 3, false>(ctx, p, g, G, n_tiles); break;
+                            case 4: tiles_fused_ols<EmuCtx, 0, 4, false>(ctx, p, g, G, n_tiles); break;
+                            default: tiles_fused_ols<EmuCtx, 0, 0, false>(ctx, p, g, G, n_tiles); break;
+                        }
                     }
                 });
             for (auto &x : th) x.join();
