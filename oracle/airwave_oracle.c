@@ -587,3 +587,86 @@ void orc_synth_fill(float *dst, int n_streams, int64_t frames, int n_channels, u
     for (int s = 0; s < n_streams; ++s)
         for (uint64_t i = 0; i < per; ++i) dst[(uint64_t)s * per + i] = orc_synth_value(seed, (uint64_t)s, i);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Parametric EQ
+ * ---------------------------------------------------------------------------------------- */
+int orc_biquad_make(int type, double gain_db, double f, double q, double fs, orc_biquad *out) {
+    if (!isfinite(fs) || !(fs > 0)) return 1;                                     /* :36-38 */
+    if (!isfinite(gain_db) || !isfinite(f) || !isfinite(q)) return 4;             /* :39-41 */
+    if (!(f > 0) || !(f < fs / 2)) return 2;                                      /* :42-44 */
+    if (!(q > 0)) return 3;                                                       /* :45-47 */
+    const double A = pow(10.0, gain_db / 40.0);                                   /* :49 */
+    const double omega = 2.0 * M_PI * f / fs;
+    const double sn = sin(omega), cs = cos(omega);
+    const double alpha = sn / (2.0 * q);
+    const double beta = 2.0 * sqrt(A) * alpha;
+    double b0, b1, b2, a0, a1, a2;
+    if (type == 0) {                                                              /* peaking :57-65 */
+        b0 = 1 + alpha * A; b1 = -2 * cs; b2 = 1 - alpha * A;
+        a0 = 1 + alpha / A; a1 = -2 * cs; a2 = 1 - alpha / A;
+    } else if (type == 1) {                                                       /* lowShelf :66-74 */
+        b0 = A * ((A + 1) - (A - 1) * cs + beta);
+        b1 = 2 * A * ((A - 1) - (A + 1) * cs);
+        b2 = A * ((A + 1) - (A - 1) * cs - beta);
+        a0 = (A + 1) + (A - 1) * cs + beta;
+        a1 = -2 * ((A - 1) + (A + 1) * cs);
+        a2 = (A + 1) + (A - 1) * cs - beta;
+    } else {                                                                      /* highShelf :75-83 */
+        b0 = A * ((A + 1) + (A - 1) * cs + beta);
+        b1 = -2 * A * ((A - 1) + (A + 1) * cs);
+        b2 = A * ((A + 1) + (A - 1) * cs - beta);
+        a0 = (A + 1) - (A - 1) * cs + beta;
+        a1 = 2 * ((A - 1) - (A + 1) * cs);
+        a2 = (A + 1) - (A - 1) * cs - beta;
+    }
+    if (!isfinite(a0) || a0 == 0) return 5;                                       /* :86-88 */
+    out->b0 = b0 / a0; out->b1 = b1 / a0; out->b2 = b2 / a0; out->a1 = a1 / a0; out->a2 = a2 / a0;
+    if (!isfinite(out->b0) || !isfinite(out->b1) || !isfinite(out->b2) || !isfinite(out->a1) || !isfinite(out->a2))
+        return 5;                                                                 /* :97-104 */
+    return 0;
+}
+
+struct orc_eq_state {
+    double sample_rate, preamp_linear;
+    int count;
+    orc_biquad c[64];
+    double lz1[64], lz2[64], rz1[64], rz2[64];
+};
+
+orc_eq_state *orc_eq_state_create(double fs, double preamp_db, const orc_biquad *c, int count) {
+    if (count < 0 || count > 64) return NULL;                                     /* maximumFilterCount :17 */
+    orc_eq_state *s = (orc_eq_state *)calloc(1, sizeof(*s));
+    if (!s) return NULL;
+    s->sample_rate = fs; s->count = count;
+    s->preamp_linear = pow(10.0, preamp_db / 20.0);                               /* :33 */
+    for (int i = 0; i < count; ++i) s->c[i] = c[i];
+    return s;
+}
+void orc_eq_state_destroy(orc_eq_state *s) { free(s); }
+void orc_eq_state_reset(orc_eq_state *s) {                                        /* :49-56 */
+    for (int i = 0; i < s->count; ++i) s->lz1[i] = s->lz2[i] = s->rz1[i] = s->rz2[i] = 0.0;
+}
+static inline double flush_subnormal(double v) { return fabs(v) < 1e-30 ? 0.0 : v; }   /* :95-97 */
+
+void orc_eq_state_process(orc_eq_state *s, const float *in_l, const float *in_r, float *out_l, float *out_r, int n) {
+    for (int f = 0; f < n; ++f) {                                                 /* :66-90 */
+        double left = (double)in_l[f] * s->preamp_linear;
+        double right = (double)(in_r ? in_r[f] : in_l[f]) * s->preamp_linear;
+        for (int k = 0; k < s->count; ++k) {
+            const orc_biquad c = s->c[k];
+            const double lo = c.b0 * left + s->lz1[k];
+            const double lz1 = c.b1 * left - c.a1 * lo + s->lz2[k];
+            const double lz2 = c.b2 * left - c.a2 * lo;
+            s->lz1[k] = flush_subnormal(lz1); s->lz2[k] = flush_subnormal(lz2);
+            left = lo;
+            const double ro = c.b0 * right + s->rz1[k];
+            const double rz1 = c.b1 * right - c.a1 * ro + s->rz2[k];
+            const double rz2 = c.b2 * right - c.a2 * ro;
+            s->rz1[k] = flush_subnormal(rz1); s->rz2[k] = flush_subnormal(rz2);
+            right = ro;
+        }
+        out_l[f] = (float)left;
+        out_r[f] = (float)right;
+    }
+}

@@ -98,3 +98,30 @@ void orc_synth_fill(float *dst, int n_streams, int64_t frames, int n_channels, u
 }
 #endif
 #endif
+
+/* ==== Parametric EQ ("next" row) ==========================================
+ * BiquadCoefficientBuilder.make (Airwave/BiquadCoefficientBuilder.swift:29-107), type: 0 peaking,
+ * 1 lowShelf, 2 highShelf.  Returns 0 or the BiquadCoefficientError ordinal + 1
+ * (1 invalidSampleRate, 2 invalidFrequency, 3 invalidQ, 4 nonFiniteInput, 5 nonFiniteCoefficients). */
+#ifndef AIRWAVE_ORACLE_EQ_H
+#define AIRWAVE_ORACLE_EQ_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct { double b0, b1, b2, a1, a2; } orc_biquad;
+int orc_biquad_make(int type, double gain_db, double frequency_hz, double q, double sample_rate, orc_biquad *out);
+
+/* ParametricEqualizerState (Airwave/ParametricEqualizerProcessor.swift:16-98): cascaded
+ * transposed-DF2 biquads, Float64 state and arithmetic, preamp 10^(dB/20), |z| < 1e-30 flushed. */
+typedef struct orc_eq_state orc_eq_state;
+orc_eq_state *orc_eq_state_create(double sample_rate, double preamp_db, const orc_biquad *coefficients, int count);
+void orc_eq_state_destroy(orc_eq_state *s);
+void orc_eq_state_reset(orc_eq_state *s);
+/* process(inputLeft:inputRight:leftOutput:rightOutput:frameCount:)  :58-91; input_right may be NULL;
+ * in-place (output == input) is allowed, as the reference's canary test does. */
+void orc_eq_state_process(orc_eq_state *s, const float *input_left, const float *input_right, float *left_output,
+                          float *right_output, int frame_count);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -480,3 +480,320 @@ def assemble_tracks(wav: WAVData, speakers: Sequence[str], target_rate: Optional
     if target_rate is not None and abs(wav.sample_rate - target_rate) > 0.01:
         tracks = np.stack([resample_intended(t, wav.sample_rate, target_rate) for t in wav.audio_data])
     return np.ascontiguousarray(tracks, dtype=np.float32), left, right
+
+
+# ================================================================================================
+# Parametric EQ ("next" row) — restatement of BiquadCoefficientBuilder.swift,
+# EqualizerAPOParser.swift, ParametricEqualizerProcessor.swift.  Pinned by the reference's own golden
+# numbers (tests/test_oracle_eq_kats.py re-expresses ParametricEqualizerProcessorTests.swift and
+# EqualizerAPOParserTests.swift).
+# ================================================================================================
+import re as _re
+
+PEAKING, LOW_SHELF, HIGH_SHELF = 0, 1, 2
+_BIQUAD_ERRORS = {1: "invalidSampleRate", 2: "invalidFrequency", 3: "invalidQ", 4: "nonFiniteInput", 5: "nonFiniteCoefficients"}
+
+
+class _Biquad(ctypes.Structure):
+    _fields_ = [("b0", ctypes.c_double), ("b1", ctypes.c_double), ("b2", ctypes.c_double), ("a1", ctypes.c_double), ("a2", ctypes.c_double)]
+
+
+def _eq_lib():
+    L = lib()
+    if not hasattr(L, "_eq_typed"):
+        L.orc_biquad_make.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.POINTER(_Biquad)]
+        L.orc_eq_state_create.restype = ctypes.c_void_p
+        L.orc_eq_state_create.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.POINTER(_Biquad), ctypes.c_int]
+        L.orc_eq_state_destroy.argtypes = [ctypes.c_void_p]
+        L.orc_eq_state_reset.argtypes = [ctypes.c_void_p]
+        L.orc_eq_state_process.argtypes = [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int]
+        L._eq_typed = True
+    return L
+
+
+class BiquadCoefficientError(ValueError):
+    def __init__(self, kind):
+        super().__init__(kind)
+        self.kind = kind
+
+
+def biquad_make(ftype: int, gain_db: float, frequency_hz: float, q: float, sample_rate: float):
+    """BiquadCoefficientBuilder.make  BiquadCoefficientBuilder.swift:29-107 -> (b0, b1, b2, a1, a2)"""
+    out = _Biquad()
+    rc = _eq_lib().orc_biquad_make(ftype, gain_db, frequency_hz, q, sample_rate, ctypes.byref(out))
+    if rc != 0:
+        raise BiquadCoefficientError(_BIQUAD_ERRORS[rc])
+    return (out.b0, out.b1, out.b2, out.a1, out.a2)
+
+
+@dataclass
+class EqualizerFilter:            # EqualizerPreset.swift:9-17
+    source_line: int
+    source_number: Optional[int]
+    is_enabled: bool
+    type: int
+    frequency_hz: float
+    gain_db: float
+    q: float
+
+
+@dataclass
+class EqualizerDefinition:        # EqualizerPreset.swift:19-27
+    preamp_db: float = 0.0
+    filters: List[EqualizerFilter] = field(default_factory=list)
+
+
+class EqualizerParseError(ValueError):
+    def __init__(self, filename, issues):
+        self.filename, self.issues = filename, issues     # issues: [(line or None, reason)]
+        det = "; ".join((f"line {l}: {r}" if l is not None else r) for l, r in issues)
+        super().__init__(f"Could not read {filename}: {det}")
+
+
+_PREAMP_RE = _re.compile(r"^Preamp\s*:\s*(\S+)\s+dB$", _re.IGNORECASE)
+_FILTER_RE = _re.compile(r"^Filter(?:\s+([0-9]+))?\s*:\s+(ON|OFF)\s+(PK|LSC|HSC)\s+Fc\s+(\S+)\s+Hz\s+Gain\s+(\S+)\s+dB\s+Q\s+(\S+)$", _re.IGNORECASE)
+
+
+def _finite_double(text: str) -> Optional[float]:
+    """Swift Double(String): decimal / exponent / hex forms, 'inf'/'nan' spellings parse but are rejected as
+    non-finite; no surrounding whitespace, no underscores."""
+    if not _re.fullmatch(r"[+-]?((\d+\.?\d*([eE][+-]?\d+)?)|(\.\d+([eE][+-]?\d+)?)|(0[xX][0-9a-fA-F]+\.?[0-9a-fA-F]*([pP][+-]?\d+)?)|inf|infinity|nan)", text, _re.IGNORECASE):
+        return None
+    try:
+        v = float.fromhex(text) if _re.match(r"[+-]?0[xX]", text) else float(text)
+    except ValueError:
+        return None
+    return v if np.isfinite(v) else None
+
+
+def eq_parse(data: bytes, filename: str = "preset.txt") -> EqualizerDefinition:
+    """EqualizerAPOParser.parse  EqualizerAPOParser.swift:36-151"""
+    if len(data) > 1_048_576:
+        raise EqualizerParseError(filename, [(None, "file exceeds the 1 MiB limit")])
+    try:
+        source = data.decode("utf-8")
+    except UnicodeDecodeError:
+        raise EqualizerParseError(filename, [(None, "file is not valid UTF-8")])
+    if source[:1] == "﻿":
+        source = source[1:]
+    preamp, has_preamp, decl = 0.0, False, 0
+    filters: List[EqualizerFilter] = []
+    issues = []
+    for index, raw in enumerate(_re.split(r"\r\n|\n|\r|\x0b|\x0c|\x85| | ", source)):
+        n = index + 1
+        line = raw.strip()
+        if not line or line.startswith("#"):
+            continue
+        m = _PREAMP_RE.fullmatch(line)
+        if m:
+            if has_preamp:
+                issues.append((n, "duplicate Preamp directive")); continue
+            v = _finite_double(m.group(1))
+            if v is None:
+                issues.append((n, "Preamp must be a finite number")); continue
+            preamp, has_preamp = v, True
+            continue
+        if line.lower().startswith("filter"):
+            decl += 1
+            if decl > 64:
+                issues.append((n, "more than 64 filter declarations are not allowed")); continue
+            m = _FILTER_RE.fullmatch(line)
+            if not m:
+                issues.append((n, "malformed Filter directive")); continue
+            number = int(m.group(1)) if m.group(1) else None
+            enabled = m.group(2).upper() == "ON"
+            ftype = {"PK": PEAKING, "LSC": LOW_SHELF, "HSC": HIGH_SHELF}[m.group(3).upper()]
+            f, g, q = _finite_double(m.group(4)), _finite_double(m.group(5)), _finite_double(m.group(6))
+            num = []
+            if f is not None:
+                if f <= 0: num.append("frequency must be positive")
+            else:
+                num.append("frequency must be a finite number")
+            if g is None: num.append("gain must be a finite number")
+            if q is not None:
+                if q <= 0: num.append("Q must be positive")
+            else:
+                num.append("Q must be a finite number")
+            if num:
+                issues.extend((n, r) for r in num); continue
+            filters.append(EqualizerFilter(n, number, enabled, ftype, f, g, q))
+            continue
+        issues.append((n, "malformed Preamp directive" if line.lower().startswith("preamp") else "unsupported directive"))
+    if not issues and preamp == 0 and not any(f.is_enabled for f in filters):
+        issues.append((None, "effective configuration must contain a non-zero preamp or an enabled supported filter"))
+    if issues:
+        raise EqualizerParseError(filename, issues)
+    return EqualizerDefinition(preamp, filters)
+
+
+class EqualizerPreparationError(ValueError):
+    def __init__(self, kind, detail=""):
+        super().__init__(f"{kind} {detail}".strip())
+        self.kind = kind
+
+
+class ParametricEqualizerState:
+    """ParametricEqualizerState  ParametricEqualizerProcessor.swift:16-98 (C-backed)."""
+
+    def __init__(self, sample_rate: float, preamp_db: float, coefficients):
+        arr = (_Biquad * max(len(coefficients), 1))(*[_Biquad(*c) for c in coefficients])
+        self._h = _eq_lib().orc_eq_state_create(sample_rate, preamp_db, arr, len(coefficients))
+        self.sample_rate, self.filter_count = sample_rate, len(coefficients)
+        self.preamp_linear = 10.0 ** (preamp_db / 20.0)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _eq_lib().orc_eq_state_destroy(self._h)
+            self._h = None
+
+    def reset(self):
+        _eq_lib().orc_eq_state_reset(self._h)
+
+    def process(self, left, right=None):
+        l = _f32(left)
+        r = None if right is None else _f32(right)
+        ol = np.full(l.size, np.nan, np.float32)
+        orr = np.full(l.size, np.nan, np.float32)
+        _eq_lib().orc_eq_state_process(self._h, _fp(l), None if r is None else _fp(r), _fp(ol), _fp(orr), l.size)
+        return ol, orr
+
+
+def eq_prepare(definition: Optional[EqualizerDefinition], sample_rate: float) -> ParametricEqualizerState:
+    """ParametricEqualizerProcessor.prepare  :168-212"""
+    if not np.isfinite(sample_rate) or sample_rate <= 0:
+        raise EqualizerPreparationError("invalidSampleRate")
+    preamp = definition.preamp_db if definition else 0.0
+    if not np.isfinite(preamp) or not np.isfinite(10.0 ** (preamp / 20.0) if abs(preamp) < 1e4 else np.inf):
+        raise EqualizerPreparationError("nonFinitePreamp")
+    enabled = [f for f in (definition.filters if definition else []) if f.is_enabled]
+    if len(enabled) > 64:
+        raise EqualizerPreparationError("tooManyFilters", str(len(enabled)))
+    coeffs = []
+    for i, f in enumerate(enabled):
+        try:
+            coeffs.append(biquad_make(f.type, f.gain_db, f.frequency_hz, f.q, sample_rate))
+        except BiquadCoefficientError as e:
+            raise EqualizerPreparationError("invalidFilter", f"{i}: {e.kind}")
+    return ParametricEqualizerState(sample_rate, preamp, coeffs)
+
+
+class ParametricEqualizerProcessor:
+    """ParametricEqualizerProcessor  :116-408: non-blocking target publication, 20 ms linear crossfades,
+    newest-wins queueing, one-slot retirement that the control side drains."""
+
+    CROSSFADE_SECONDS = 0.020
+    MAX_CALLBACK_FRAMES = 4096
+
+    def __init__(self, sample_rate: float, max_frames_per_callback: int = 4096):
+        if not np.isfinite(sample_rate) or sample_rate <= 0:
+            raise EqualizerPreparationError("invalidSampleRate")
+        if not (0 < max_frames_per_callback <= self.MAX_CALLBACK_FRAMES):
+            raise EqualizerPreparationError("tooManyFilters", str(max_frames_per_callback))
+        self.sample_rate, self.max_frames = sample_rate, max_frames_per_callback
+        self.unity = eq_prepare(None, sample_rate)
+        self.active = self.unity
+        self.transition_length = max(1, int(np.floor(sample_rate * self.CROSSFADE_SECONDS + 0.5)))   # .rounded(): half away from zero
+        self.target = None            # published target (control side)
+        self.audio_target = None
+        self.observed = None
+        self.t_from = self.t_to = None
+        self.pending_target = None
+        self.pending_retirement = None
+        self.retired = None           # the one-slot retirement box
+        self.t_frame = 0
+        self.reset_requested = False
+
+    def set_target(self, definition):                       # :226-228
+        self.target = eq_prepare(definition, self.sample_rate)
+
+    def reset(self):                                        # :230-234
+        self.reset_requested = True
+
+    def drain_retired_states(self):                         # :237-241
+        self.retired = None
+
+    def process(self, left, right=None):                    # :244-309
+        l = _f32(left)
+        r = None if right is None else _f32(right)
+        n = l.size
+        if n == 0:
+            return l.copy(), l.copy()
+        if n > self.max_frames:
+            raise ValueError("frameCount exceeds maxFramesPerCallback")
+        self._observe()
+        self._flush_pending_retirement()
+        if self.reset_requested:
+            self.reset_requested = False
+            for s in (self.active, self.t_from, self.t_to):
+                if s is not None:
+                    s.reset()
+        out_l = np.empty(n, np.float32)
+        out_r = np.empty(n, np.float32)
+        off = 0
+        while off < n:
+            if self.t_from is None or self.t_to is None:
+                a, b = self.active.process(l[off:], None if r is None else r[off:])
+                out_l[off:], out_r[off:] = a, b
+                return out_l, out_r
+            seg = min(self.transition_length - self.t_frame, n - off)
+            ol, orr = self.t_from.process(l[off:off + seg], None if r is None else r[off:off + seg])
+            nl, nr = self.t_to.process(l[off:off + seg], None if r is None else r[off:off + seg])
+            prog = (self.t_frame + np.arange(seg) + 1).astype(np.float64) / float(self.transition_length)
+            inv = 1.0 - prog
+            out_l[off:off + seg] = (ol.astype(np.float64) * inv + nl.astype(np.float64) * prog).astype(np.float32)
+            out_r[off:off + seg] = (orr.astype(np.float64) * inv + nr.astype(np.float64) * prog).astype(np.float32)
+            self.t_frame += seg
+            off += seg
+            if self.t_frame == self.transition_length:
+                self._finish()
+        return out_l, out_r
+
+    def _observe(self):                                     # :311-333
+        if self.target is not None:
+            self.audio_target = self.target
+        t = self.audio_target
+        if t is None or t is self.observed:
+            return
+        self.observed = t
+        if self.t_to is not None:
+            if t is not self.t_to:
+                self.pending_target = t
+        elif self.pending_retirement is not None:
+            self.pending_target = t
+        elif t is not self.active:
+            self._begin(t)
+
+    def _begin(self, t):                                    # :349-354
+        if t is self.active:
+            return
+        self.t_from, self.t_to, self.t_frame = self.active, t, 0
+
+    def _finish(self):                                      # :356-371
+        frm = self.t_from
+        self.active, self.t_from, self.t_to, self.t_frame = self.t_to, None, None, 0
+        if not self._retire(frm):
+            return
+        if self.pending_target is not None:
+            p, self.pending_target = self.pending_target, None
+            if p is not self.active:
+                self._begin(p)
+
+    def _retire(self, state):                               # :373-386
+        if self.pending_retirement is not None:
+            return False
+        if self.retired is None:
+            self.retired = state
+            return True
+        self.pending_retirement = state
+        return False
+
+    def _flush_pending_retirement(self):                    # :388-406
+        if self.pending_retirement is None:
+            return
+        if self.retired is not None:
+            return
+        self.retired, self.pending_retirement = self.pending_retirement, None
+        if self.pending_target is not None:
+            p, self.pending_target = self.pending_target, None
+            if p is not self.active:
+                self._begin(p)
