@@ -14,7 +14,16 @@ from .api import (  # noqa: E402
     RealtimeAudioProcessor, Resampler, Spatializer, WAVData, WAVError, WAVLoader, default_context,
 )
 
+from .eq import (  # noqa: E402
+    BiquadCoefficientBuilder, BiquadCoefficientError, EqualizerAPOParser, EqualizerAudioEffectError, EqualizerDefinition,
+    EqualizerFilter, EqualizerParseError, EqualizerRuntimeEffect, ParametricEqualizerPreparationError,
+    ParametricEqualizerProcessor, ParametricEqualizerState,
+)
+
 __all__ = [
+    "BiquadCoefficientBuilder", "BiquadCoefficientError", "EqualizerAPOParser", "EqualizerAudioEffectError",
+    "EqualizerDefinition", "EqualizerFilter", "EqualizerParseError", "EqualizerRuntimeEffect",
+    "ParametricEqualizerPreparationError", "ParametricEqualizerProcessor", "ParametricEqualizerState",
     "AirwaveError", "Context", "ConvolutionEngine", "HRIR", "HRIRChannelMap", "HRIRError", "HRIRManager",
     "InputLayout", "RealtimeAudioProcessor", "Resampler", "Spatializer", "WAVData", "WAVError", "WAVLoader",
     "default_context",

@@ -85,6 +85,31 @@ SIGNATURES = {
     "aw_resample": (_I32, [c_float_p, _I32, _D, _D, c_float_p, _I32, c_int32_p]),
     "aw_preset_activate": (_I32, [_V, _S, _D, _V, _V, _I32, c_void_pp, c_void_pp]),
     "aw_synth_fill": (_I32, [_V, _V, _I32, _I64, _I32, _U64, _U64]),
+    # parametric EQ row
+    "aw_biquad_make": (_I32, [_I32, _D, _D, _D, _D, ctypes.POINTER(ctypes.c_double), c_int32_p]),
+    "aw_eq_definition_create": (_I32, [_D, c_void_pp]),
+    "aw_eq_definition_add_filter": (_I32, [_V, _I32, _I32, _D, _D, _D]),
+    "aw_eq_definition_destroy": (None, [_V]),
+    "aw_eq_definition_preamp_db": (_D, [_V]),
+    "aw_eq_definition_filter_count": (_I32, [_V]),
+    "aw_eq_definition_filter": (_I32, [_V, _I32, c_int32_p, ctypes.POINTER(ctypes.c_int64), c_int32_p, c_int32_p,
+                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "aw_eq_parse": (_I32, [_V, _SZ, c_void_pp, ctypes.c_char_p, _SZ]),
+    "aw_eq_state_create": (_I32, [_V, _V, _D, _I32, c_void_pp]),
+    "aw_eq_state_destroy": (None, [_V]),
+    "aw_eq_state_reset": (_I32, [_V]),
+    "aw_eq_state_process": (_I32, [_V, _V, _V, _I64]),
+    "aw_eq_state_filter_count": (_I32, [_V]),
+    "aw_eq_state_preamp_linear": (_D, [_V]),
+    "aw_eq_create": (_I32, [_V, _D, _I32, _I32, c_void_pp]),
+    "aw_eq_destroy": (None, [_V]),
+    "aw_eq_set_target": (_I32, [_V, _V]),
+    "aw_eq_reset": (_I32, [_V]),
+    "aw_eq_drain_retired": (_I32, [_V]),
+    "aw_eq_process": (_I32, [_V, _V, _V, _I64]),
+    "aw_eq_process_planar": (_I32, [_V, c_float_p, c_float_p, c_float_p, c_float_p, _I32]),
+    "aw_eq_transition_length": (_I32, [_V]),
+    "aw_eq_is_transitioning": (_I32, [_V]),
 }
 
 _lib = None

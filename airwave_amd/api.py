@@ -18,7 +18,8 @@ AW_OK = 0
 STATUS_NAMES = {
     1: "INVALID_ARGUMENT", 2: "OUT_OF_MEMORY", 3: "HIP", 4: "NO_DEVICE", 5: "INVALID_CHANNEL_MAPPING",
     6: "CONVOLUTION_SETUP_FAILED", 7: "INVALID_CHANNEL_COUNT", 8: "WAV_FILE_READ", 9: "WAV_EMPTY_FILE",
-    10: "WAV_UNSUPPORTED_FORMAT", 11: "BLOCK_SIZE_MISMATCH",
+    10: "WAV_UNSUPPORTED_FORMAT", 11: "BLOCK_SIZE_MISMATCH", 12: "EQ_PARSE", 13: "EQ_INVALID_SAMPLE_RATE",
+    14: "EQ_NON_FINITE_PREAMP", 15: "EQ_TOO_MANY_FILTERS", 16: "EQ_INVALID_FILTER",
 }
 
 

@@ -19,12 +19,16 @@ ARCH = "gfx950"
 
 SOURCES = [
     "device/kernels.hip",
+    "device/eq_kernels.hip",
     "runtime.cpp",
+    "eq_runtime.cpp",
+    "host/eq.cpp",
     "host/tables.cpp",
     "host/host_api.cpp",
 ]
 HEADERS = [
-    "device/cplx.hpp", "device/tile_ols.hpp", "device/kernels.hpp", "runtime.hpp", "host/tables.hpp",
+    "device/cplx.hpp", "device/tile_ols.hpp", "device/kernels.hpp", "device/eq_cascade.hpp", "device/eq_kernels.hpp",
+    "runtime.hpp", "host/tables.hpp", "host/eq.hpp",
     "../../include/airwave_hip.h",
 ]
 

@@ -49,6 +49,11 @@ const char *aw_status_string(aw_status s) {
         case AW_ERR_WAV_EMPTY_FILE: return "WAV file is empty (0 frames)";                // :139
         case AW_ERR_WAV_UNSUPPORTED_FORMAT: return "Unsupported WAV format";              // :143
         case AW_ERR_BLOCK_SIZE_MISMATCH: return "frame count differs from the engine block size";
+        case AW_ERR_EQ_PARSE: return "Could not read the equalizer preset";                // EqualizerAPOParser.swift:19
+        case AW_ERR_EQ_INVALID_SAMPLE_RATE: return "Sample rate must be finite and positive.";   // ParametricEqualizerProcessor.swift:106-107
+        case AW_ERR_EQ_NON_FINITE_PREAMP: return "Preamp must produce a finite linear gain.";   // :108-109
+        case AW_ERR_EQ_TOO_MANY_FILTERS: return "Equalizer supports at most 64 filters";   // :110-111
+        case AW_ERR_EQ_INVALID_FILTER: return "Filter is invalid";                          // :112-113
         default: return "unknown status";
     }
 }

@@ -44,7 +44,12 @@ enum {
     AW_ERR_WAV_FILE_READ = 8,            /* WAVError.fileReadError   WAVLoader.swift:31-33,59-61 */
     AW_ERR_WAV_EMPTY_FILE = 9,           /* WAVError.emptyFile       WAVLoader.swift:44-46 */
     AW_ERR_WAV_UNSUPPORTED_FORMAT = 10,  /* WAVError.unsupportedFormat WAVLoader.swift:89-91 */
-    AW_ERR_BLOCK_SIZE_MISMATCH = 11      /* ConvolutionEngine.process(input:output:frameCount:) guard, ConvolutionEngine.swift:372 */
+    AW_ERR_BLOCK_SIZE_MISMATCH = 11,     /* ConvolutionEngine.process(input:output:frameCount:) guard, ConvolutionEngine.swift:372 */
+    AW_ERR_EQ_PARSE = 12,                /* EqualizerParseError                     EqualizerAPOParser.swift:8-21 */
+    AW_ERR_EQ_INVALID_SAMPLE_RATE = 13,  /* ParametricEqualizerPreparationError.invalidSampleRate  ParametricEqualizerProcessor.swift:100-101 */
+    AW_ERR_EQ_NON_FINITE_PREAMP = 14,    /* .nonFinitePreamp  :102 */
+    AW_ERR_EQ_TOO_MANY_FILTERS = 15,     /* .tooManyFilters   :103 (also the maxFramesPerCallback guard, :148-150) */
+    AW_ERR_EQ_INVALID_FILTER = 16        /* .invalidFilter(index:error:)  :104; BiquadCoefficientError  BiquadCoefficientBuilder.swift:11-16 */
 };
 AW_API const char *aw_status_string(aw_status s);
 AW_API const char *aw_last_error_message(void); /* thread-local, valid until the next failing call */
@@ -204,6 +209,70 @@ AW_API aw_status aw_preset_activate(aw_context *ctx, const char *wav_path, doubl
  * value(stream, i) as oracle/airwave_oracle.h:orc_synth_value.  dst: [n_streams][frames][n_channels]. */
 AW_API aw_status aw_synth_fill(aw_context *ctx, float *dst_device, int32_t n_streams, int64_t frames,
                                int32_t n_channels, uint64_t seed, uint64_t first_stream);
+
+/* ==== Parametric EQ (the effect that follows the spatializer) ======================
+ * Mirrors BiquadCoefficientBuilder, EqualizerAPOParser, ParametricEqualizerState and
+ * ParametricEqualizerProcessor for a batch of independent stereo streams held in HBM
+ * ([stream][frames][2] interleaved L,R float32 — the spatializer's output layout).  Arithmetic is
+ * Float64 like the reference's; the time axis is evaluated chunk-parallel (device/eq_cascade.hpp), so
+ * results agree with the sequential recurrence to Float64 rounding (<= 1 ulp of the Float32 output). */
+
+/* BiquadCoefficientBuilder.make  BiquadCoefficientBuilder.swift:29-107.  type: 0 peaking, 1 lowShelf,
+ * 2 highShelf.  coefficients_out = {b0, b1, b2, a1, a2}.  On AW_ERR_EQ_INVALID_FILTER *error_kind is the
+ * BiquadCoefficientError: 1 invalidSampleRate, 2 invalidFrequency, 3 invalidQ, 4 nonFiniteInput,
+ * 5 nonFiniteCoefficients (error_kind may be NULL). */
+AW_API aw_status aw_biquad_make(int32_t type, double gain_db, double frequency_hz, double q, double sample_rate,
+                                double coefficients_out[5], int32_t *error_kind);
+
+/* EqualizerDefinition / EqualizerFilter  EqualizerPreset.swift:9-27 (host object). */
+typedef struct aw_eq_definition aw_eq_definition;
+AW_API aw_status aw_eq_definition_create(double preamp_db, aw_eq_definition **out);
+AW_API aw_status aw_eq_definition_add_filter(aw_eq_definition *d, int32_t is_enabled, int32_t type, double frequency_hz,
+                                             double gain_db, double q);
+AW_API void aw_eq_definition_destroy(aw_eq_definition *d);
+AW_API double aw_eq_definition_preamp_db(const aw_eq_definition *d);
+AW_API int32_t aw_eq_definition_filter_count(const aw_eq_definition *d);
+/* source_number_out: -1 when the directive carried no number (nil).  Any out pointer may be NULL. */
+AW_API aw_status aw_eq_definition_filter(const aw_eq_definition *d, int32_t index, int32_t *source_line, int64_t *source_number,
+                                         int32_t *is_enabled, int32_t *type, double *frequency_hz, double *gain_db, double *q);
+/* EqualizerAPOParser.parse(data:filename:)  EqualizerAPOParser.swift:36-151.  On AW_ERR_EQ_PARSE the
+ * issues are written to issues_out as "line N: reason" / "reason" joined by "; " (the text of
+ * EqualizerParseError.errorDescription without the filename prefix), truncated to issues_capacity. */
+AW_API aw_status aw_eq_parse(const void *data, size_t size, aw_eq_definition **out, char *issues_out, size_t issues_capacity);
+
+/* ParametricEqualizerState  ParametricEqualizerProcessor.swift:16-98, prepared by
+ * ParametricEqualizerProcessor.prepare(definition:sampleRate:) :168-212, for n_streams streams.
+ * definition may be NULL (unity).  On AW_ERR_EQ_INVALID_FILTER aw_last_error_message() names the filter. */
+typedef struct aw_eq_state aw_eq_state;
+AW_API aw_status aw_eq_state_create(aw_context *ctx, const aw_eq_definition *definition, double sample_rate,
+                                    int32_t n_streams, aw_eq_state **out);
+AW_API void aw_eq_state_destroy(aw_eq_state *s);
+AW_API aw_status aw_eq_state_reset(aw_eq_state *s);                                     /* reset() :49-56 */
+/* process(...) :58-91 on device buffers, in place allowed; asynchronous on the context stream. */
+AW_API aw_status aw_eq_state_process(aw_eq_state *s, const float *in_device, float *out_device, int64_t frames);
+AW_API int32_t aw_eq_state_filter_count(const aw_eq_state *s);
+AW_API double aw_eq_state_preamp_linear(const aw_eq_state *s);
+
+/* ParametricEqualizerProcessor  :116-408: starts at unity; aw_eq_set_target prepares and publishes a
+ * target that the next process call crossfades to over max(1, round(0.020 * sample_rate)) frames
+ * (:155); newest target wins while a fade runs (:311-333); a finished fade parks the old state in a
+ * one-slot retirement box that aw_eq_drain_retired empties, and a full box holds the next fade back
+ * (:373-406).  max_frames_per_callback: 0 = unlimited (batch); otherwise the reference's guard
+ * 1..4096 (:148-150, AW_ERR_EQ_TOO_MANY_FILTERS as there) and process() rejects longer calls. */
+typedef struct aw_eq aw_eq;
+AW_API aw_status aw_eq_create(aw_context *ctx, double sample_rate, int32_t n_streams, int32_t max_frames_per_callback,
+                              aw_eq **out);
+AW_API void aw_eq_destroy(aw_eq *eq);
+AW_API aw_status aw_eq_set_target(aw_eq *eq, const aw_eq_definition *definition_or_null);   /* setTarget :226-228 */
+AW_API aw_status aw_eq_reset(aw_eq *eq);                                                     /* reset()   :230-234 */
+AW_API aw_status aw_eq_drain_retired(aw_eq *eq);                                             /* drainRetiredStates :237-241 */
+AW_API aw_status aw_eq_process(aw_eq *eq, const float *in_device, float *out_device, int64_t frames);
+/* The StereoAudioProcessing surface (AudioPipeline.swift:3-11): HOST planar buffers, one stream,
+ * in_right may be NULL (left is duplicated, :68); synchronous. */
+AW_API aw_status aw_eq_process_planar(aw_eq *eq, const float *in_left, const float *in_right, float *out_left,
+                                      float *out_right, int32_t frames);
+AW_API int32_t aw_eq_transition_length(const aw_eq *eq);
+AW_API int32_t aw_eq_is_transitioning(const aw_eq *eq);
 
 AW_API const char *aw_version(void);
 

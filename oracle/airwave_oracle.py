@@ -557,7 +557,7 @@ _FILTER_RE = _re.compile(r"^Filter(?:\s+([0-9]+))?\s*:\s+(ON|OFF)\s+(PK|LSC|HSC)
 def _finite_double(text: str) -> Optional[float]:
     """Swift Double(String): decimal / exponent / hex forms, 'inf'/'nan' spellings parse but are rejected as
     non-finite; no surrounding whitespace, no underscores."""
-    if not _re.fullmatch(r"[+-]?((\d+\.?\d*([eE][+-]?\d+)?)|(\.\d+([eE][+-]?\d+)?)|(0[xX][0-9a-fA-F]+\.?[0-9a-fA-F]*([pP][+-]?\d+)?)|inf|infinity|nan)", text, _re.IGNORECASE):
+    if not _re.fullmatch(r"[+-]?(([0-9]+\.?[0-9]*([eE][+-]?[0-9]+)?)|(\.[0-9]+([eE][+-]?[0-9]+)?)|(0[xX][0-9a-fA-F]+\.?[0-9a-fA-F]*([pP][+-]?[0-9]+)?)|inf|infinity|nan)", text, _re.IGNORECASE):
         return None
     try:
         v = float.fromhex(text) if _re.match(r"[+-]?0[xX]", text) else float(text)
@@ -579,7 +579,9 @@ def eq_parse(data: bytes, filename: str = "preset.txt") -> EqualizerDefinition:
     preamp, has_preamp, decl = 0.0, False, 0
     filters: List[EqualizerFilter] = []
     issues = []
-    for index, raw in enumerate(_re.split(r"\r\n|\n|\r|\x0b|\x0c|\x85| | ", source)):
+    # components(separatedBy: .newlines) splits at EVERY newline scalar (CR LF therefore yields an empty
+    # component and advances the line number twice) — unpinned by the reference tests, kept literal.
+    for index, raw in enumerate(_re.split("[\n\r\x0b\x0c\x85\u2028\u2029]", source)):
         n = index + 1
         line = raw.strip()
         if not line or line.startswith("#"):

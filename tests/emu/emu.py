@@ -8,9 +8,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _LIB = os.path.join(_HERE, "libemu.so")
-_SRCS = [os.path.join(_HERE, "emu_harness.cpp"), os.path.join(_ROOT, "airwave_amd/csrc/host/tables.cpp")]
-_DEPS = _SRCS + [os.path.join(_ROOT, "airwave_amd/csrc/device", f) for f in ("tile_ols.hpp", "cplx.hpp")] + [
-    os.path.join(_ROOT, "airwave_amd/csrc/host/tables.hpp")]
+_SRCS = [os.path.join(_HERE, "emu_harness.cpp"), os.path.join(_ROOT, "airwave_amd/csrc/host/tables.cpp"),
+         os.path.join(_ROOT, "airwave_amd/csrc/host/eq.cpp")]
+_DEPS = _SRCS + [os.path.join(_ROOT, "airwave_amd/csrc/device", f) for f in ("tile_ols.hpp", "cplx.hpp", "eq_cascade.hpp")] + [
+    os.path.join(_ROOT, "airwave_amd/csrc/host/tables.hpp"), os.path.join(_ROOT, "airwave_amd/csrc/host/eq.hpp")]
 _lib = None
 
 fp = ctypes.POINTER(ctypes.c_float)
@@ -28,6 +29,8 @@ def lib():
         _lib.emu_partitioned.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
                                          ctypes.c_longlong, ctypes.c_int]
         _lib.emu_fft_small.argtypes = [fp, ctypes.c_int, ctypes.c_int]
+        _lib.emu_eq_process.argtypes = [fp, fp, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_longlong, ctypes.c_double,
+                                        ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.c_int]
     return _lib
 
 
@@ -72,3 +75,18 @@ def fft_small(v, inverse=False):
     a = np.ascontiguousarray(np.asarray(v, dtype=np.complex64)).view(np.float32).copy()
     assert lib().emu_fft_small(a.ctypes.data_as(fp), a.size // 2, int(inverse)) == 0
     return a.view(np.complex64)
+
+
+def eq_process(x, sample_rate, preamp_db, filters, z=None):
+    """x: [streams][frames][2] float32; filters: [(type, fc, gain_db, q)].  Returns (y, z) with z the carried state."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    S, F, _ = x.shape
+    fl = np.ascontiguousarray(np.asarray(filters, dtype=np.float64).reshape(-1, 4))
+    K = fl.shape[0]
+    z = np.zeros((S, max(K, 1), 4), np.float64) if z is None else np.ascontiguousarray(z, dtype=np.float64)
+    out = np.full((S, F, 2), np.nan, dtype=np.float32)
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = lib().emu_eq_process(x.ctypes.data_as(fp), out.ctypes.data_as(fp), z.ctypes.data_as(dp), S, F, sample_rate, preamp_db,
+                              fl.ctypes.data_as(dp), K)
+    assert rc == K, rc
+    return out, z

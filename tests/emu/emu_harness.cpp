@@ -13,6 +13,8 @@
 #include <vector>
 
 #include "../../airwave_amd/csrc/device/tile_ols.hpp"
+#include "../../airwave_amd/csrc/device/eq_cascade.hpp"
+#include "../../airwave_amd/csrc/host/eq.hpp"
 #include "../../airwave_amd/csrc/host/tables.hpp"
 
 namespace {
@@ -20,11 +22,11 @@ namespace {
 alignas(16) float g_zeros[1024] = {0};
 
 struct EmuShared {
-    std::barrier<> wg{awk::kThreads};
+    std::barrier<> wg;
     std::vector<std::unique_ptr<std::barrier<>>> wave;
     std::vector<awk::cf> lds;
-    EmuShared() : lds((size_t)awk::kLdsElems) {
-        for (int w = 0; w < awk::kThreads / 64; ++w) wave.emplace_back(new std::barrier<>(64));
+    explicit EmuShared(int threads = awk::kThreads, size_t lds_elems = (size_t)awk::kLdsElems) : wg(threads), lds(lds_elems) {
+        for (int w = 0; w < threads / 64; ++w) wave.emplace_back(new std::barrier<>(64));
     }
 };
 
@@ -175,6 +177,47 @@ int emu_fft_small(float *data, int n, int inverse) {
         std::memcpy(data, v, sizeof(v));
     } else return -1;
     return 0;
+}
+
+// Parametric EQ cascade: one emulated workgroup (kEqThreads) per stream for the chunk-aligned part,
+// eq_sequential for the tail — the same split runtime.cpp makes.  filters: [n][4] = type, fc, gain, q.
+// z: [stream][K][4] state, carried in and out.  Returns K or a negative prepare error.
+int emu_eq_process(const float *in, float *out, double *z, int n_streams, long long frames, double sample_rate,
+                   double preamp_db, const double *filters, int n_filters) {
+    using namespace awk;
+    awh::EqDefinition def;
+    def.preamp_db = preamp_db;
+    for (int i = 0; i < n_filters; ++i) {
+        awh::EqFilter f;
+        f.type = (int)filters[i * 4]; f.frequency_hz = filters[i * 4 + 1]; f.gain_db = filters[i * 4 + 2]; f.q = filters[i * 4 + 3];
+        def.filters.push_back(f);
+    }
+    awh::EqPrepared prep;
+    int bi = 0, bk = 0;
+    const int rc = awh::eq_prepare(&def, sample_rate, prep, &bi, &bk);
+    if (rc) return -rc;
+    EqParams p{};
+    p.in = in; p.out = out; p.z = z;
+    p.t.coef = prep.coef.data(); p.t.zir = prep.zir.data(); p.t.ppow = prep.ppow.data(); p.t.plane = prep.plane.data();
+    p.t.preamp = prep.preamp; p.t.n_filters = prep.n_filters;
+    p.stride_frames = frames;
+    const long long body = frames - frames % kEqChunk;
+    if (body > 0) {
+        p.frames = body;
+        EmuShared sh(kEqThreads, (size_t)kEqLdsBytes / sizeof(cf));
+        for (int s = 0; s < n_streams; ++s) {
+            std::vector<std::thread> th;
+            th.reserve(kEqThreads);
+            for (int t = 0; t < kEqThreads; ++t) th.emplace_back([&, t]() { EmuCtx ctx{t, &sh}; eq_cascade_stream(ctx, p, s); });
+            for (auto &x : th) x.join();
+        }
+    }
+    if (frames > body) {
+        p.in = in + body * 2; p.out = out + body * 2; p.frames = frames - body;
+        for (int s = 0; s < n_streams; ++s)
+            for (int ear = 0; ear < 2; ++ear) eq_sequential(p, s, ear);
+    }
+    return prep.n_filters;
 }
 
 }  // extern "C"
