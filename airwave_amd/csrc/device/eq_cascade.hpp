@@ -24,6 +24,12 @@
 #pragma once
 #include "cplx.hpp"
 
+// Timing ablations (wrong results; tools/eq_ablate.sh only): bit 0 no recurrence, 1 no in-wave scan,
+// 2 no wave chaining, 3 no zero-input correction.
+#ifndef AW_EQ_ABL
+#define AW_EQ_ABL 0
+#endif
+
 namespace awk {
 
 constexpr int kEqThreads = 256;
@@ -37,7 +43,10 @@ constexpr int kEqStageBytes = kEqThreads * kEqStageStride * 8;            // 36,
 constexpr int kEqScanBytes = kEqThreads * 4 * 8;                          // [thread][4] double, wave-private slots
 constexpr int kEqTotalsBytes = 2 * (kEqThreads / 64) * 4 * 8;             // ping-pong [wave][4]
 constexpr int kEqCarryBytes = 2 * kEqMaxFilters * 4 * 8;                  // ping-pong [filter][4]
-constexpr int kEqLdsBytes = kEqStageBytes + kEqScanBytes + kEqTotalsBytes + kEqCarryBytes;   // 49,408
+constexpr int kEqLdsFixedBytes = kEqStageBytes + kEqScanBytes + kEqTotalsBytes + kEqCarryBytes;   // 49,408
+// + the uniform per-filter tables (coef | zir | ppow), staged once per launch
+constexpr int kEqTabDoubles = 5 + kEqChunk * 2 + kEqScanSteps * 4;        // 65 per filter
+AW_HD int eq_lds_bytes(int n_filters) { return kEqLdsFixedBytes + n_filters * kEqTabDoubles * 8; }
 
 // Per-state tables, built on the host in double (host/eq.cpp).
 struct EqTables {
@@ -62,10 +71,12 @@ AW_HD double eq_flush(double v) { return (v < 0 ? -v : v) < 1e-30 ? 0.0 : v; }  
 
 // acc += P * q for the (z1, z2) pairs of both ears
 AW_HD void eq_apply(const double *P, const double *q, double &l1, double &l2, double &r1, double &r2) {
-    l1 += P[0] * q[0] + P[1] * q[1];
-    l2 += P[2] * q[0] + P[3] * q[1];
-    r1 += P[0] * q[2] + P[1] * q[3];
-    r2 += P[2] * q[2] + P[3] * q[3];
+    const double p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3];
+    const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    l1 = __builtin_fma(p1, q1, __builtin_fma(p0, q0, l1));
+    l2 = __builtin_fma(p3, q1, __builtin_fma(p2, q0, l2));
+    r1 = __builtin_fma(p1, q3, __builtin_fma(p0, q2, r1));
+    r2 = __builtin_fma(p3, q3, __builtin_fma(p2, q2, r2));
 }
 
 // One workgroup, one stream; p.frames must be a multiple of kEqChunk.
@@ -77,6 +88,7 @@ template <class Ctx> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParams &p, l
     double *scan = reinterpret_cast<double *>(lds + kEqStageBytes);
     double *totals = reinterpret_cast<double *>(lds + kEqStageBytes + kEqScanBytes);
     double *carry = reinterpret_cast<double *>(lds + kEqStageBytes + kEqScanBytes + kEqTotalsBytes);
+    double *tab = reinterpret_cast<double *>(lds + kEqLdsFixedBytes);   // [K][65]: coef 5 | zir 32 | ppow 28
     const int wave = ctx.wave();
     const int K = p.t.n_filters;
     double *zs = p.z + stream * (long long)K * 4;
@@ -85,6 +97,11 @@ template <class Ctx> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParams &p, l
     const double preamp = p.t.preamp;
 
     for (int i = tid; i < K * 4; i += kEqThreads) carry[i] = zs[i];
+    for (int i = tid; i < K * kEqTabDoubles; i += kEqThreads) {
+        const int k = i / kEqTabDoubles, r = i - k * kEqTabDoubles;
+        tab[i] = r < 5 ? p.t.coef[k * 5 + r]
+                       : r < 5 + kEqChunk * 2 ? p.t.zir[k * kEqChunk * 2 + (r - 5)] : p.t.ppow[k * kEqScanSteps * 4 + (r - 5 - kEqChunk * 2)];
+    }
     int par = 0;
 
     for (long long base = 0; base < p.frames; base += kEqSpan) {
@@ -109,26 +126,29 @@ template <class Ctx> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParams &p, l
         }
 
         for (int k = 0; k < K; ++k) {
-            const double *c = p.t.coef + k * 5;
-            const double b0 = c[0], b1 = c[1], b2 = c[2], a1 = c[3], a2 = c[4];
+            const double *c = tab + k * kEqTabDoubles;
+            const double b0 = c[0], b1 = c[1], b2 = c[2], na1 = -c[3], na2 = -c[4];
+            // this lane's power of P for step (2c): issued now, consumed after the chunk's recurrence
+            const double *plp = p.t.plane + ((long long)k * 64 + lane) * 4;
+            const double pl[4] = {plp[0], plp[1], plp[2], plp[3]};
             // (1) zero-state response of this chunk, in place (:71-87 with z = 0)
             double l1 = 0, l2 = 0, r1 = 0, r2 = 0;
 #pragma unroll
-            for (int j = 0; j < kEqChunk; ++j) {
-                const double lo = b0 * xl[j] + l1;
-                l1 = b1 * xl[j] - a1 * lo + l2;
-                l2 = b2 * xl[j] - a2 * lo;
+            for (int j = 0; j < ((AW_EQ_ABL & 1) ? 1 : kEqChunk); ++j) {
+                const double lo = __builtin_fma(b0, xl[j], l1);
+                l1 = __builtin_fma(na1, lo, __builtin_fma(b1, xl[j], l2));
+                l2 = __builtin_fma(na2, lo, b2 * xl[j]);
                 xl[j] = lo;
-                const double ro = b0 * xr[j] + r1;
-                r1 = b1 * xr[j] - a1 * ro + r2;
-                r2 = b2 * xr[j] - a2 * ro;
+                const double ro = __builtin_fma(b0, xr[j], r1);
+                r1 = __builtin_fma(na1, ro, __builtin_fma(b1, xr[j], r2));
+                r2 = __builtin_fma(na2, ro, b2 * xr[j]);
                 xr[j] = ro;
             }
-            const double *pp = p.t.ppow + k * kEqScanSteps * 4;
+            const double *pp = c + 5 + kEqChunk * 2;
             const double e0 = l1, e1 = l2, e2 = r1, e3 = r2;
             // (2a) inclusive Hillis-Steele scan INSIDE each wave (d = 1 .. 32) through wave-private slots
 #pragma unroll
-            for (int s = 0; s < 6; ++s) {
+            for (int s = 0; s < ((AW_EQ_ABL & 2) ? 1 : 6); ++s) {
                 const int d = 1 << s;
                 double *w = scan + tid * 4;
                 w[0] = l1; w[1] = l2; w[2] = r1; w[3] = r2;
@@ -146,11 +166,11 @@ template <class Ctx> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParams &p, l
                     t[0] = l1; t[1] = l2; t[2] = r1; t[3] = r2;
                 }
             }
-            ctx.barrier();
+            if (!(AW_EQ_ABL & 4)) ctx.barrier();
             // (2b) state entering this wave: W_0 = carried state, W_w = P^64 W_{w-1} + T_{w-1}
             const double *cin = carry + par * kEqMaxFilters * 4 + k * 4;
             double w0 = cin[0], w1 = cin[1], w2 = cin[2], w3 = cin[3];
-            for (int i = 0; i < wave; ++i) {
+            for (int i = 0; i < ((AW_EQ_ABL & 4) ? 0 : wave); ++i) {
                 const double *t = tot + i * 4;
                 double n0 = t[0], n1 = t[1], n2 = t[2], n3 = t[3];
                 const double q[4] = {w0, w1, w2, w3};
@@ -165,7 +185,7 @@ template <class Ctx> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParams &p, l
             }
             {
                 const double q[4] = {w0, w1, w2, w3};
-                eq_apply(p.t.plane + ((long long)k * 64 + lane) * 4, q, s0, s1, s2, s3);
+                eq_apply(pl, q, s0, s1, s2, s3);
             }
             if (tid == nchunks - 1) {   // state after the last active chunk -> next span / next call
                 double *cout = carry + (par ^ 1) * kEqMaxFilters * 4 + k * 4;
@@ -176,11 +196,12 @@ template <class Ctx> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParams &p, l
             }
             ctx.wave_sync();   // the exclusive reads above precede the next filter's slot writes
             // (3) zero-input response of the entering state
-            const double *g = p.t.zir + k * kEqChunk * 2;
+            const double *g = c + 5;
 #pragma unroll
-            for (int j = 0; j < kEqChunk; ++j) {
-                xl[j] += g[2 * j] * s0 + g[2 * j + 1] * s1;
-                xr[j] += g[2 * j] * s2 + g[2 * j + 1] * s3;
+            for (int j = 0; j < ((AW_EQ_ABL & 8) ? 1 : kEqChunk); ++j) {
+                const double g0 = g[2 * j], g1 = g[2 * j + 1];
+                xl[j] = __builtin_fma(g1, s1, __builtin_fma(g0, s0, xl[j]));
+                xr[j] = __builtin_fma(g1, s3, __builtin_fma(g0, s2, xr[j]));
             }
         }
         par = K ? par ^ 1 : par;

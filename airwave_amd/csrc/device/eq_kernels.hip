@@ -58,7 +58,7 @@ __global__ void aw_eq_copy_kernel(const float *__restrict__ src, long long src_s
 
 hipError_t launch_eq_cascade(const EqParams &p, int n_streams, hipStream_t stream) {
     if (n_streams <= 0 || p.frames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(aw_eq_cascade_kernel, dim3((unsigned)n_streams), dim3(kEqThreads), kEqLdsBytes, stream, p);
+    hipLaunchKernelGGL(aw_eq_cascade_kernel, dim3((unsigned)n_streams), dim3(kEqThreads), (size_t)eq_lds_bytes(p.t.n_filters), stream, p);
     return hipGetLastError();
 }
 

@@ -204,7 +204,7 @@ int emu_eq_process(const float *in, float *out, double *z, int n_streams, long l
     const long long body = frames - frames % kEqChunk;
     if (body > 0) {
         p.frames = body;
-        EmuShared sh(kEqThreads, (size_t)kEqLdsBytes / sizeof(cf));
+        EmuShared sh(kEqThreads, (size_t)eq_lds_bytes(prep.n_filters) / sizeof(cf));
         for (int s = 0; s < n_streams; ++s) {
             std::vector<std::thread> th;
             th.reserve(kEqThreads);

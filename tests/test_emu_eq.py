@@ -1,9 +1,13 @@
 """CPU thread emulation of the EQ cascade kernel (the code hipcc compiles, device/eq_cascade.hpp) against the
 oracle's sequential recurrence: span boundaries, partial spans, tails, carried state, poles near the unit circle."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
-from emu import emu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+import emu  # noqa: E402
 
 FILTERS = [(1, 105.0, -2.8, 0.7), (0, 65.3, 1.0, 1.68), (0, 1000.0, 6.0, 0.707), (2, 10000.0, -5.2, 0.7), (0, 20.0, 3.0, 4.0)]
 
