@@ -14,6 +14,7 @@ from .api import (  # noqa: E402
     RealtimeAudioProcessor, Resampler, Spatializer, WAVData, WAVError, WAVLoader, default_context,
 )
 
+from .batching import MixedRateBatch, RateBucket, bucket_by_rate, resample_tracks  # noqa: E402
 from .eq import (  # noqa: E402
     BiquadCoefficientBuilder, BiquadCoefficientError, EqualizerAPOParser, EqualizerAudioEffectError, EqualizerDefinition,
     EqualizerFilter, EqualizerParseError, EqualizerRuntimeEffect, ParametricEqualizerPreparationError,
@@ -21,6 +22,7 @@ from .eq import (  # noqa: E402
 )
 
 __all__ = [
+    "MixedRateBatch", "RateBucket", "bucket_by_rate", "resample_tracks",
     "BiquadCoefficientBuilder", "BiquadCoefficientError", "EqualizerAPOParser", "EqualizerAudioEffectError",
     "EqualizerDefinition", "EqualizerFilter", "EqualizerParseError", "EqualizerRuntimeEffect",
     "ParametricEqualizerPreparationError", "ParametricEqualizerProcessor", "ParametricEqualizerState",

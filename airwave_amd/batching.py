@@ -1,0 +1,74 @@
+"""Mixed-rate batches (BASELINE cfg 5): streams are bucketed by sample rate and every
+bucket gets its own renderer network built exactly as HRIRManager.activatePreset builds one for an output
+device of that rate — the HRIR (not the audio) is resampled to the stream rate with Resampler
+(HRIRManager.swift:389-403, Resampler.swift:31-68) — so one preset serves 44.1/48/96 kHz streams side by
+side.  Host-side orchestration over the kernels of the convolution path; nothing here touches samples."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .api import Context, HRIR, HRIRChannelMap, InputLayout, Resampler, Spatializer, default_context
+
+
+@dataclass
+class RateBucket:
+    sample_rate: float
+    stream_ids: List[int]            # positions in the caller's stream list, in order
+    hrir_taps: int
+    spatializer: Spatializer
+
+
+def bucket_by_rate(stream_rates: Sequence[float]) -> Dict[float, List[int]]:
+    """Stable bucketing: rates in first-appearance order, stream ids ascending inside a bucket."""
+    buckets: Dict[float, List[int]] = {}
+    for i, r in enumerate(stream_rates):
+        buckets.setdefault(float(r), []).append(i)
+    return buckets
+
+
+def resample_tracks(tracks: np.ndarray, from_rate: float, to_rate: float) -> np.ndarray:
+    """Every HRIR track through Resampler.resampleHighQuality (identity when the rates agree, :33-35)."""
+    if from_rate == to_rate:
+        return np.ascontiguousarray(tracks, dtype=np.float32)
+    return np.stack([Resampler.resampleHighQuality(t, from_rate, to_rate) for t in tracks])
+
+
+class MixedRateBatch:
+    """One preset, streams at several sample rates: `buckets[rate].spatializer` convolves that rate's streams."""
+
+    def __init__(self, tracks, hrir_rate: float, layout: InputLayout, stream_rates: Sequence[float],
+                 hrirMap: Optional[HRIRChannelMap] = None, ctx: Optional[Context] = None):
+        self.ctx = ctx or default_context()
+        tracks = np.ascontiguousarray(tracks, dtype=np.float32)
+        cmap = hrirMap or (HRIRChannelMap.hesuvi14Channel(layout) if tracks.shape[0] >= 14 else HRIRChannelMap.hesuvi7Channel(layout))
+        lt, rt = cmap.resolve(layout, tracks.shape[0])
+        self.left_track, self.right_track = lt, rt
+        self.buckets: Dict[float, RateBucket] = {}
+        for rate, ids in bucket_by_rate(stream_rates).items():
+            tr = resample_tracks(tracks, hrir_rate, rate)
+            sp = Spatializer(HRIR(tr, rate, ctx=self.ctx), lt, rt, n_streams=len(ids), ctx=self.ctx)
+            self.buckets[rate] = RateBucket(rate, ids, int(tr.shape[1]), sp)
+
+    def process_device(self, in_ptrs: Dict[float, int], out_ptrs: Dict[float, int], frames: Dict[float, int]) -> None:
+        """Per-rate device buffers ([bucket streams][frames][C] -> [..][frames][2]); all launches are queued on
+        the context stream, buckets back to back."""
+        for rate, b in self.buckets.items():
+            b.spatializer.process_device(in_ptrs[rate], out_ptrs[rate], frames[rate])
+
+    def process(self, streams: Sequence[np.ndarray], stream_rates: Sequence[float]) -> List[np.ndarray]:
+        """Host convenience for tests: streams[i] is [frames_i][C] at stream_rates[i]; streams of one bucket must
+        have equal length.  Returns the stereo outputs in the caller's order."""
+        out: List[Optional[np.ndarray]] = [None] * len(streams)
+        for rate, b in self.buckets.items():
+            x = np.stack([np.asarray(streams[i], dtype=np.float32) for i in b.stream_ids])
+            y = b.spatializer.process(x)
+            for k, i in enumerate(b.stream_ids):
+                out[i] = y[k]
+        return out  # type: ignore[return-value]
+
+    def reset(self) -> None:
+        for b in self.buckets.values():
+            b.spatializer.reset()

@@ -159,6 +159,8 @@ __global__ void __launch_bounds__(kThreads) aw_part_cmac_ifft_kernel(TileParams 
 // batches of two pairs at run time: more than 8 channels, where full unrolling only spills).
 #define AW_FOR_EACH_VEC(X) X(2, 1) X(4, 2) X(8, 4) X(12, 0) X(16, 0)
 #define AW_FOR_EACH_GEN(X) X(1) X(2) X(3) X(4) X(0)
+// boundary tiles of the common layouts keep whole-frame vector loads (history / zero-page selects per frame)
+#define AW_FOR_EACH_BVEC(X) X(2, 1) X(4, 2) X(8, 4)
 
 hipError_t prepare_kernels() {
     hipError_t e = hipSuccess;
@@ -177,8 +179,14 @@ hipError_t prepare_kernels() {
     if (e == hipSuccess)                                                                             \
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<0, NP, false>),  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+#define AW_SET_BVEC(CS, NP)                                                                          \
+    if (e == hipSuccess)                                                                             \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<CS, NP, false>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     AW_FOR_EACH_VEC(AW_SET_VEC)
     AW_FOR_EACH_GEN(AW_SET_GEN)
+    AW_FOR_EACH_BVEC(AW_SET_BVEC)
+#undef AW_SET_BVEC
 #undef AW_SET_VEC
 #undef AW_SET_GEN
     if (e == hipSuccess)
@@ -222,6 +230,12 @@ static void launch_vec(const TileParams &p, long long n_tiles, hipStream_t strea
 
 static void launch_gen(const TileParams &p, long long n_tiles, hipStream_t stream) {
     const dim3 grid = persistent_grid(n_tiles), block(kThreads);
+    switch (p.n_channels) {
+#define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_fused_ols_kernel<CS, NP, false>), grid, block, kLdsBytes, stream, p, n_tiles); return;
+        AW_FOR_EACH_BVEC(AW_CASE)
+#undef AW_CASE
+        default: break;
+    }
     const int np = p.n_pairs <= 4 ? p.n_pairs : 0;
     switch (np) {
 #define AW_CASE(NP) case NP: hipLaunchKernelGGL((aw_fused_ols_kernel<0, NP, false>), grid, block, kLdsBytes, stream, p, n_tiles); break;
@@ -232,7 +246,8 @@ static void launch_gen(const TileParams &p, long long n_tiles, hipStream_t strea
 }
 
 // Interior tiles (window entirely inside the call's input) and boundary tiles are separate launches.
-hipError_t launch_fused_ols(const TileParams &p_in, int n_streams, hipStream_t stream) {
+hipError_t launch_fused_ols(const TileParams &p_in, int n_streams, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
+                            long long *dominant_tiles) {
     TileParams p = p_in;
     // tile i is interior iff  i*hop - hist_len >= 0  and  i*hop - hist_len + N <= frames
     long long lo = (p.hist_len + p.hop - 1) / p.hop;
@@ -245,11 +260,18 @@ hipError_t launch_fused_ols(const TileParams &p_in, int n_streams, hipStream_t s
     const long long n_int = (long long)n_streams * (hi - lo);
     const long long n_bnd = (long long)n_streams * (p.tiles_per_stream - (hi - lo));
     if (n_int > 0x7fffffffLL || n_bnd > 0x7fffffffLL) return hipErrorInvalidValue;
+    // the events bracket the DOMINANT launch only (interior tiles when the layout has a vector variant)
+    const bool dom_int = n_int > 0;
+    if (dominant_tiles) *dominant_tiles = dom_int ? n_int : n_bnd;
+    if (ev0 && dom_int) (void)hipEventRecord(ev0, stream);
     if (n_int > 0) launch_vec(p, n_int, stream);
+    if (ev1 && dom_int) (void)hipEventRecord(ev1, stream);
     if (n_bnd > 0) {
         TileParams pb = p;
         pb.dbg = nullptr;                 // diagnostic stamps describe the interior launch only
+        if (ev0 && !dom_int) (void)hipEventRecord(ev0, stream);
         launch_gen(pb, n_bnd, stream);
+        if (ev1 && !dom_int) (void)hipEventRecord(ev1, stream);
     }
     return hipGetLastError();
 }

@@ -10,7 +10,10 @@ namespace awk {
 
 // Fused overlap-save spatializer: one workgroup per (stream, tile).  Returns hipSuccess or the
 // launch error.  `n_streams * p.tiles_per_stream` workgroups of kThreads.
-hipError_t launch_fused_ols(const TileParams &p, int n_streams, hipStream_t stream);
+// ev0/ev1 (optional) are recorded around the dominant launch only: the interior tiles when the
+// channel count has a vectorised variant, else the single generic launch; *dominant_tiles = its tile count.
+hipError_t launch_fused_ols(const TileParams &p, int n_streams, hipStream_t stream, hipEvent_t ev0 = nullptr,
+                            hipEvent_t ev1 = nullptr, long long *dominant_tiles = nullptr);
 const char *fused_ols_kernel_name(int n_channels);
 
 // Partitioned (long-HRIR) path: window spectra -> scratch, then CMAC over partitions + inverse.

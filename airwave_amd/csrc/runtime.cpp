@@ -283,6 +283,7 @@ int64_t aw_spatializer_info(const aw_spatializer *sp, int32_t what) {
         case 2: return sp->partitions;
         case 3: return sp->path;
         case 4: return sp->hist_len;
+        case 5: return sp->dominant_frames;   // output frames covered by the launch aw_spatializer_kernel_time() times (last call)
         default: return -1;
     }
 }
@@ -372,15 +373,12 @@ static aw_status sp_process_fused(aw_spatializer *sp, const float *in, float *ou
     }
 #endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (sp->profiling) {
-        e0 = sp_get_event(sp); e1 = sp_get_event(sp);
-        AW_HIP_TRY(hipEventRecord(e0, sp->ctx->stream));
-    }
-    AW_HIP_TRY(awk::launch_fused_ols(p, sp->n_streams, sp->ctx->stream));
-    if (sp->profiling) {
-        AW_HIP_TRY(hipEventRecord(e1, sp->ctx->stream));
-        sp->pending.emplace_back(e0, e1);
-    }
+    if (sp->profiling) { e0 = sp_get_event(sp); e1 = sp_get_event(sp); }
+    long long dom_tiles = 0;
+    AW_HIP_TRY(awk::launch_fused_ols(p, sp->n_streams, sp->ctx->stream, e0, e1, &dom_tiles));
+    // output frames the timed launch produced (tiles x hop, the last tile of a stream may be short)
+    sp->dominant_frames = std::min<long long>(dom_tiles * (long long)sp->hop, (long long)sp->n_streams * frames);
+    if (sp->profiling) sp->pending.emplace_back(e0, e1);
     return AW_OK;
 }
 
@@ -423,6 +421,7 @@ static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, flo
             AW_HIP_TRY(hipEventRecord(e1, sp->ctx->stream));
             sp->pending.emplace_back(e0, e1);
         }
+        sp->dominant_frames = (long long)ns * frames;
     }
     return AW_OK;
 }

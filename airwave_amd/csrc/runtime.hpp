@@ -61,6 +61,7 @@ struct aw_spatializer {
     hipEvent_t k0 = nullptr, k1 = nullptr;
     double kernel_ms_sum = 0.0;
     int kernel_launches = 0;
+    long long dominant_frames = 0;         // output frames produced by the timed (dominant) launch of the last call
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // recorded, not yet read
     std::vector<hipEvent_t> event_pool;
 };

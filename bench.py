@@ -30,7 +30,15 @@ WORKLOADS = {
                  desc="cfg1: stereo 48 kHz -> NeutralSH1.0, 1 stream (plumbing)"),
     "cfg2": dict(streams=128, channels=8, hrir="RoomSH1.0.wav", taps=4320, seconds=10.0,
                  desc="cfg2: 7.1 (8ch) 48 kHz -> RoomSH1.0 14-track HeSuVi HRIR, 128-stream batch x 10 s"),
+    # the other BASELINE configs (parity-test cases first; benched on request: --workload cfg3|cfg4|cfg5)
+    "cfg3": dict(streams=1024, channels=7, hrir=None, taps=32768, seconds=10.0,
+                 desc="cfg3: 7 speakers [FL,FR,FC,BL,BR,SL,SR] 48 kHz -> synthetic 14 x 32768-tap HRIR (seed 1234), 1024-stream batch x 10 s"),
+    "cfg4": dict(streams=512, channels=7, hrir="StageSH1.0.wav", taps=4320, seconds=10.0, rates=[96000], eq=True,
+                 desc="cfg4: 7 speakers 96 kHz -> StageSH1.0 resampled x2 (8640 taps) + 10-band parametric EQ, 512 streams/GPU x 10 s"),
+    "cfg5": dict(streams=1024, channels=7, hrir="StageSH1.0.wav", taps=4320, seconds=10.0, rates=[44100, 48000, 96000],
+                 desc="cfg5: 7 speakers, streams split evenly over 44.1/48/96 kHz -> StageSH1.0 resampled per rate, 1024 streams/GPU x 10 s"),
 }
+SPEAKERS7 = ["FL", "FR", "FC", "BL", "BR", "SL", "SR"]
 
 
 def load_hrir(name: str, taps: int):
@@ -38,8 +46,8 @@ def load_hrir(name: str, taps: int):
     data independent).  Read through the product's own WAV loader."""
     import numpy as np
     import airwave_amd as aw
-    path = os.path.join(ROOT, "tests", "golden", "hrtf", name)
-    if os.path.exists(path):
+    path = os.path.join(ROOT, "tests", "golden", "hrtf", name) if name else ""
+    if name and os.path.exists(path):
         w = aw.WAVLoader.load(path)
         return w.audio_data, f"fixture {name}"
     rng = np.random.default_rng(1234)
@@ -66,7 +74,7 @@ def measured_traffic(S: int, F: int, C: int):
     return best
 
 
-def cpu_baseline(x_host, tracks, lt, rt, frames: int):
+def cpu_baseline(x_host, tracks, lt, rt, frames: int, eq_definition=None, rate: float = 48000.0):
     """Times the CPU oracle (float32 restatement of the reference algorithm: B=512, one engine per
     (channel, ear), per-ear forward FFTs) on the host cores, on a bounded sample of the same input."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -75,7 +83,12 @@ def cpu_baseline(x_host, tracks, lt, rt, frames: int):
     threads = max(1, min(cores, x_host.shape[0]))
     orc.spatialize_f32(x_host[:1, :4096], tracks, lt, rt, threads=1)   # warm the library / page in
     t0 = time.perf_counter()
-    orc.spatialize_f32(x_host, tracks, lt, rt, threads=threads)
+    y = orc.spatialize_f32(x_host, tracks, lt, rt, threads=threads)
+    if eq_definition is not None:      # the EQ that follows the spatializer in cfg 4 (one state per stream, sequential recurrence)
+        od = orc.EqualizerDefinition(eq_definition.preampDB, [orc.EqualizerFilter(f.sourceLine, f.sourceNumber, f.isEnabled, f.type,
+                                                                                    f.frequencyHz, f.gainDB, f.q) for f in eq_definition.filters])
+        for s in range(y.shape[0]):
+            orc.eq_prepare(od, rate).process(y[s, :, 0], y[s, :, 1])
     dt = time.perf_counter() - t0
     return {
         "value": x_host.shape[0] * frames / dt, "unit": "stereo frames/s", "cores": threads, "kind": "port",
@@ -89,8 +102,8 @@ def cpu_baseline(x_host, tracks, lt, rt, frames: int):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="default 20 (cfg1/cfg2), 3 (cfg3-5)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 3 (cfg1/cfg2), 1 (cfg3-5)")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--seconds", type=float, default=0.0, help="override seconds per stream")
@@ -120,51 +133,88 @@ def main() -> None:
     wl = dict(WORKLOADS[args.workload])
     S = args.streams or wl["streams"]
     C = wl["channels"]
-    rate = 48000
-    F = int(round((args.seconds or wl["seconds"]) * rate))
+    seconds = args.seconds or wl["seconds"]
+    rates = wl.get("rates", [48000])
     tracks, hrir_src = load_hrir(wl["hrir"], wl["taps"])
+    if args.steps is None:
+        args.steps = 20 if args.workload in ("cfg1", "cfg2") else 3
+    if args.warmup is None:
+        args.warmup = 3 if args.workload in ("cfg1", "cfg2") else 1
 
     ctx = aw.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-    layout = aw.InputLayout.detect(C)
-    lt, rt = aw.HRIRChannelMap.hesuvi14Channel(layout).resolve(layout, tracks.shape[0])
-    sp = aw.Spatializer(aw.HRIR(tracks, float(rate), ctx=ctx), lt, rt, n_streams=S, ctx=ctx)
-
-    x = torch.empty((S, F, C), dtype=torch.float32, device="cuda")
-    y = torch.empty((S, F, 2), dtype=torch.float32, device="cuda")
+    layout = aw.InputLayout.detect(C) if C != 7 else aw.InputLayout(SPEAKERS7, "7 speakers")
     first_stream, _ = weak_shard(S, world, rank)                                  # stream ids are global
-    ctx.synth_fill(x.data_ptr(), S, F, C, seed=0xA17AE, first_stream=first_stream)
-    torch.cuda.synchronize()
 
-    def step():
-        sp.process_device(x.data_ptr(), y.data_ptr(), F)
+    # One leg per sample rate (cfg 5 buckets streams by rate; every other workload has one leg).
+    stream_rates = [rates[i * len(rates) // S] for i in range(S)] if len(rates) > 1 else [rates[0]] * S
+    batch = aw.MixedRateBatch(tracks, 48000.0, layout, stream_rates, ctx=ctx)
+    eq_def = None
+    if wl.get("eq"):
+        eq_def = aw.EqualizerAPOParser.parse(open(os.path.join(ROOT, "tests", "golden", "eq", "CCA CRA ParametricEq.txt"), "rb").read(), "CCA CRA ParametricEq.txt")
+    legs = []
+    for rate, b in batch.buckets.items():
+        n, F = len(b.stream_ids), int(round(seconds * rate))
+        x = torch.empty((n, F, C), dtype=torch.float32, device="cuda")
+        y = torch.empty((n, F, 2), dtype=torch.float32, device="cuda")
+        ctx.synth_fill(x.data_ptr(), n, F, C, seed=0xA17AE, first_stream=first_stream + b.stream_ids[0])
+        eq = aw.ParametricEqualizerState(eq_def, float(rate), n_streams=n, ctx=ctx) if eq_def is not None else None
+        legs.append(dict(rate=rate, n=n, F=F, x=x, y=y, sp=b.spatializer, eq=eq, taps=b.hrir_taps))
+    torch.cuda.synchronize()
+    eq_events = []
+
+    def step(timed=False):
+        for g in legs:
+            g["sp"].process_device(g["x"].data_ptr(), g["y"].data_ptr(), g["F"])
+            if g["eq"] is not None:
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                g["eq"].process_device(g["y"].data_ptr(), g["y"].data_ptr(), g["F"])     # in place, on the same stream
+                if timed:
+                    e1.record()
+                    eq_events.append((e0, e1))
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    sp.set_profiling(True)            # HIP events around the dominant kernel, on the launch stream
+    for g in legs:
+        g["sp"].set_profiling(True)   # HIP events around the dominant kernel, on the launch stream
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(timed=True)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-    n_launch, kernel_ms, kernel_name = sp.kernel_time()
-    sp.set_profiling(False)
+    frames_step = sum(g["n"] * g["F"] for g in legs)
 
     # RCCL over xGMI: the only collective of the run (sum of frames, max of elapsed)
-    frames_total, elapsed_max, _ = aggregate_throughput(float(S) * F * args.steps, elapsed, device="cuda")
+    frames_total, elapsed_max, _ = aggregate_throughput(float(frames_step) * args.steps, elapsed, device="cuda")
 
     if rank == 0:
-        finite = bool(torch.isfinite(y[:, -4096:]).all().item())
         bytes_per_frame = 4 * C + 8                      # PCM in + stereo out
-        alg_bytes = bytes_per_frame * S * F              # per launch of the dominant kernel
+        kernel_ms, dom_frames, names, paths = 0.0, 0, [], []
+        for g in legs:
+            n_launch, ms, name = g["sp"].kernel_time()
+            g["sp"].set_profiling(False)
+            info = g["sp"].info()
+            # a partitioned call may be chunked over streams: ms is the average per chunk launch
+            launches_per_step = max(1, round(n_launch / args.steps))
+            kernel_ms += ms * launches_per_step
+            dom_frames += info["dominant_frames"] * launches_per_step if info["path"] == 0 else g["n"] * g["F"]
+            names.append(name)
+            paths.append({"rate": g["rate"], "streams": g["n"], "frames": g["F"], "taps": g["taps"], "fft": info["fft"], "hop": info["hop"],
+                          "partitions": info["partitions"], "path": "fused overlap-save" if info["path"] == 0 else "partitioned"})
+        finite = all(bool(torch.isfinite(g["y"][:, -4096:]).all().item()) for g in legs)
+        # algorithmic bytes of the frames the timed (dominant) launches produced
+        alg_bytes = bytes_per_frame * dom_frames
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        info = sp.info()
-        tr = measured_traffic(S, F, C)
+        g0 = legs[0]
+        tr = measured_traffic(g0["n"], g0["F"], C) if len(legs) == 1 else None
+        lt, rt = batch.left_track, batch.right_track
         result = {
             "metric": "stereo frames/sec @48kHz, 14ch HeSuVi HRIR",
             "value": frames_total / elapsed_max,
@@ -176,27 +226,34 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if eq_def is None else "f32 (convolution) + f64 (EQ)",
             "data": f"synthetic U(-0.5,0.5) counter RNG seed 0xA17AE+stream, resident in HBM; HRIR: {hrir_src}",
             "config": {
-                "workload": wl["desc"], "streams_per_gpu": S, "frames_per_stream": F, "sample_rate": rate,
-                "input_channels": C, "hrir_tracks": int(tracks.shape[0]), "hrir_taps": int(tracks.shape[1]),
-                "convolutions_per_stream": int(2 * (lt >= 0).sum()), "parallelism": f"streams sharded x{world}, no data-path collective",
-                "fft": info["fft"], "hop": info["hop"], "path": "fused overlap-save" if info["path"] == 0 else "partitioned",
+                "workload": wl["desc"], "streams_per_gpu": S, "frames_per_stream": g0["F"], "sample_rate": g0["rate"],
+                "input_channels": C, "hrir_tracks": int(tracks.shape[0]), "hrir_taps": g0["taps"],
+                "convolutions_per_stream": int((lt >= 0).sum() + (rt >= 0).sum()), "parallelism": f"streams sharded x{world}, no data-path collective",
+                "fft": paths[0]["fft"], "hop": paths[0]["hop"], "path": paths[0]["path"], "legs": paths,
                 "outputs_finite": finite,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": tr[1]["total"] if tr else None,
                 "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC)", "traffic_source": os.path.relpath(tr[0], ROOT) if tr else None,
-                "kernel": kernel_name, "kernel_avg_ms": kernel_ms, "launches_timed": n_launch,
+                "kernel": ", ".join(sorted(set(names))), "kernel_avg_ms": kernel_ms, "launches_timed": args.steps,
                 "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_frame": bytes_per_frame,
+                "frames_per_launch": dom_frames,
             },
         }
+        if eq_events:
+            eq_ms = sum(a.elapsed_time(b) for a, b in eq_events) / args.steps
+            result["roofline"]["eq_kernel_ms_per_step"] = eq_ms
+            result["roofline"]["eq_achieved_GBs"] = 16.0 * frames_step / (eq_ms * 1e-3) / 1e9      # 8 B in + 8 B out per frame
         if not args.no_cpu_baseline:
-            ns = max(1, min(S, args.cpu_sample_streams))
-            x_host = x[:ns].cpu().numpy()
-            result["cpu_baseline"] = cpu_baseline(x_host, tracks, lt, rt, F)
+            ns = max(1, min(g0["n"], args.cpu_sample_streams))
+            Fc = g0["F"] if args.workload in ("cfg1", "cfg2") else min(g0["F"], int(g0["rate"]))     # long-tap configs: 1 s per stream
+            x_host = g0["x"][:ns, :Fc].cpu().numpy()
+            tr0 = aw.resample_tracks(tracks, 48000.0, float(g0["rate"]))
+            result["cpu_baseline"] = cpu_baseline(x_host, tr0, lt, rt, Fc, eq_definition=eq_def, rate=float(g0["rate"]))
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -1,0 +1,49 @@
+"""cfg 5 host row: streams bucketed by sample rate, one renderer network per rate with the HRIR resampled to
+that rate (HRIRManager.swift:389-403).  CPU part: bucketing + resampled-HRIR assembly against the oracle's
+restatement; GPU part: every bucket's output against the float64 truth on the resampled HRIR."""
+import os
+
+import numpy as np
+import pytest
+
+import airwave_amd as aw
+
+
+def test_bucketing_is_stable_and_complete():
+    rates = [48000, 44100, 48000, 96000, 44100, 48000]
+    b = aw.bucket_by_rate(rates)
+    assert list(b) == [48000.0, 44100.0, 96000.0]
+    assert b[48000.0] == [0, 2, 5] and b[44100.0] == [1, 4] and b[96000.0] == [3]
+    assert sorted(i for ids in b.values() for i in ids) == list(range(len(rates)))
+
+
+def test_resampled_tracks_match_oracle(oracle, golden_dir):
+    w = oracle.wav_load(os.path.join(golden_dir, "hrtf", "StageSH1.0.wav"))
+    tr = np.asarray(w.audio_data)
+    for rate in (44100.0, 48000.0, 96000.0):
+        got = aw.resample_tracks(tr, 48000.0, rate)
+        exp = np.stack([oracle.resample_intended(t, 48000.0, rate) for t in tr]) if rate != 48000.0 else tr
+        assert got.shape == exp.shape and got.shape[1] == {44100.0: 3968, 48000.0: 4320, 96000.0: 8640}[rate]
+        assert np.max(np.abs(got - exp)) <= 1e-7
+
+
+@pytest.mark.gpu
+def test_mixed_rate_batch_matches_truth_per_bucket(oracle, golden_dir):
+    w = oracle.wav_load(os.path.join(golden_dir, "hrtf", "StageSH1.0.wav"))
+    tr = np.asarray(w.audio_data)
+    layout = aw.InputLayout(["FL", "FR", "FC", "BL", "BR", "SL", "SR"], "7 speakers")
+    rates = [44100.0, 48000.0, 96000.0, 48000.0, 96000.0, 44100.0]
+    batch = aw.MixedRateBatch(tr, 48000.0, layout, rates)
+    assert {r: (b.hrir_taps, b.spatializer.info()["path"]) for r, b in batch.buckets.items()} == {
+        44100.0: (3968, 0), 48000.0: (4320, 0), 96000.0: (8640, 1)}
+    frames = {44100.0: 9000, 48000.0: 10000, 96000.0: 12000}
+    xs = [oracle.synth_input(1, frames[r], 7, seed=100 + i)[0] for i, r in enumerate(rates)]
+    ys = batch.process(xs, rates)
+    spk = ["FL", "FR", "FC", "BL", "BR", "SL", "SR"]
+    for i, r in enumerate(rates):
+        tracks, lt, rt = oracle.assemble_tracks(w, spk, target_rate=r)      # the oracle resamples the HRIR itself
+        truth = oracle.spatialize_f64(xs[i], tracks, lt, rt)
+        assert oracle.peak_rel_error(ys[i], truth) < 1e-5, (i, r)
+    batch.reset()
+    again = batch.process(xs, rates)
+    assert all(np.array_equal(a, b) for a, b in zip(again, ys))
