@@ -81,6 +81,11 @@ struct GpuCtx {
     }
     // Scheduling fence (no instruction): keeps hipcc from interleaving the two rows' butterflies,
     // which doubles their temporaries at the register-pressure peak.
+    // unconditional scheduling fence (bounds how far loads are hoisted)
+    __device__ __forceinline__ void sched_fence_hard() const {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
     __device__ __forceinline__ void sched_fence() const {
 #if AW_SCHED_FENCE
         __builtin_amdgcn_sched_barrier(0);
@@ -149,7 +154,8 @@ __global__ void __launch_bounds__(kThreads) aw_part_cmac_ifft_kernel(TileParams 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
     const long long id = xcd_remap((long long)blockIdx.x, nwg);
-    tile_part_cmac_inverse<GpuCtx>(ctx, p, id / p.n_blocks, (int)(id % p.n_blocks));
+    const int groups = (p.n_blocks + kPartBlocks - 1) / kPartBlocks;
+    tile_part_cmac_inverse<GpuCtx>(ctx, p, id / groups, (int)(id % groups) * kPartBlocks);
 }
 
 // Kernel variants.  Vectorised interior kernels <CS, NP, true> exist for the channel counts whose
@@ -288,7 +294,7 @@ hipError_t launch_part_forward(const TileParams &p, int n_streams, hipStream_t s
 }
 
 hipError_t launch_part_cmac_ifft(const TileParams &p, int n_streams, hipStream_t stream) {
-    const long long nwg = (long long)n_streams * p.n_blocks;
+    const long long nwg = (long long)n_streams * ((p.n_blocks + kPartBlocks - 1) / kPartBlocks);
     if (nwg <= 0) return hipSuccess;
     if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(aw_part_cmac_ifft_kernel, dim3((unsigned)nwg), dim3(kThreads), kLdsBytes, stream, p, nwg);

@@ -510,11 +510,22 @@ AW_HD void tile_part_forward(Ctx &ctx, const TileParams &p, long long stream, in
     }
 }
 
-// Kernel 2: one output block: W = sum over partitions and pairs, inverse, store the last hop frames.
+// Kernel 2: kPartBlocks consecutive output blocks of one stream per workgroup:
+//   W_b = sum over partitions q and pairs of  X_{b-q} . H_q ,  inverse, store the last hop frames.
+// With kPartBlocks > 1 the blocks share every table entry (held in registers) and P-1 of their P input
+// windows; measured slower than one block per workgroup (see AW_PART_BLOCKS), kept as a tuning knob.
+#ifndef AW_PART_FENCE
+#define AW_PART_FENCE 0
+#endif
+#ifndef AW_PART_BLOCKS
+#define AW_PART_BLOCKS 1      // measured on cfg 4 / cfg 3: 1 block 11.3 / 27.3 ms, 2: 15.8 / 41.3, 3: 23.2 / 61.8, 4: 13.7 / 34.1 —
+#endif                        // the kernel is load-latency bound at 8 waves/CU, so serialising blocks in one workgroup only adds round trips
+constexpr int kPartBlocks = AW_PART_BLOCKS;
+
 template <class Ctx>
-AW_HD void tile_part_cmac_inverse(Ctx &ctx, const TileParams &p, long long stream, int block) {
+AW_HD void tile_part_cmac_inverse(Ctx &ctx, const TileParams &p, long long stream, int block0) {
     const int t = ctx.tid();
-    const int lane = ctx.lane(), wave = ctx.wave();
+    const int lane0 = ctx.lane(), wave = ctx.wave();
     cf *buf0 = ctx.lds();
     cf *twa = buf0 + 2 * kBufElems;
     cf *twb = twa + kTwaElems;
@@ -523,40 +534,63 @@ AW_HD void tile_part_cmac_inverse(Ctx &ctx, const TileParams &p, long long strea
     if (t < kTwbElems) twb[t] = p.twb[t];
     ctx.barrier();                                        // twiddles visible (the forward path has its own barrier)
     const int n_windows = p.n_blocks + p.partitions - 1;
+    // A trailing odd block gets a phantom partner (branch-free: a uniform branch here costs ~70 spilled
+    // VGPRs): its windows are clamped to valid ones and every frame it would store lies past the call.
 
-    cf wacc[2][8];
+    cf wacc[kPartBlocks][2][8];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int b = 0; b < kPartBlocks; ++b)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) wacc[s][i] = mk(0.f, 0.f);
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wacc[b][s][i] = mk(0.f, 0.f);
 
     for (int q = 0; q < p.partitions; ++q) {
-        const int widx = block + (p.partitions - 1) - q;              // window that partition q reads
-        const cf *spec_w = p.spec + ((stream * n_windows + widx) * p.n_pairs) * (long long)kN;
         for (int pair = 0; pair < p.n_pairs; ++pair) {
-            const cf *zs = spec_w + (long long)pair * kN;
             const cf2 *tab = p.tab + ((long long)q * p.n_pairs + pair) * kN;
+            // per-iteration opaque lane: keeps the ~40 lane-dependent 64-bit offsets from being hoisted out
+            // of the (q, pair) loop and held live across it (105 spilled VGPRs otherwise)
+            const int lane = ctx.opaque_i(lane0);
+            // one row at a time: 8 table entries in registers, applied to both blocks; the fences keep
+            // hipcc from hoisting every load of the (q, pair) step to the top (161 spilled VGPRs without them)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int k1 = wave_row(wave, s);
                 const int pk1 = (16 - k1) & 15;                       // partner row
                 const int bidx = 511 - lane + (k1 == 0 ? 1 : 0);
+                cf2 tb[8];
 #pragma unroll
-                for (int kc = 0; kc < 8; ++kc) {
-                    int idx = bidx - 64 * kc;
-                    if (kc == 0) idx &= 511;
-                    const cf z = zs[k1 * kSub + lane + 64 * kc];
-                    const cf zp = zs[pk1 * kSub + idx];
-                    const cf2 ab = tab[k1 * kSub + lane + 64 * kc];
-                    wacc[s][kc] = cfma(z, ab.a, wacc[s][kc]);
-                    wacc[s][kc] = cfmac(zp, ab.b, wacc[s][kc]);
+                for (int kc = 0; kc < 8; ++kc) tb[kc] = tab[k1 * kSub + lane + 64 * kc];
+#pragma unroll
+                for (int b = 0; b < kPartBlocks; ++b) {
+                    int widx = block0 + b + (p.partitions - 1) - q;            // window that partition q reads for block b
+                    widx = widx < n_windows ? widx : n_windows - 1;
+                    const cf *zs = p.spec + (((stream * n_windows + widx) * p.n_pairs) + pair) * (long long)kN;
+                    cf z[8], zp[8];
+#pragma unroll
+                    for (int kc = 0; kc < 8; ++kc) {
+                        int idx = bidx - 64 * kc;
+                        if (kc == 0) idx &= 511;
+                        z[kc] = zs[k1 * kSub + lane + 64 * kc];
+                        zp[kc] = zs[pk1 * kSub + idx];
+                    }
+#pragma unroll
+                    for (int kc = 0; kc < 8; ++kc) {
+                        wacc[b][s][kc] = cfma(z[kc], tb[kc].a, wacc[b][s][kc]);
+                        wacc[b][s][kc] = cfmac(zp[kc], tb[kc].b, wacc[b][s][kc]);
+                    }
+                    if (AW_PART_FENCE) ctx.sched_fence_hard();
                 }
             }
         }
     }
-    const long long f0 = ((long long)block - 1) * p.hop;             // window of block b: frames [(b-1)B, (b+1)B)
-    tile_inverse_rows(ctx, wacc, buf0, twa, twb);
-    tile_inverse_final(ctx, p, buf0, w1, t, stream, f0, p.first_valid);
+#pragma unroll
+    for (int b = 0; b < kPartBlocks; ++b) {
+        if (b > 0) ctx.barrier();                                     // the previous block's final exchange has been read
+        const long long f0 = ((long long)(block0 + b) - 1) * p.hop;  // window of block b: frames [(b-1)B, (b+1)B)
+        tile_inverse_rows(ctx, wacc[b], buf0, twa, twb);
+        tile_inverse_final(ctx, p, buf0, w1, t, stream, f0, p.first_valid);
+    }
 }
 
 }  // namespace awk

@@ -41,6 +41,7 @@ struct EmuCtx {
     int opaque_i(int v) const { return v; }
     void stamp(int) const {}
     void sched_fence() const {}
+    void sched_fence_hard() const {}
     void flush_stamps() const {}
     awk::cf ld(const awk::cf *p) const { return *p; }
     void stagger(int, int) const {}
@@ -155,7 +156,8 @@ int emu_partitioned(const float *in, float *out, const float *hist, const float 
             }
     };
     run([&](EmuCtx &ctx, int s, int w) { tile_part_forward<EmuCtx, 0>(ctx, p, s, w); }, n_windows);
-    run([&](EmuCtx &ctx, int s, int b) { tile_part_cmac_inverse<EmuCtx>(ctx, p, s, b); }, p.n_blocks);
+    run([&](EmuCtx &ctx, int s, int g) { tile_part_cmac_inverse<EmuCtx>(ctx, p, s, g * kPartBlocks); },
+        (p.n_blocks + kPartBlocks - 1) / kPartBlocks);
     return 0;
 }
 
