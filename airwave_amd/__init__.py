@@ -15,6 +15,7 @@ from .api import (  # noqa: E402
 )
 
 from .batching import MixedRateBatch, RateBucket, bucket_by_rate, resample_tracks  # noqa: E402
+from .graph import AudioEffectGraph, AudioEffectPreparationResult, AudioEffectWarning  # noqa: E402
 from .eq import (  # noqa: E402
     BiquadCoefficientBuilder, BiquadCoefficientError, EqualizerAPOParser, EqualizerAudioEffectError, EqualizerDefinition,
     EqualizerFilter, EqualizerParseError, EqualizerRuntimeEffect, ParametricEqualizerPreparationError,
@@ -22,6 +23,7 @@ from .eq import (  # noqa: E402
 )
 
 __all__ = [
+    "AudioEffectGraph", "AudioEffectPreparationResult", "AudioEffectWarning",
     "MixedRateBatch", "RateBucket", "bucket_by_rate", "resample_tracks",
     "BiquadCoefficientBuilder", "BiquadCoefficientError", "EqualizerAPOParser", "EqualizerAudioEffectError",
     "EqualizerDefinition", "EqualizerFilter", "EqualizerParseError", "EqualizerRuntimeEffect",

@@ -89,6 +89,7 @@ SIGNATURES = {
     "aw_biquad_make": (_I32, [_I32, _D, _D, _D, _D, ctypes.POINTER(ctypes.c_double), c_int32_p]),
     "aw_eq_definition_create": (_I32, [_D, c_void_pp]),
     "aw_eq_definition_add_filter": (_I32, [_V, _I32, _I32, _D, _D, _D]),
+    "aw_eq_definition_set_source": (_I32, [_V, _I32, _I32, _I64]),
     "aw_eq_definition_destroy": (None, [_V]),
     "aw_eq_definition_preamp_db": (_D, [_V]),
     "aw_eq_definition_filter_count": (_I32, [_V]),
@@ -122,7 +123,7 @@ def load() -> ctypes.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -m airwave_amd.build` (hipcc, gfx950). "
+            f"{LIB_PATH} is missing: build it with `python airwave_amd/build.py` (hipcc, gfx950). "
             "airwave_amd has no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():

@@ -1,6 +1,6 @@
 """Builds airwave_amd/libairwave_hip.so for gfx950 with hipcc (no torch, no cmake).
 
-    python -m airwave_amd.build [--force]
+    python airwave_amd/build.py [--force]      (run as a script: importing the package needs the built library)
 
 hipcc cross-compiles without a GPU; the .so stays in-tree (git-ignored) so it travels with the
 repository snapshot to the GPU box.

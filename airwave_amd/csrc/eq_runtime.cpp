@@ -168,6 +168,12 @@ aw_status aw_eq_definition_add_filter(aw_eq_definition *d, int32_t enabled, int3
     d->def.filters.push_back(fl);
     return AW_OK;
 }
+aw_status aw_eq_definition_set_source(aw_eq_definition *d, int32_t i, int32_t line, int64_t number) {
+    if (!d || i < 0 || i >= (int32_t)d->def.filters.size()) return fail(AW_ERR_INVALID_ARGUMENT, "filter index out of range");
+    d->def.filters[i].source_line = line;
+    d->def.filters[i].source_number = number;
+    return AW_OK;
+}
 void aw_eq_definition_destroy(aw_eq_definition *d) { delete d; }
 double aw_eq_definition_preamp_db(const aw_eq_definition *d) { return d ? d->def.preamp_db : 0.0; }
 int32_t aw_eq_definition_filter_count(const aw_eq_definition *d) { return d ? (int32_t)d->def.filters.size() : 0; }

@@ -84,8 +84,9 @@ class EqualizerDefinition:                        # EqualizerPreset.swift:19-27
         lib = _capi.load()
         h = ctypes.c_void_p()
         _check(lib.aw_eq_definition_create(self.preampDB, ctypes.byref(h)))
-        for f in self.filters:
+        for i, f in enumerate(self.filters):
             _check(lib.aw_eq_definition_add_filter(h, int(f.isEnabled), f.type, f.frequencyHz, f.gainDB, f.q))
+            _check(lib.aw_eq_definition_set_source(h, i, f.sourceLine, -1 if f.sourceNumber is None else f.sourceNumber))
         return h
 
 

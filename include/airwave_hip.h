@@ -231,6 +231,8 @@ typedef struct aw_eq_definition aw_eq_definition;
 AW_API aw_status aw_eq_definition_create(double preamp_db, aw_eq_definition **out);
 AW_API aw_status aw_eq_definition_add_filter(aw_eq_definition *d, int32_t is_enabled, int32_t type, double frequency_hz,
                                              double gain_db, double q);
+/* EqualizerFilter.sourceLine / sourceNumber of filter `index` (defaults: index + 1, none = -1). */
+AW_API aw_status aw_eq_definition_set_source(aw_eq_definition *d, int32_t index, int32_t source_line, int64_t source_number);
 AW_API void aw_eq_definition_destroy(aw_eq_definition *d);
 AW_API double aw_eq_definition_preamp_db(const aw_eq_definition *d);
 AW_API int32_t aw_eq_definition_filter_count(const aw_eq_definition *d);
