@@ -7,7 +7,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
-_LIB = os.path.join(_HERE, "libemu.so")
+_DEFS = os.environ.get("AW_EMU_DEFINES", "").split()          # e.g. "-DAW_SUBFFT_SKEW=1": emulate a tuning variant
+_LIB = os.path.join(_HERE, "libemu.so" if not _DEFS else "libemu_variant.so")
 _SRCS = [os.path.join(_HERE, "emu_harness.cpp"), os.path.join(_ROOT, "airwave_amd/csrc/host/tables.cpp"),
          os.path.join(_ROOT, "airwave_amd/csrc/host/eq.cpp")]
 _DEPS = _SRCS + [os.path.join(_ROOT, "airwave_amd/csrc/device", f) for f in ("tile_ols.hpp", "cplx.hpp", "eq_cascade.hpp")] + [
@@ -21,8 +22,8 @@ ip = ctypes.POINTER(ctypes.c_int32)
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(d) for d in _DEPS):
-            subprocess.run(["g++", "-std=c++20", "-O2", "-pthread", "-shared", "-fPIC", "-o", _LIB] + _SRCS, check=True)
+        if _DEFS or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(d) for d in _DEPS):
+            subprocess.run(["g++", "-std=c++20", "-O2", "-pthread", "-shared", "-fPIC"] + _DEFS + ["-o", _LIB] + _SRCS, check=True)
         _lib = ctypes.CDLL(_LIB)
         _lib.emu_fused_ols.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
                                        ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int]
