@@ -150,12 +150,16 @@ __global__ void __launch_bounds__(kThreads) aw_part_forward_kernel(TileParams p,
     tile_part_forward<GpuCtx, CS>(ctx, p, id / n_windows, (int)(id % n_windows));
 }
 
-__global__ void __launch_bounds__(kThreads) aw_part_cmac_ifft_kernel(TileParams p, long long nwg) {
+// grid = (N / kCmacThreads, block groups, streams): one thread per bin of kCmacBlocks consecutive blocks
+__global__ void __launch_bounds__(kCmacThreads) aw_part_cmac_kernel(TileParams p) {
+    part_cmac_bin(p, (long long)blockIdx.z, (int)blockIdx.y * kCmacBlocks, (int)(blockIdx.x * kCmacThreads + threadIdx.x));
+}
+
+__global__ void __launch_bounds__(kThreads) aw_part_inverse_kernel(TileParams p, long long nwg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
     const long long id = xcd_remap((long long)blockIdx.x, nwg);
-    const int groups = (p.n_blocks + kPartBlocks - 1) / kPartBlocks;
-    tile_part_cmac_inverse<GpuCtx>(ctx, p, id / groups, (int)(id % groups) * kPartBlocks);
+    tile_part_inverse<GpuCtx>(ctx, p, id / p.n_blocks, (int)(id % p.n_blocks));
 }
 
 // Kernel variants.  Vectorised interior kernels <CS, NP, true> exist for the channel counts whose
@@ -202,8 +206,8 @@ hipError_t prepare_kernels() {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_forward_kernel<0>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_cmac_ifft_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_inverse_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kInvLdsBytes);
     return e;
 }
 
@@ -293,11 +297,20 @@ hipError_t launch_part_forward(const TileParams &p, int n_streams, hipStream_t s
     return hipGetLastError();
 }
 
-hipError_t launch_part_cmac_ifft(const TileParams &p, int n_streams, hipStream_t stream) {
-    const long long nwg = (long long)n_streams * ((p.n_blocks + kPartBlocks - 1) / kPartBlocks);
+hipError_t launch_part_cmac(const TileParams &p, int n_streams, hipStream_t stream) {
+    const int groups = (p.n_blocks + kCmacBlocks - 1) / kCmacBlocks;
+    if (n_streams <= 0 || groups <= 0) return hipSuccess;
+    if (groups > 65535 || n_streams > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(aw_part_cmac_kernel, dim3(kN / kCmacThreads, (unsigned)groups, (unsigned)n_streams), dim3(kCmacThreads), 0,
+                       stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_part_inverse(const TileParams &p, int n_streams, hipStream_t stream) {
+    const long long nwg = (long long)n_streams * p.n_blocks;
     if (nwg <= 0) return hipSuccess;
     if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(aw_part_cmac_ifft_kernel, dim3((unsigned)nwg), dim3(kThreads), kLdsBytes, stream, p, nwg);
+    hipLaunchKernelGGL(aw_part_inverse_kernel, dim3((unsigned)nwg), dim3(kThreads), kInvLdsBytes, stream, p, nwg);
     return hipGetLastError();
 }
 

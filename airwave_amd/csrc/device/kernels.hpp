@@ -16,9 +16,11 @@ hipError_t launch_fused_ols(const TileParams &p, int n_streams, hipStream_t stre
                             hipEvent_t ev1 = nullptr, long long *dominant_tiles = nullptr);
 const char *fused_ols_kernel_name(int n_channels);
 
-// Partitioned (long-HRIR) path: window spectra -> scratch, then CMAC over partitions + inverse.
+// Partitioned (long-HRIR) path: window spectra -> scratch; per-bin CMAC over partitions for groups of
+// consecutive blocks -> W scratch; inverse transform of every block's W.
 hipError_t launch_part_forward(const TileParams &p, int n_streams, hipStream_t stream);
-hipError_t launch_part_cmac_ifft(const TileParams &p, int n_streams, hipStream_t stream);
+hipError_t launch_part_cmac(const TileParams &p, int n_streams, hipStream_t stream);
+hipError_t launch_part_inverse(const TileParams &p, int n_streams, hipStream_t stream);
 
 // hist_new[s][i][c] <- frame (frames - hist_len + i) of (hist_old ++ in), for every stream.
 hipError_t launch_hist_update(const float *in, const float *hist_old, float *hist_new, long long frames,

@@ -79,6 +79,7 @@ struct TileParams {
     int tile_lo, tile_hi;   // tiles [tile_lo, tile_hi) of every stream are INTERIOR (window inside the input)
     // partitioned (long-HRIR) path only:
     cf *spec;               // [stream][window][pair][16][512] input-window spectra (scratch)
+    cf *wspec;              // [stream][block][16][512] accumulated output spectra W (scratch)
     int partitions;         // P = ceil(taps / hop); tables are [partition][pair][N]
     int n_blocks;           // output blocks of `hop` frames per stream in this call
     int first_valid;        // first window position that is stored (N - hop)
@@ -510,87 +511,88 @@ AW_HD void tile_part_forward(Ctx &ctx, const TileParams &p, long long stream, in
     }
 }
 
-// Kernel 2: kPartBlocks consecutive output blocks of one stream per workgroup:
-//   W_b = sum over partitions q and pairs of  X_{b-q} . H_q ,  inverse, store the last hop frames.
-// With kPartBlocks > 1 the blocks share every table entry (held in registers) and P-1 of their P input
-// windows; measured slower than one block per workgroup (see AW_PART_BLOCKS), kept as a tuning knob.
-#ifndef AW_PART_FENCE
-#define AW_PART_FENCE 0
-#endif
-#ifndef AW_PART_BLOCKS
-#define AW_PART_BLOCKS 1      // measured on cfg 4 / cfg 3: 1 block 11.3 / 27.3 ms, 2: 15.8 / 41.3, 3: 23.2 / 61.8, 4: 13.7 / 34.1 —
-#endif                        // the kernel is load-latency bound at 8 waves/CU, so serialising blocks in one workgroup only adds round trips
-constexpr int kPartBlocks = AW_PART_BLOCKS;
+// Kernel 2 (no LDS, one thread per frequency bin): W_b[k] = sum over partitions q and pairs of
+//   Z_{b-q}[k] A_q[k] + conj(Z_{b-q}[N-k]) B_q[k]      for kCmacBlocks consecutive output blocks b.
+// A thread keeps its bin's table entries of kCmacQ partitions in registers and applies them to every
+// block of the group, and the blocks share all but kCmacBlocks-1 of their input windows: per block
+// the kernel reads (R+P-1)/R windows and P/R table sets instead of P and P (R = kCmacBlocks).  All
+// loads of a (pair, partition chunk) step are independent, and without LDS the kernel runs at full
+// occupancy — the fused CMAC+inverse kernel it replaces was load-latency bound at 8 waves per CU.
+constexpr int kCmacBlocks = 4;
+constexpr int kCmacQ = 8;
+constexpr int kCmacThreads = 256;
 
-template <class Ctx>
-AW_HD void tile_part_cmac_inverse(Ctx &ctx, const TileParams &p, long long stream, int block0) {
-    const int t = ctx.tid();
-    const int lane0 = ctx.lane(), wave = ctx.wave();
-    cf *buf0 = ctx.lds();
-    cf *twa = buf0 + 2 * kBufElems;
-    cf *twb = twa + kTwaElems;
-    const cf w1 = p.tw1[t];
-    twa[t] = p.twa[t];
-    if (t < kTwbElems) twb[t] = p.twb[t];
-    ctx.barrier();                                        // twiddles visible (the forward path has its own barrier)
-    const int n_windows = p.n_blocks + p.partitions - 1;
-    // A trailing odd block gets a phantom partner (branch-free: a uniform branch here costs ~70 spilled
-    // VGPRs): its windows are clamped to valid ones and every frame it would store lies past the call.
-
-    cf wacc[kPartBlocks][2][8];
+AW_HD void part_cmac_bin(const TileParams &p, long long stream, int block0, int i) {
+    const int k1 = i >> 9, k2 = i & 511;
+    // partner bin N-k in the [k1][k2] storage order: row (16-k1)&15, column (512-k2)&511 for row 0, else 511-k2
+    const int pi = (((16 - k1) & 15) << 9) + (k1 == 0 ? ((512 - k2) & 511) : (511 - k2));
+    const int P = p.partitions;
+    const int n_windows = p.n_blocks + P - 1;
+    const int nb = p.n_blocks - block0 < kCmacBlocks ? p.n_blocks - block0 : kCmacBlocks;
+    cf w[kCmacBlocks];
 #pragma unroll
-    for (int b = 0; b < kPartBlocks; ++b)
+    for (int r = 0; r < kCmacBlocks; ++r) w[r] = mk(0.f, 0.f);
+    const cf *spec_s = p.spec + stream * (long long)n_windows * p.n_pairs * kN;
+    for (int pair = 0; pair < p.n_pairs; ++pair) {
+        for (int q0 = 0; q0 < P; q0 += kCmacQ) {
+            const int nq = P - q0 < kCmacQ ? P - q0 : kCmacQ;
+            cf2 tb[kCmacQ];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int j = 0; j < kCmacQ; ++j) {
+                const int q = q0 + (j < nq ? j : 0);                        // phantom entries re-read a valid one, never used
+                tb[j] = p.tab[((long long)q * p.n_pairs + pair) * kN + i];
+            }
+            // block r (of the group) and partition q0+j read window  block0 + r + (P-1) - (q0+j):
+            // walk the diagonals d = r - j so that both the block and the table index are compile-time
 #pragma unroll
-            for (int i = 0; i < 8; ++i) wacc[b][s][i] = mk(0.f, 0.f);
-
-    for (int q = 0; q < p.partitions; ++q) {
-        for (int pair = 0; pair < p.n_pairs; ++pair) {
-            const cf2 *tab = p.tab + ((long long)q * p.n_pairs + pair) * kN;
-            // per-iteration opaque lane: keeps the ~40 lane-dependent 64-bit offsets from being hoisted out
-            // of the (q, pair) loop and held live across it (105 spilled VGPRs otherwise)
-            const int lane = ctx.opaque_i(lane0);
-            // one row at a time: 8 table entries in registers, applied to both blocks; the fences keep
-            // hipcc from hoisting every load of the (q, pair) step to the top (161 spilled VGPRs without them)
+            for (int d = -(kCmacQ - 1); d < kCmacBlocks; ++d) {
+                const int u = d + P - 1 - q0;                                // window relative to block0
+                const bool used = (d >= -(nq - 1)) && (d <= nb - 1);        // some (r, j) on this diagonal is real (uniform)
+                if (!used) continue;
+                const cf *zs = spec_s + ((long long)(block0 + u) * p.n_pairs + pair) * kN;
+                const cf z = zs[i], zp = zs[pi];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int k1 = wave_row(wave, s);
-                const int pk1 = (16 - k1) & 15;                       // partner row
-                const int bidx = 511 - lane + (k1 == 0 ? 1 : 0);
-                cf2 tb[8];
-#pragma unroll
-                for (int kc = 0; kc < 8; ++kc) tb[kc] = tab[k1 * kSub + lane + 64 * kc];
-#pragma unroll
-                for (int b = 0; b < kPartBlocks; ++b) {
-                    int widx = block0 + b + (p.partitions - 1) - q;            // window that partition q reads for block b
-                    widx = widx < n_windows ? widx : n_windows - 1;
-                    const cf *zs = p.spec + (((stream * n_windows + widx) * p.n_pairs) + pair) * (long long)kN;
-                    cf z[8], zp[8];
-#pragma unroll
-                    for (int kc = 0; kc < 8; ++kc) {
-                        int idx = bidx - 64 * kc;
-                        if (kc == 0) idx &= 511;
-                        z[kc] = zs[k1 * kSub + lane + 64 * kc];
-                        zp[kc] = zs[pk1 * kSub + idx];
+                for (int r = 0; r < kCmacBlocks; ++r) {
+                    const int j = r - d;
+                    if (j < 0 || j >= kCmacQ) continue;                      // compile-time
+                    if (r < nb && j < nq) {
+                        w[r] = cfma(z, tb[j].a, w[r]);
+                        w[r] = cfmac(zp, tb[j].b, w[r]);
                     }
-#pragma unroll
-                    for (int kc = 0; kc < 8; ++kc) {
-                        wacc[b][s][kc] = cfma(z[kc], tb[kc].a, wacc[b][s][kc]);
-                        wacc[b][s][kc] = cfmac(zp[kc], tb[kc].b, wacc[b][s][kc]);
-                    }
-                    if (AW_PART_FENCE) ctx.sched_fence_hard();
                 }
             }
         }
     }
 #pragma unroll
-    for (int b = 0; b < kPartBlocks; ++b) {
-        if (b > 0) ctx.barrier();                                     // the previous block's final exchange has been read
-        const long long f0 = ((long long)(block0 + b) - 1) * p.hop;  // window of block b: frames [(b-1)B, (b+1)B)
-        tile_inverse_rows(ctx, wacc[b], buf0, twa, twb);
-        tile_inverse_final(ctx, p, buf0, w1, t, stream, f0, p.first_valid);
-    }
+    for (int r = 0; r < kCmacBlocks; ++r)
+        if (r < nb) p.wspec[((stream * p.n_blocks) + block0 + r) * (long long)kN + i] = w[r];
+}
+
+// Kernel 3: inverse transform of one output block's W, store the last hop frames.  One exchange
+// buffer only (78 KB of LDS: two workgroups per CU).
+constexpr int kInvLdsElems = kBufElems + kTwaElems + kTwbElems;
+constexpr int kInvLdsBytes = kInvLdsElems * 8;
+
+template <class Ctx>
+AW_HD void tile_part_inverse(Ctx &ctx, const TileParams &p, long long stream, int block) {
+    const int t = ctx.tid();
+    const int lane = ctx.lane(), wave = ctx.wave();
+    cf *buf0 = ctx.lds();
+    cf *twa = buf0 + kBufElems;
+    cf *twb = twa + kTwaElems;
+    const cf w1 = p.tw1[t];
+    twa[t] = p.twa[t];
+    if (t < kTwbElems) twb[t] = p.twb[t];
+    const cf *ws = p.wspec + ((stream * p.n_blocks) + block) * (long long)kN;
+    cf wacc[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) wacc[s][kc] = ws[wave_row(wave, s) * kSub + lane + 64 * kc];
+    ctx.barrier();                                        // twiddles visible
+    const long long f0 = ((long long)block - 1) * p.hop;  // window of block b: frames [(b-1)B, (b+1)B)
+    tile_inverse_rows(ctx, wacc, buf0, twa, twb);
+    tile_inverse_final(ctx, p, buf0, w1, t, stream, f0, p.first_valid);
 }
 
 }  // namespace awk

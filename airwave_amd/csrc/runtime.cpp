@@ -320,7 +320,7 @@ int32_t aw_spatializer_kernel_time(aw_spatializer *sp, double *avg_ms, const cha
     }
     sp->pending.clear();
     if (avg_ms) *avg_ms = sp->kernel_launches ? sp->kernel_ms_sum / sp->kernel_launches : 0.0;
-    if (kernel_name) *kernel_name = sp->path == 0 ? awk::fused_ols_kernel_name(sp->n_channels) : "aw_part_cmac_ifft_kernel";
+    if (kernel_name) *kernel_name = sp->path == 0 ? awk::fused_ols_kernel_name(sp->n_channels) : "aw_part_forward_kernel + aw_part_cmac_kernel + aw_part_inverse_kernel";
     const int n = sp->kernel_launches;
     sp->kernel_ms_sum = 0.0;
     sp->kernel_launches = 0;
@@ -386,19 +386,22 @@ static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, flo
     const int N = awk::kN, B = sp->hop, P = sp->partitions;
     const int n_blocks = (int)((frames + B - 1) / B);
     const long long n_windows = (long long)n_blocks + P - 1;
-    const size_t per_stream = (size_t)n_windows * sp->n_pairs * N;          // complex elements
+    const size_t per_stream = (size_t)n_windows * sp->n_pairs * N;          // complex elements of window spectra
+    const size_t per_stream_w = (size_t)n_blocks * N;                       // complex elements of accumulated W
     size_t budget_mb = 6144;
     if (const char *e = getenv("AW_SPEC_SCRATCH_MB")) budget_mb = (size_t)atoll(e);
-    long long chunk = (long long)((budget_mb << 20) / (per_stream * sizeof(awk::cf)));
+    long long chunk = (long long)((budget_mb << 20) / ((per_stream + per_stream_w) * sizeof(awk::cf)));
     if (chunk < 1) chunk = 1;
     if (chunk > sp->n_streams) chunk = sp->n_streams;
-    const size_t need = per_stream * (size_t)chunk;
+    if (chunk > 65535) chunk = 65535;                                       // grid.z of the CMAC launch
+    const size_t need = (per_stream + per_stream_w) * (size_t)chunk;
     if (sp->spec_capacity < need) {
         if (sp->d_spec) AW_HIP_TRY(hipFree(sp->d_spec));
         sp->d_spec = nullptr; sp->spec_capacity = 0;
         AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sp->d_spec), need * sizeof(awk::cf)));
         sp->spec_capacity = need;
     }
+    sp->dominant_frames = 0;
     for (long long s0 = 0; s0 < sp->n_streams; s0 += chunk) {
         const int ns = (int)std::min<long long>(chunk, sp->n_streams - s0);
         awk::TileParams p{};
@@ -408,15 +411,18 @@ static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, flo
         p.tab = sp->d_tab; p.tw1 = sp->ctx->d_tw1; p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb; p.zeros = sp->ctx->d_zeros;
         p.frames = frames; p.n_channels = sp->n_channels; p.n_pairs = sp->n_pairs;
         p.hop = B; p.hist_len = sp->hist_len; p.tiles_per_stream = n_blocks;
-        p.spec = sp->d_spec; p.partitions = P; p.n_blocks = n_blocks; p.first_valid = N - B;
+        p.spec = sp->d_spec; p.wspec = sp->d_spec + per_stream * (size_t)chunk;
+        p.partitions = P; p.n_blocks = n_blocks; p.first_valid = N - B;
         p.stagger = 0; p.dbg = nullptr;
-        AW_HIP_TRY(awk::launch_part_forward(p, ns, sp->ctx->stream));
+        // the timed unit of this path is the whole three-kernel pipeline of one stream chunk
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (sp->profiling) {
             e0 = sp_get_event(sp); e1 = sp_get_event(sp);
             AW_HIP_TRY(hipEventRecord(e0, sp->ctx->stream));
         }
-        AW_HIP_TRY(awk::launch_part_cmac_ifft(p, ns, sp->ctx->stream));
+        AW_HIP_TRY(awk::launch_part_forward(p, ns, sp->ctx->stream));
+        AW_HIP_TRY(awk::launch_part_cmac(p, ns, sp->ctx->stream));
+        AW_HIP_TRY(awk::launch_part_inverse(p, ns, sp->ctx->stream));
         if (sp->profiling) {
             AW_HIP_TRY(hipEventRecord(e1, sp->ctx->stream));
             sp->pending.emplace_back(e0, e1);

@@ -156,8 +156,12 @@ int emu_partitioned(const float *in, float *out, const float *hist, const float 
             }
     };
     run([&](EmuCtx &ctx, int s, int w) { tile_part_forward<EmuCtx, 0>(ctx, p, s, w); }, n_windows);
-    run([&](EmuCtx &ctx, int s, int g) { tile_part_cmac_inverse<EmuCtx>(ctx, p, s, g * kPartBlocks); },
-        (p.n_blocks + kPartBlocks - 1) / kPartBlocks);
+    std::vector<cf> wspec((size_t)n_streams * p.n_blocks * kN);
+    p.wspec = wspec.data();
+    for (int s = 0; s < n_streams; ++s)                       // kernel 2: one "thread" per bin and block group
+        for (int b0 = 0; b0 < p.n_blocks; b0 += kCmacBlocks)
+            for (int i = 0; i < kN; ++i) part_cmac_bin(p, s, b0, i);
+    run([&](EmuCtx &ctx, int s, int b) { tile_part_inverse<EmuCtx>(ctx, p, s, b); }, p.n_blocks);
     return 0;
 }
 
