@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(kThreads) aw_part_inverse_kernel(TileParams p,
 // case — the few boundary tiles of those, and all tiles of the other channel counts — runs the
 // generic-addressing kernels <0, NP, false> (NP = compile-time pair count 1..4; NP = 0 loops over
 // batches of two pairs at run time: more than 8 channels, where full unrolling only spills).
-#define AW_FOR_EACH_VEC(X) X(2, 1) X(4, 2) X(8, 4) X(12, 0) X(16, 0)
+#define AW_FOR_EACH_VEC(X) X(2, 1) X(4, 2) X(6, 3) X(7, 4) X(8, 4) X(12, 0) X(14, 0) X(16, 0)
 #define AW_FOR_EACH_GEN(X) X(1) X(2) X(3) X(4) X(0)
 // boundary tiles of the common layouts keep whole-frame vector loads (history / zero-page selects per frame)
 #define AW_FOR_EACH_BVEC(X) X(2, 1) X(4, 2) X(8, 4)
@@ -211,13 +211,16 @@ hipError_t prepare_kernels() {
     return e;
 }
 
-static bool has_vec_variant(int C) { return C == 2 || C == 4 || C == 8 || C == 12 || C == 16; }
+static bool has_vec_variant(int C) { return C == 2 || C == 4 || C == 6 || C == 7 || C == 8 || C == 12 || C == 14 || C == 16; }
 
 const char *fused_ols_kernel_name(int C) {
     switch (C) {
         case 2: return "aw_fused_ols_kernel<2, 1, true>";
         case 4: return "aw_fused_ols_kernel<4, 2, true>";
+        case 6: return "aw_fused_ols_kernel<6, 3, true>";
+        case 7: return "aw_fused_ols_kernel<7, 4, true>";
         case 8: return "aw_fused_ols_kernel<8, 4, true>";
+        case 14: return "aw_fused_ols_kernel<14, 0, true>";
         case 12: return "aw_fused_ols_kernel<12, 0, true>";
         case 16: return "aw_fused_ols_kernel<16, 0, true>";
         default: return "aw_fused_ols_kernel<0, NP, false>";
@@ -261,7 +264,9 @@ hipError_t launch_fused_ols(const TileParams &p_in, int n_streams, hipStream_t s
     TileParams p = p_in;
     // tile i is interior iff  i*hop - hist_len >= 0  and  i*hop - hist_len + N <= frames
     long long lo = (p.hist_len + p.hop - 1) / p.hop;
-    long long hi = (p.frames - kN + p.hist_len) >= 0 ? (p.frames - kN + p.hist_len) / p.hop + 1 : 0;
+    // layouts whose frames are not whole float4s read up to 3 floats past a frame: keep one frame of slack
+    const long long usable = p.frames - ((p.n_channels % 4 != 0 && p.n_channels != 2) ? 1 : 0);
+    long long hi = (usable - kN + p.hist_len) >= 0 ? (usable - kN + p.hist_len) / p.hop + 1 : 0;
     if (hi > p.tiles_per_stream) hi = p.tiles_per_stream;
     if (hi < lo) hi = lo;
     if (lo > p.tiles_per_stream) { lo = p.tiles_per_stream; hi = lo; }

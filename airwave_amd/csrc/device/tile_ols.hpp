@@ -65,7 +65,7 @@ struct TileParams {
     const float *in;        // [stream][frames][C] interleaved, device
     float *out;             // [stream][frames][2]
     const float *hist;      // [stream][hist_len][C]: the hist_len frames preceding in[...][0]
-    const cf2 *tab;         // [pair][16][512] {A,B}, index k = k1 + 16 k2 stored at [k1][k2]
+    const cf2 *tab;         // [pair][16][512] {A,B}, index k = k1 + 16 k2 stored at [k1][k2]; fused path: + one all-zero pair at the end
     const cf *tw1;          // [512]  : W_N^t (pass-1 twiddle base; powers are formed in registers)
     const cf *twa;          // [8][64]: W_512^{lane ka}, ka-major (sub-FFT pass A)
     const cf *twb;          // [8][8] : W_64^{l0 kb}, kb-major   (sub-FFT pass B)
@@ -173,6 +173,7 @@ AW_HD void sub_fft512x2(Ctx &ctx, cf (&a)[2][8], cf *scr0, cf *scr1, const cf *t
 // ---- the tile ----------------------------------------------------------------------------------
 struct alignas(16) f4 { float x, y, z, w; };
 struct alignas(8) f2 { float x, y; };
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };   // 16 bytes at dword alignment
 
 // One interleaved frame -> registers (channels c0 .. c0+3, zero padded).  Frames before the call
 // come from the history buffer (previous calls' tail; zeros after create/reset), frames past the
@@ -221,9 +222,16 @@ AW_HD void load_batch(const TileParams &p, const float *in_s, const float *hist_
             if constexpr (CS % 4 == 0) {
                 const f4 v = *reinterpret_cast<const f4 *>(src);
                 raw[j][0] = v.x; raw[j][1] = v.y; raw[j][2] = v.z; raw[j][3] = v.w;
-            } else {
+            } else if constexpr (CS == 2) {
                 const f2 v = *reinterpret_cast<const f2 *>(src);
                 raw[j][0] = v.x; raw[j][1] = v.y; raw[j][2] = 0.f; raw[j][3] = 0.f;
+            } else {
+                // frames that are not whole float4s (6, 7, 14 channels): one dword-aligned 16-B load all the
+                // same.  The last batch of a frame runs up to 3 floats into the next frame; those lanes belong
+                // to channels >= CS, whose filters are zero tables (build_pair_tables / the zero pair), so the
+                // finite stray samples contribute nothing.  The launch keeps one frame of slack at the end.
+                const f4u v = *reinterpret_cast<const f4u *>(src);
+                raw[j][0] = v.x; raw[j][1] = v.y; raw[j][2] = v.z; raw[j][3] = v.w;
             }
         }
     } else {
@@ -425,7 +433,7 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
         ctx.stamp(pair0 > 0 ? 8 : 3);
         pair_subfft_cmac(ctx, p, pair0, buf0, twa, twb, tab, lane, wave, wacc, kTabEarly0);
         ctx.stamp(pair0 > 0 ? 9 : 4);
-        const int pair1 = (NP > 0 || pair0 + 1 < n_pairs) ? pair0 + 1 : pair0;   // phantom: any valid table
+        const int pair1 = pair0 + 1;     // a phantom second pair (odd pair count, runtime loop) lands on the zero pair after the last one
         if (two && kTabEarly1) load_tab(p, pair1, wave, lane, tab);
         if (kPrefetchRawEarly && more) load_batch<CS, INTERIOR>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
         if (two) pair_subfft_cmac(ctx, p, pair1, buf1, twa, twb, tab, lane, wave, wacc, kTabEarly1);

@@ -242,6 +242,9 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
                                cnt, tab);
         all.insert(all.end(), tab.begin(), tab.end());
     }
+    // fused path: one all-zero pair after the last one — a phantom pair (odd pair count in the runtime-loop
+    // kernels; stray lanes of non-float4 frames) multiplies it and contributes nothing
+    if (sp->path == 0) all.resize(all.size() + awk::kN, awk::cf2{awk::mk(0.f, 0.f), awk::mk(0.f, 0.f)});
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&sp->d_tab), all.size() * sizeof(awk::cf2));
     if (e == hipSuccess) e = hipMemcpy(sp->d_tab, all.data(), all.size() * sizeof(awk::cf2), hipMemcpyHostToDevice);
     if (e != hipSuccess) { aw_spatializer_destroy(sp); return awr::hip_fail(e, "filter tables"); }

@@ -64,6 +64,7 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
     std::vector<cf2> tab;
     awh::build_twiddles(tw);
     awh::build_pair_tables(tracks, n_tracks, taps, n_channels, left_track, right_track, 0, taps, tab);
+    tab.resize(tab.size() + kN, cf2{mk(0, 0), mk(0, 0)});            // the zero pair (as runtime.cpp appends it)
     std::vector<float> zero_hist;
     TileParams p{};
     p.in = in; p.out = out; p.tab = tab.data(); p.tw1 = tw.tw1.data(); p.twa = tw.twa.data(); p.twb = tw.twb.data(); p.zeros = g_zeros;
@@ -77,11 +78,13 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
     p.hist = hist;
     // same interior/boundary split as awk::launch_fused_ols
     long long lo = (p.hist_len + p.hop - 1) / p.hop;
-    long long hi = (p.frames - kN + p.hist_len) >= 0 ? (p.frames - kN + p.hist_len) / p.hop + 1 : 0;
+    const long long usable = p.frames - ((n_channels % 4 != 0 && n_channels != 2) ? 1 : 0);
+    long long hi = (usable - kN + p.hist_len) >= 0 ? (usable - kN + p.hist_len) / p.hop + 1 : 0;
     if (hi > p.tiles_per_stream) hi = p.tiles_per_stream;
     if (hi < lo) hi = lo;
     if (lo > p.tiles_per_stream) { lo = p.tiles_per_stream; hi = lo; }
-    const bool vec = n_channels == 2 || n_channels == 4 || n_channels == 8 || n_channels == 12 || n_channels == 16;
+    const bool vec = n_channels == 2 || n_channels == 4 || n_channels == 6 || n_channels == 7 || n_channels == 8 ||
+                     n_channels == 12 || n_channels == 14 || n_channels == 16;
     if (!vec || variant != 1) { lo = 0; hi = 0; }
     p.tile_lo = (int)lo; p.tile_hi = (int)hi;
     EmuShared sh;
@@ -99,7 +102,10 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
                         switch (n_channels) {
                             case 2: tiles_fused_ols<EmuCtx, 2, 1, true>(ctx, p, g, G, n_tiles); break;
                             case 4: tiles_fused_ols<EmuCtx, 4, 2, true>(ctx, p, g, G, n_tiles); break;
+                            case 6: tiles_fused_ols<EmuCtx, 6, 3, true>(ctx, p, g, G, n_tiles); break;
+                            case 7: tiles_fused_ols<EmuCtx, 7, 4, true>(ctx, p, g, G, n_tiles); break;
                             case 8: tiles_fused_ols<EmuCtx, 8, 4, true>(ctx, p, g, G, n_tiles); break;
+                            case 14: tiles_fused_ols<EmuCtx, 14, 0, true>(ctx, p, g, G, n_tiles); break;
                             case 12: tiles_fused_ols<EmuCtx, 12, 0, true>(ctx, p, g, G, n_tiles); break;
                             default: tiles_fused_ols<EmuCtx, 16, 0, true>(ctx, p, g, G, n_tiles); break;
                         }

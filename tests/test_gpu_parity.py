@@ -69,6 +69,23 @@ def test_every_channel_count_matches_f32_oracle_and_truth(aw, oracle, golden_dir
         assert oracle.peak_rel_error(y[s], yo[s]) < TOL
 
 
+@pytest.mark.parametrize("channels", [2, 4, 6, 7, 8, 12, 14, 16])
+def test_interior_kernels_of_every_vector_layout(aw, oracle, golden_dir, channels):
+    """Long enough for interior tiles (whole-frame vector loads; 6/7/14-channel frames are not whole float4s and
+    read into the next frame: zero tables must cancel the stray lanes), odd frame count, two calls."""
+    w = wav(oracle, golden_dir, "StageSH1.0.wav")
+    tracks = np.asarray(w.audio_data)
+    lt = (np.arange(channels) % 14).astype(np.int32)
+    rt = ((np.arange(channels) + 7) % 14).astype(np.int32)
+    frames = 21001
+    x = oracle.synth_input(3, frames, channels, seed=channels)
+    sp = aw.Spatializer(aw.HRIR(tracks), lt, rt, n_streams=3)
+    y = np.concatenate([sp.process(x[:, :15000]), sp.process(x[:, 15000:])], axis=1)
+    assert not np.isnan(y).any()
+    for s in (0, 2):
+        assert oracle.peak_rel_error(y[s], oracle.spatialize_f64(x[s], tracks, lt, rt)) < TOL
+
+
 @pytest.mark.parametrize("taps", [1, 2, 511, 512, 513, 4097, 6145])
 def test_hrir_lengths_on_the_fused_path(aw, oracle, taps):
     h = oracle.synth_hrir(4, taps, seed=taps)
