@@ -37,23 +37,24 @@ constexpr int kEqChunk = 16;
 constexpr int kEqSpan = kEqThreads * kEqChunk;   // 4096 frames
 constexpr int kEqMaxFilters = 64;                // ParametricEqualizerState.maximumFilterCount :17
 constexpr int kEqScanSteps = 7;                  // P^(2^s), s = 0 .. 6 (6 = one whole wave of chunks)
-constexpr int kEqStageStride = kEqChunk + 2;     // float2 units; +16 B per chunk spreads the banks
 // LDS map (bytes)
-constexpr int kEqStageBytes = kEqThreads * kEqStageStride * 8;            // 36,864
-constexpr int kEqScanBytes = kEqThreads * 4 * 8;                          // [thread][4] double, wave-private slots
+constexpr int kEqStageBytes = kEqThreads * (kEqChunk * 2 + 4) * 4;        // 36,864: [chunk][32 + 4] floats (both ears)
+constexpr int kEqScanBytes = 4 * kEqThreads * 8;                          // [4][thread] double (component-major: conflict-free 8-B accesses)
 constexpr int kEqTotalsBytes = 2 * (kEqThreads / 64) * 4 * 8;             // ping-pong [wave][4]
 constexpr int kEqCarryBytes = 2 * kEqMaxFilters * 4 * 8;                  // ping-pong [filter][4]
-constexpr int kEqLdsFixedBytes = kEqStageBytes + kEqScanBytes + kEqTotalsBytes + kEqCarryBytes;   // 49,408
-// + the uniform per-filter tables (coef | zir | ppow), staged once per launch
+constexpr int kEqLdsBytes = kEqStageBytes + kEqScanBytes + kEqTotalsBytes + kEqCarryBytes;   // 49,408
 constexpr int kEqTabDoubles = 5 + kEqChunk * 2 + kEqScanSteps * 4;        // 65 per filter
-AW_HD int eq_lds_bytes(int n_filters) { return kEqLdsFixedBytes + n_filters * kEqTabDoubles * 8; }
 
 // Per-state tables, built on the host in double (host/eq.cpp).
 struct EqTables {
-    const double *coef;   // [K][5]  b0 b1 b2 a1 a2 (normalised by a0)
-    const double *zir;    // [K][kEqChunk][2]   row 0 of M^j, j = 0 .. kEqChunk-1
-    const double *ppow;   // [K][kEqScanSteps][4]   P^(2^s), P = M^kEqChunk, row-major 2x2
-    const double *plane;  // [K][64][4]             P^lane, lane = 0 .. 63
+    // [K][kEqTabDoubles] wave-uniform entries, read straight from global memory: the index is uniform and the
+    // kernel takes the pointer as a `const __restrict__` argument, so hipcc issues scalar loads (s_load) and the
+    // values reach the FMAs as SGPR operands — no LDS or VGPR traffic for them:
+    //   [0,5)   b0 b1 b2 a1 a2 (normalised by a0)
+    //   [5,37)  row 0 of M^j, j = 0 .. kEqChunk-1          (zero-input response)
+    //   [37,65) P^(2^s), s = 0 .. 6, P = M^kEqChunk, row-major 2x2
+    const double *tab;
+    const double *plane;  // [K][64][4]  P^lane, lane = 0 .. 63 (per-lane: vector loads)
     double preamp;        // 10^(dB/20)
     int n_filters;
 };
@@ -69,39 +70,49 @@ struct EqParams {
 
 AW_HD double eq_flush(double v) { return (v < 0 ? -v : v) < 1e-30 ? 0.0 : v; }   // flushSubnormal :95-97
 
-// acc += P * q for the (z1, z2) pairs of both ears
-AW_HD void eq_apply(const double *P, const double *q, double &l1, double &l2, double &r1, double &r2) {
+// st += P * q for the (z1, z2) state pairs of E ears (st, q: [2 E])
+template <int E> AW_HD void eq_apply(const double *P, const double (&q)[2 * E], double (&st)[2 * E]) {
     const double p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3];
-    const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-    l1 = __builtin_fma(p1, q1, __builtin_fma(p0, q0, l1));
-    l2 = __builtin_fma(p3, q1, __builtin_fma(p2, q0, l2));
-    r1 = __builtin_fma(p1, q3, __builtin_fma(p0, q2, r1));
-    r2 = __builtin_fma(p3, q3, __builtin_fma(p2, q2, r2));
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const double q0 = q[2 * e], q1 = q[2 * e + 1];
+        st[2 * e] = __builtin_fma(p1, q1, __builtin_fma(p0, q0, st[2 * e]));
+        st[2 * e + 1] = __builtin_fma(p3, q1, __builtin_fma(p2, q0, st[2 * e + 1]));
+    }
 }
 
-// One workgroup, one stream; p.frames must be a multiple of kEqChunk.
-template <class Ctx> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParams &p, long long stream) {
+// scan slots: component c of thread t at scan[c * kEqThreads + t] (component-major: conflict-free 8-B accesses)
+template <int E> AW_HD void eq_put(double *scan, int t, const double (&v)[2 * E]) {
+#pragma unroll
+    for (int c = 0; c < 2 * E; ++c) scan[c * kEqThreads + t] = v[c];
+}
+template <int E> AW_HD void eq_get(const double *scan, int t, double (&q)[2 * E]) {
+#pragma unroll
+    for (int c = 0; c < 2 * E; ++c) q[c] = scan[c * kEqThreads + t];
+}
+
+// One workgroup walks one stream's timeline for E ears starting at ear0: E = 2 (both ears in every thread)
+// or E = 1 (a workgroup per (stream, ear): twice the waves in flight for small batches; the kernel is
+// latency bound — VALU 40 % busy at 2 waves/SIMD, rocprofv3 PMC — so occupancy is what it needs).
+// p.frames must be a multiple of kEqChunk.
+template <class Ctx, int E> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParams &p, long long stream, int ear0) {
+    constexpr int S = 2 * E;                     // state doubles per filter handled here
     const int tid = ctx.tid();
     const int lane = tid & 63;
     char *lds = reinterpret_cast<char *>(ctx.lds());
-    cf *stage = reinterpret_cast<cf *>(lds);
+    float *stage = reinterpret_cast<float *>(lds);                         // [chunk][kEqChunk * E + pad] floats
     double *scan = reinterpret_cast<double *>(lds + kEqStageBytes);
     double *totals = reinterpret_cast<double *>(lds + kEqStageBytes + kEqScanBytes);
     double *carry = reinterpret_cast<double *>(lds + kEqStageBytes + kEqScanBytes + kEqTotalsBytes);
-    double *tab = reinterpret_cast<double *>(lds + kEqLdsFixedBytes);   // [K][65]: coef 5 | zir 32 | ppow 28
+    constexpr int kStride = kEqChunk * E + (E == 2 ? 4 : 1);               // floats per chunk row: 36 (16-B units) / 17
     const int wave = ctx.wave();
     const int K = p.t.n_filters;
-    double *zs = p.z + stream * (long long)K * 4;
-    const cf *in = reinterpret_cast<const cf *>(p.in) + stream * p.stride_frames;
-    cf *out = reinterpret_cast<cf *>(p.out) + stream * p.stride_frames;
+    double *zs = p.z + stream * (long long)K * 4 + ear0 * 2;               // [K][4]: this workgroup's S of every 4
+    const float *in = p.in + stream * p.stride_frames * 2 + ear0;
+    float *out = p.out + stream * p.stride_frames * 2 + ear0;
     const double preamp = p.t.preamp;
 
-    for (int i = tid; i < K * 4; i += kEqThreads) carry[i] = zs[i];
-    for (int i = tid; i < K * kEqTabDoubles; i += kEqThreads) {
-        const int k = i / kEqTabDoubles, r = i - k * kEqTabDoubles;
-        tab[i] = r < 5 ? p.t.coef[k * 5 + r]
-                       : r < 5 + kEqChunk * 2 ? p.t.zir[k * kEqChunk * 2 + (r - 5)] : p.t.ppow[k * kEqScanSteps * 4 + (r - 5 - kEqChunk * 2)];
-    }
+    for (int i = tid; i < K * S; i += kEqThreads) carry[i] = zs[(i / S) * 4 + (i % S)];
     int par = 0;
 
     for (long long base = 0; base < p.frames; base += kEqSpan) {
@@ -109,90 +120,94 @@ template <class Ctx> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParams &p, l
         const int nfr = rem < kEqSpan ? (int)rem : kEqSpan;
         const int nchunks = nfr / kEqChunk;
         ctx.barrier();   // stage reads of the previous span and the carry writes are complete
+        // HBM -> LDS coalesced, LDS -> registers transposed to one chunk per thread
 #pragma unroll
         for (int j = 0; j < kEqChunk; ++j) {
             const int f = j * kEqThreads + tid;
-            cf v = mk(0.f, 0.f);
-            if (f < nfr) v = in[base + f];
-            stage[(f >> 4) * kEqStageStride + (f & 15)] = v;
+            float *dst = stage + (f >> 4) * kStride + (f & 15) * E;
+            if constexpr (E == 2) {
+                cf v = mk(0.f, 0.f);
+                if (f < nfr) v = *reinterpret_cast<const cf *>(in + (base + f) * 2);
+                *reinterpret_cast<cf *>(dst) = v;
+            } else {
+                *dst = f < nfr ? in[(base + f) * 2] : 0.f;
+            }
         }
         ctx.barrier();
-        double xl[kEqChunk], xr[kEqChunk];
+        double x[E][kEqChunk];
 #pragma unroll
-        for (int j = 0; j < kEqChunk; ++j) {
-            const cf v = stage[tid * kEqStageStride + j];
-            xl[j] = (double)v.x * preamp;   // :67-69
-            xr[j] = (double)v.y * preamp;
-        }
+        for (int j = 0; j < kEqChunk; ++j)
+#pragma unroll
+            for (int e = 0; e < E; ++e) x[e][j] = (double)stage[tid * kStride + j * E + e] * preamp;   // :67-69
 
         for (int k = 0; k < K; ++k) {
-            const double *c = tab + k * kEqTabDoubles;
+            const double *c = p.t.tab + (long long)k * kEqTabDoubles;      // uniform: scalar loads
             const double b0 = c[0], b1 = c[1], b2 = c[2], na1 = -c[3], na2 = -c[4];
             // this lane's power of P for step (2c): issued now, consumed after the chunk's recurrence
             const double *plp = p.t.plane + ((long long)k * 64 + lane) * 4;
             const double pl[4] = {plp[0], plp[1], plp[2], plp[3]};
             // (1) zero-state response of this chunk, in place (:71-87 with z = 0)
-            double l1 = 0, l2 = 0, r1 = 0, r2 = 0;
+            double st[S];
 #pragma unroll
-            for (int j = 0; j < ((AW_EQ_ABL & 1) ? 1 : kEqChunk); ++j) {
-                const double lo = __builtin_fma(b0, xl[j], l1);
-                l1 = __builtin_fma(na1, lo, __builtin_fma(b1, xl[j], l2));
-                l2 = __builtin_fma(na2, lo, b2 * xl[j]);
-                xl[j] = lo;
-                const double ro = __builtin_fma(b0, xr[j], r1);
-                r1 = __builtin_fma(na1, ro, __builtin_fma(b1, xr[j], r2));
-                r2 = __builtin_fma(na2, ro, b2 * xr[j]);
-                xr[j] = ro;
-            }
+            for (int i = 0; i < S; ++i) st[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < ((AW_EQ_ABL & 1) ? 1 : kEqChunk); ++j)
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const double lo = __builtin_fma(b0, x[e][j], st[2 * e]);
+                    st[2 * e] = __builtin_fma(na1, lo, __builtin_fma(b1, x[e][j], st[2 * e + 1]));
+                    st[2 * e + 1] = __builtin_fma(na2, lo, b2 * x[e][j]);
+                    x[e][j] = lo;
+                }
             const double *pp = c + 5 + kEqChunk * 2;
-            const double e0 = l1, e1 = l2, e2 = r1, e3 = r2;
+            double end[S];
+#pragma unroll
+            for (int i = 0; i < S; ++i) end[i] = st[i];
             // (2a) inclusive Hillis-Steele scan INSIDE each wave (d = 1 .. 32) through wave-private slots
 #pragma unroll
             for (int s = 0; s < ((AW_EQ_ABL & 2) ? 1 : 6); ++s) {
                 const int d = 1 << s;
-                double *w = scan + tid * 4;
-                w[0] = l1; w[1] = l2; w[2] = r1; w[3] = r2;
+                eq_put<E>(scan, tid, st);
                 ctx.wave_sync();
-                if (lane >= d) eq_apply(pp + s * 4, scan + (tid - d) * 4, l1, l2, r1, r2);
+                if (lane >= d) {
+                    double q[S];
+                    eq_get<E>(scan, tid - d, q);
+                    eq_apply<E>(pp + s * 4, q, st);
+                }
                 ctx.wave_sync();
             }
             // wave totals -> LDS (ping-pong by filter parity), exclusive in-wave value from lane - 1
             double *tot = totals + (k & 1) * (kEqThreads / 64) * 4;
-            {
-                double *w = scan + tid * 4;
-                w[0] = l1; w[1] = l2; w[2] = r1; w[3] = r2;
-                if (lane == 63) {
-                    double *t = tot + wave * 4;
-                    t[0] = l1; t[1] = l2; t[2] = r1; t[3] = r2;
-                }
+            eq_put<E>(scan, tid, st);
+            if (lane == 63) {
+#pragma unroll
+                for (int i = 0; i < S; ++i) tot[wave * 4 + i] = st[i];
             }
             if (!(AW_EQ_ABL & 4)) ctx.barrier();
             // (2b) state entering this wave: W_0 = carried state, W_w = P^64 W_{w-1} + T_{w-1}
-            const double *cin = carry + par * kEqMaxFilters * 4 + k * 4;
-            double w0 = cin[0], w1 = cin[1], w2 = cin[2], w3 = cin[3];
+            const double *cin = carry + par * kEqMaxFilters * 4 + k * S;
+            double w[S];
+#pragma unroll
+            for (int i = 0; i < S; ++i) w[i] = cin[i];
             for (int i = 0; i < ((AW_EQ_ABL & 4) ? 0 : wave); ++i) {
-                const double *t = tot + i * 4;
-                double n0 = t[0], n1 = t[1], n2 = t[2], n3 = t[3];
-                const double q[4] = {w0, w1, w2, w3};
-                eq_apply(pp + 6 * 4, q, n0, n1, n2, n3);
-                w0 = n0; w1 = n1; w2 = n2; w3 = n3;
+                double n[S];
+#pragma unroll
+                for (int m = 0; m < S; ++m) n[m] = tot[i * 4 + m];
+                eq_apply<E>(pp + 6 * 4, w, n);
+#pragma unroll
+                for (int m = 0; m < S; ++m) w[m] = n[m];
             }
             // (2c) state entering this chunk: in-wave exclusive prefix + P^lane W_w
-            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-            if (lane > 0) {
-                const double *q = scan + (tid - 1) * 4;
-                s0 = q[0]; s1 = q[1]; s2 = q[2]; s3 = q[3];
-            }
-            {
-                const double q[4] = {w0, w1, w2, w3};
-                eq_apply(pl, q, s0, s1, s2, s3);
-            }
+            double sin_[S];
+#pragma unroll
+            for (int i = 0; i < S; ++i) sin_[i] = 0.0;
+            if (lane > 0) eq_get<E>(scan, tid - 1, sin_);
+            eq_apply<E>(pl, w, sin_);
             if (tid == nchunks - 1) {   // state after the last active chunk -> next span / next call
-                double *cout = carry + (par ^ 1) * kEqMaxFilters * 4 + k * 4;
-                const double q[4] = {s0, s1, s2, s3};
-                double c0 = e0, c1 = e1, c2 = e2, c3 = e3;
-                eq_apply(pp, q, c0, c1, c2, c3);
-                cout[0] = c0; cout[1] = c1; cout[2] = c2; cout[3] = c3;
+                double *cout = carry + (par ^ 1) * kEqMaxFilters * 4 + k * S;
+                eq_apply<E>(pp, sin_, end);
+#pragma unroll
+                for (int i = 0; i < S; ++i) cout[i] = end[i];
             }
             ctx.wave_sync();   // the exclusive reads above precede the next filter's slot writes
             // (3) zero-input response of the entering state
@@ -200,23 +215,29 @@ template <class Ctx> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParams &p, l
 #pragma unroll
             for (int j = 0; j < ((AW_EQ_ABL & 8) ? 1 : kEqChunk); ++j) {
                 const double g0 = g[2 * j], g1 = g[2 * j + 1];
-                xl[j] = __builtin_fma(g1, s1, __builtin_fma(g0, s0, xl[j]));
-                xr[j] = __builtin_fma(g1, s3, __builtin_fma(g0, s2, xr[j]));
+#pragma unroll
+                for (int e = 0; e < E; ++e) x[e][j] = __builtin_fma(g1, sin_[2 * e + 1], __builtin_fma(g0, sin_[2 * e], x[e][j]));
             }
         }
         par = K ? par ^ 1 : par;
 
 #pragma unroll
-        for (int j = 0; j < kEqChunk; ++j) stage[tid * kEqStageStride + j] = mk((float)xl[j], (float)xr[j]);   // :88-89
+        for (int j = 0; j < kEqChunk; ++j)
+#pragma unroll
+            for (int e = 0; e < E; ++e) stage[tid * kStride + j * E + e] = (float)x[e][j];   // :88-89
         ctx.barrier();
 #pragma unroll
         for (int j = 0; j < kEqChunk; ++j) {
             const int f = j * kEqThreads + tid;
-            if (f < nfr) out[base + f] = stage[(f >> 4) * kEqStageStride + (f & 15)];
+            const float *src = stage + (f >> 4) * kStride + (f & 15) * E;
+            if (f < nfr) {
+                if constexpr (E == 2) *reinterpret_cast<cf *>(out + (base + f) * 2) = *reinterpret_cast<const cf *>(src);
+                else out[(base + f) * 2] = *src;
+            }
         }
     }
     ctx.barrier();
-    for (int i = tid; i < K * 4; i += kEqThreads) zs[i] = eq_flush(carry[par * kEqMaxFilters * 4 + i]);
+    for (int i = tid; i < K * S; i += kEqThreads) zs[(i / S) * 4 + (i % S)] = eq_flush(carry[par * kEqMaxFilters * 4 + i]);
 }
 
 // The reference's recurrence verbatim, one thread per (stream, ear): calls shorter than a chunk and
@@ -232,7 +253,7 @@ AW_HD void eq_sequential(const EqParams &p, long long stream, int ear) {
     for (long long f = 0; f < p.frames; ++f) {
         double v = (double)in[2 * f] * p.t.preamp;
         for (int k = 0; k < K; ++k) {
-            const double *c = p.t.coef + k * 5;
+            const double *c = p.t.tab + (long long)k * kEqTabDoubles;
             const double lo = c[0] * v + zs[k * 4];
             const double z1 = c[1] * v - c[3] * lo + zs[k * 4 + 1];
             const double z2 = c[2] * v - c[4] * lo;

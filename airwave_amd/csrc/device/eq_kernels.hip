@@ -1,6 +1,11 @@
 // eq_kernels.hip — gfx950 kernels of the parametric EQ row (device code in eq_cascade.hpp).
 #include "eq_kernels.hpp"
 
+#include <cstdlib>
+
+#ifndef AW_EQ_WAVES
+#define AW_EQ_WAVES 2
+#endif
 namespace awk {
 
 namespace {
@@ -22,10 +27,18 @@ struct EqGpuCtx {
 
 }  // namespace
 
-__global__ void __launch_bounds__(kEqThreads) aw_eq_cascade_kernel(EqParams p) {
+// The tables come in as `const __restrict__` kernel arguments (not inside the struct): with a wave-uniform
+// index that is what lets hipcc read them with scalar loads.  in/out may alias (in place) and are not restrict.
+// E = 2: one workgroup per stream; E = 1: one per (stream, ear).
+template <int E>
+__global__ void __launch_bounds__(kEqThreads, 2) aw_eq_cascade_kernel(EqParams p, const double *__restrict__ tab,
+                                                                        const double *__restrict__ plane) {
     extern __shared__ __align__(16) unsigned char eq_lds[];
     EqGpuCtx ctx{reinterpret_cast<cf *>(eq_lds)};
-    eq_cascade_stream(ctx, p, (long long)blockIdx.x);
+    p.t.tab = tab;
+    p.t.plane = plane;
+    if constexpr (E == 2) eq_cascade_stream<EqGpuCtx, 2>(ctx, p, (long long)blockIdx.x, 0);
+    else eq_cascade_stream<EqGpuCtx, 1>(ctx, p, (long long)(blockIdx.x >> 1), (int)(blockIdx.x & 1));
 }
 
 __global__ void aw_eq_sequential_kernel(EqParams p, int n_streams) {
@@ -58,7 +71,20 @@ __global__ void aw_eq_copy_kernel(const float *__restrict__ src, long long src_s
 
 hipError_t launch_eq_cascade(const EqParams &p, int n_streams, hipStream_t stream) {
     if (n_streams <= 0 || p.frames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(aw_eq_cascade_kernel, dim3((unsigned)n_streams), dim3(kEqThreads), (size_t)eq_lds_bytes(p.t.n_filters), stream, p);
+    // split the ears over two workgroups while one workgroup per stream leaves CUs idle (measured: 128 streams
+    // 2.84 -> 2.25 ms; at 512 streams the unsplit kernel wins, 7.1 vs 9.8 ms: the split reads every line twice
+    // and halves each thread's independent FMA chains)
+    static int cus = 0, force = -1;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        if (const char *e = getenv("AW_EQ_EAR_SPLIT")) force = atoi(e);
+    }
+    const bool split = force >= 0 ? force != 0 : 2 * n_streams < 3 * cus;
+    if (split)
+        hipLaunchKernelGGL(aw_eq_cascade_kernel<1>, dim3((unsigned)n_streams * 2), dim3(kEqThreads), kEqLdsBytes, stream, p, p.t.tab, p.t.plane);
+    else
+        hipLaunchKernelGGL(aw_eq_cascade_kernel<2>, dim3((unsigned)n_streams), dim3(kEqThreads), kEqLdsBytes, stream, p, p.t.tab, p.t.plane);
     return hipGetLastError();
 }
 

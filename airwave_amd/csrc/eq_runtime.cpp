@@ -70,22 +70,15 @@ aw_status prepare_state(aw_context *ctx, const awh::EqDefinition *def, double sa
     auto st = std::make_shared<EqState>();
     st->ctx = ctx; st->n_streams = n_streams; st->sample_rate = sample_rate;
     const int K = prep.n_filters;
-    const size_t n_coef = prep.coef.size(), n_zir = prep.zir.size(), n_pp = prep.ppow.size(), n_pl = prep.plane.size();
-    const size_t n_tab = std::max<size_t>(n_coef + n_zir + n_pp + n_pl, 1);
-    AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&st->d_tables), n_tab * sizeof(double)));
+    const size_t n_tab = prep.tab.size(), n_pl = prep.plane.size();
+    AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&st->d_tables), std::max<size_t>(n_tab + n_pl, 1) * sizeof(double)));
     if (K > 0) {
-        std::vector<double> all;
-        all.reserve(n_tab);
-        all.insert(all.end(), prep.coef.begin(), prep.coef.end());
-        all.insert(all.end(), prep.zir.begin(), prep.zir.end());
-        all.insert(all.end(), prep.ppow.begin(), prep.ppow.end());
+        std::vector<double> all(prep.tab);
         all.insert(all.end(), prep.plane.begin(), prep.plane.end());
         AW_HIP_TRY(hipMemcpy(st->d_tables, all.data(), all.size() * sizeof(double), hipMemcpyHostToDevice));
     }
-    st->t.coef = st->d_tables;
-    st->t.zir = st->t.coef + n_coef;
-    st->t.ppow = st->t.zir + n_zir;
-    st->t.plane = st->t.ppow + n_pp;
+    st->t.tab = st->d_tables;
+    st->t.plane = st->d_tables + n_tab;
     st->t.preamp = prep.preamp;
     st->t.n_filters = K;
     st->z_count = std::max<size_t>((size_t)n_streams * K * 4, 1);

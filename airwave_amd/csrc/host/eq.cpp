@@ -294,9 +294,7 @@ int eq_prepare(const EqDefinition *def, double fs, EqPrepared &out, int *bad_ind
     out = EqPrepared{};
     out.preamp = preamp;
     out.n_filters = K;
-    out.coef.resize((size_t)K * 5);
-    out.zir.resize((size_t)K * awk::kEqChunk * 2);
-    out.ppow.resize((size_t)K * awk::kEqScanSteps * 4);
+    out.tab.resize((size_t)K * awk::kEqTabDoubles);
     out.plane.resize((size_t)K * 64 * 4);
     for (int k = 0; k < K; ++k) {
         Biquad c;
@@ -306,15 +304,16 @@ int eq_prepare(const EqDefinition *def, double fs, EqPrepared &out, int *bad_ind
             if (bad_kind) *bad_kind = kind;
             return kEqPrepInvalidFilter;
         }
-        double *cf = &out.coef[(size_t)k * 5];
+        double *cf = &out.tab[(size_t)k * awk::kEqTabDoubles];
+        double *zir = cf + 5, *ppow = zir + awk::kEqChunk * 2;
         cf[0] = c.b0; cf[1] = c.b1; cf[2] = c.b2; cf[3] = c.a1; cf[4] = c.a2;
         // zero-input state matrix of the transposed direct form II section (x = 0 in :71-77):
         //   z1' = -a1 z1 + z2,  z2' = -a2 z1,  y = z1
         const double M[4] = {-c.a1, 1.0, -c.a2, 0.0};
         double Mj[4] = {1, 0, 0, 1};
         for (int j = 0; j < awk::kEqChunk; ++j) {
-            out.zir[((size_t)k * awk::kEqChunk + j) * 2] = Mj[0];
-            out.zir[((size_t)k * awk::kEqChunk + j) * 2 + 1] = Mj[1];
+            zir[j * 2] = Mj[0];
+            zir[j * 2 + 1] = Mj[1];
             mat2_mul(M, Mj, Mj);
         }
         double P[4] = {Mj[0], Mj[1], Mj[2], Mj[3]};   // M^chunk
@@ -324,7 +323,7 @@ int eq_prepare(const EqDefinition *def, double fs, EqPrepared &out, int *bad_ind
             mat2_mul(P, Pl, Pl);
         }
         for (int s = 0; s < awk::kEqScanSteps; ++s) {
-            std::memcpy(&out.ppow[((size_t)k * awk::kEqScanSteps + s) * 4], P, sizeof(P));
+            std::memcpy(&ppow[s * 4], P, sizeof(P));
             mat2_mul(P, P, P);
         }
     }

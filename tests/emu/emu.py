@@ -31,7 +31,7 @@ def lib():
                                          ctypes.c_longlong, ctypes.c_int]
         _lib.emu_fft_small.argtypes = [fp, ctypes.c_int, ctypes.c_int]
         _lib.emu_eq_process.argtypes = [fp, fp, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_longlong, ctypes.c_double,
-                                        ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+                                        ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int]
     return _lib
 
 
@@ -78,7 +78,7 @@ def fft_small(v, inverse=False):
     return a.view(np.complex64)
 
 
-def eq_process(x, sample_rate, preamp_db, filters, z=None):
+def eq_process(x, sample_rate, preamp_db, filters, z=None, ear_split=False):
     """x: [streams][frames][2] float32; filters: [(type, fc, gain_db, q)].  Returns (y, z) with z the carried state."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     S, F, _ = x.shape
@@ -88,6 +88,6 @@ def eq_process(x, sample_rate, preamp_db, filters, z=None):
     out = np.full((S, F, 2), np.nan, dtype=np.float32)
     dp = ctypes.POINTER(ctypes.c_double)
     rc = lib().emu_eq_process(x.ctypes.data_as(fp), out.ctypes.data_as(fp), z.ctypes.data_as(dp), S, F, sample_rate, preamp_db,
-                              fl.ctypes.data_as(dp), K)
+                              fl.ctypes.data_as(dp), K, int(ear_split))
     assert rc == K, rc
     return out, z

@@ -195,7 +195,7 @@ int emu_fft_small(float *data, int n, int inverse) {
 // eq_sequential for the tail — the same split runtime.cpp makes.  filters: [n][4] = type, fc, gain, q.
 // z: [stream][K][4] state, carried in and out.  Returns K or a negative prepare error.
 int emu_eq_process(const float *in, float *out, double *z, int n_streams, long long frames, double sample_rate,
-                   double preamp_db, const double *filters, int n_filters) {
+                   double preamp_db, const double *filters, int n_filters, int ear_split) {
     using namespace awk;
     awh::EqDefinition def;
     def.preamp_db = preamp_db;
@@ -210,18 +210,26 @@ int emu_eq_process(const float *in, float *out, double *z, int n_streams, long l
     if (rc) return -rc;
     EqParams p{};
     p.in = in; p.out = out; p.z = z;
-    p.t.coef = prep.coef.data(); p.t.zir = prep.zir.data(); p.t.ppow = prep.ppow.data(); p.t.plane = prep.plane.data();
+    p.t.tab = prep.tab.data(); p.t.plane = prep.plane.data();
     p.t.preamp = prep.preamp; p.t.n_filters = prep.n_filters;
     p.stride_frames = frames;
     const long long body = frames - frames % kEqChunk;
     if (body > 0) {
         p.frames = body;
-        EmuShared sh(kEqThreads, (size_t)eq_lds_bytes(prep.n_filters) / sizeof(cf));
+        EmuShared sh(kEqThreads, (size_t)kEqLdsBytes / sizeof(cf));
         for (int s = 0; s < n_streams; ++s) {
             std::vector<std::thread> th;
             th.reserve(kEqThreads);
-            for (int t = 0; t < kEqThreads; ++t) th.emplace_back([&, t]() { EmuCtx ctx{t, &sh}; eq_cascade_stream(ctx, p, s); });
-            for (auto &x : th) x.join();
+            for (int ear = 0; ear < (ear_split ? 2 : 1); ++ear) {        // E = 1: one emulated workgroup per (stream, ear)
+                th.clear();
+                for (int t = 0; t < kEqThreads; ++t)
+                    th.emplace_back([&, t]() {
+                        EmuCtx ctx{t, &sh};
+                        if (ear_split) eq_cascade_stream<EmuCtx, 1>(ctx, p, s, ear);
+                        else eq_cascade_stream<EmuCtx, 2>(ctx, p, s, 0);
+                    });
+                for (auto &x : th) x.join();
+            }
         }
     }
     if (frames > body) {

@@ -22,13 +22,14 @@ def _oracle_run(oracle, fs, preamp, filters, calls):
     return outs
 
 
+@pytest.mark.parametrize("ear_split", [False, True])
 @pytest.mark.parametrize("frames", [5, 16, 31, 4096, 4096 + 16 * 3 + 7, 2 * 4096 + 16])
-def test_cascade_matches_sequential_recurrence(oracle, frames):
+def test_cascade_matches_sequential_recurrence(oracle, frames, ear_split):
     rng = np.random.default_rng(frames)
     x = rng.uniform(-0.5, 0.5, (2, frames, 2)).astype(np.float32)
     x2 = rng.uniform(-0.5, 0.5, (2, 333, 2)).astype(np.float32)
-    y, z = emu.eq_process(x, 48000.0, -2.56, FILTERS)
-    y2, _ = emu.eq_process(x2, 48000.0, -2.56, FILTERS, z)         # the stream continues: state carried
+    y, z = emu.eq_process(x, 48000.0, -2.56, FILTERS, ear_split=ear_split)
+    y2, _ = emu.eq_process(x2, 48000.0, -2.56, FILTERS, z, ear_split=ear_split)   # the stream continues: state carried
     e, e2 = _oracle_run(oracle, 48000.0, -2.56, FILTERS, [x, x2])
     # Float64 reassociation only: at most 1 ulp of the Float32 output
     assert np.max(np.abs(y - e)) <= 6e-8 and np.max(np.abs(y2 - e2)) <= 6e-8
