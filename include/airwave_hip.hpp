@@ -113,4 +113,52 @@ class RealtimeAudioProcessor {
     aw_realtime *h_ = nullptr;
 };
 
+// ---- parametric EQ (EqualizerPreset.swift, EqualizerAPOParser.swift, ParametricEqualizerProcessor.swift) ----
+enum class EqualizerFilterType : int32_t { peaking = 0, lowShelf = 1, highShelf = 2 };
+
+class EqualizerDefinition {
+  public:
+    explicit EqualizerDefinition(double preampDB = 0.0) { check(aw_eq_definition_create(preampDB, &h_)); }
+    // EqualizerAPOParser.parse(data:filename:) — throws aw::Error(AW_ERR_EQ_PARSE, "line N: reason; ...")
+    static EqualizerDefinition parse(const void *data, size_t size) {
+        aw_eq_definition *d = nullptr;
+        char issues[4096];
+        const aw_status s = aw_eq_parse(data, size, &d, issues, sizeof(issues));
+        if (s != AW_OK) throw Error(s, issues);
+        return EqualizerDefinition(d);
+    }
+    EqualizerDefinition(EqualizerDefinition &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    EqualizerDefinition(const EqualizerDefinition &) = delete;
+    ~EqualizerDefinition() { aw_eq_definition_destroy(h_); }
+    EqualizerDefinition &addFilter(EqualizerFilterType type, double frequencyHz, double gainDB, double q, bool isEnabled = true) {
+        check(aw_eq_definition_add_filter(h_, isEnabled ? 1 : 0, (int32_t)type, frequencyHz, gainDB, q));
+        return *this;
+    }
+    double preampDB() const { return aw_eq_definition_preamp_db(h_); }
+    int filterCount() const { return aw_eq_definition_filter_count(h_); }
+    const aw_eq_definition *get() const { return h_; }
+  private:
+    explicit EqualizerDefinition(aw_eq_definition *d) : h_(d) {}
+    aw_eq_definition *h_ = nullptr;
+};
+
+// ParametricEqualizerProcessor :116-408 (one stream, planar host buffers: the StereoAudioProcessing surface)
+class ParametricEqualizerProcessor {
+  public:
+    ParametricEqualizerProcessor(Context &ctx, double sampleRate, int maxFramesPerCallback = 4096) {
+        check(aw_eq_create(ctx.get(), sampleRate, 1, maxFramesPerCallback, &h_));
+    }
+    ~ParametricEqualizerProcessor() { aw_eq_destroy(h_); }
+    ParametricEqualizerProcessor(const ParametricEqualizerProcessor &) = delete;
+    void setTarget(const EqualizerDefinition *definition) { check(aw_eq_set_target(h_, definition ? definition->get() : nullptr)); }   // :226
+    void reset() { check(aw_eq_reset(h_)); }                                                                                          // :230
+    void drainRetiredStates() { check(aw_eq_drain_retired(h_)); }                                                                     // :237
+    void process(const float *inputLeft, const float *inputRight, float *leftOutput, float *rightOutput, int frameCount) {          // :253
+        check(aw_eq_process_planar(h_, inputLeft, inputRight, leftOutput, rightOutput, frameCount));
+    }
+    int transitionLength() const { return aw_eq_transition_length(h_); }
+  private:
+    aw_eq *h_ = nullptr;
+};
+
 }  // namespace aw

@@ -46,6 +46,27 @@ int main(int argc, char **argv) {
             proc.reset();
             engine->reset();
         }
+        // the EQ that follows the spatializer in the reference's graph: parse an APO preset, fade to it across
+        // 512-frame callbacks, retarget to unity (ParametricEqualizerProcessor.setTarget / process / drainRetiredStates)
+        if (argc > 3) {
+            FILE *pf = std::fopen(argv[3], "rb");
+            if (!pf) return 5;
+            std::vector<char> text(1 << 16);
+            const size_t len = std::fread(text.data(), 1, text.size(), pf);
+            std::fclose(pf);
+            aw::EqualizerDefinition def = aw::EqualizerDefinition::parse(text.data(), len);
+            aw::ParametricEqualizerProcessor eq(ctx, 48000.0, 512);
+            eq.setTarget(&def);
+            state = 777u;
+            for (int call = 0; call < 6; ++call) {
+                if (call == 4) { eq.drainRetiredStates(); eq.setTarget(nullptr); }
+                std::vector<float> l(512), r(512), ol(512), orr(512);
+                for (int i = 0; i < 512; ++i) { l[i] = rnd(); r[i] = rnd(); }
+                eq.process(l.data(), r.data(), ol.data(), orr.data(), 512);
+                dump.insert(dump.end(), ol.begin(), ol.end());
+                dump.insert(dump.end(), orr.begin(), orr.end());
+            }
+        }
         aw_map_destroy(map); aw_layout_destroy(layout); aw_wav_destroy(wav);
         FILE *f = std::fopen(argv[2], "wb");
         if (!f) return 4;

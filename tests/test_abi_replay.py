@@ -53,3 +53,33 @@ def test_replay_matches_oracle(oracle, golden_dir, tmp_path):
     exp = np.concatenate(exp)
     assert exp.size == half
     assert np.max(np.abs(got[:half] - exp)) <= 1e-5 * np.max(np.abs(exp))
+
+
+@pytest.mark.gpu
+def test_replay_eq_through_the_cpp_mirror(oracle, golden_dir, tmp_path):
+    """The EQ half of the graph from a compiled host: aw::EqualizerDefinition::parse + aw::ParametricEqualizerProcessor."""
+    build()
+    wav_path = os.path.join(golden_dir, "hrtf", "NeutralSH1.0.wav")
+    preset = os.path.join(golden_dir, "eq", "CCA CRA ParametricEq.txt")
+    out = str(tmp_path / "dump_eq.bin")
+    subprocess.run([EXE, wav_path, out, preset], check=True)
+    got = np.fromfile(out, dtype=np.float32)[-6 * 1024:]
+    p = oracle.ParametricEqualizerProcessor(48000.0, 512)
+    p.set_target(oracle.eq_parse(open(preset, "rb").read(), "f.txt"))
+    state = 777
+
+    def rnd():
+        nonlocal state
+        state = (state * 1664525 + 1013904223) & 0xFFFFFFFF
+        return np.float32(state >> 8) / np.float32(16777216.0) - np.float32(0.5)
+
+    exp = []
+    for call in range(6):
+        if call == 4:
+            p.drain_retired_states()
+            p.set_target(None)
+        lr = np.array([rnd() for _ in range(1024)], dtype=np.float32)
+        l, r = p.process(lr[0::2], lr[1::2])
+        exp += [l, r]
+    exp = np.concatenate(exp)
+    assert np.max(np.abs(got - exp)) <= 2e-7
