@@ -141,13 +141,20 @@ __global__ void __launch_bounds__(kThreads) aw_fused_ols_kernel(TileParams p, lo
 
 static int g_persistent_wgs = 256;      // one resident workgroup per CU (152 KB LDS each)
 
-template <int CS>
+// Windows [tile_lo, tile_hi) of every stream lie inside the call's input (INTERIOR), the others touch the
+// history or the zero page.  p.tile_lo/hi carry the window range here.
+template <int CS, bool INTERIOR>
 __global__ void __launch_bounds__(kThreads) aw_part_forward_kernel(TileParams p, long long nwg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
     const long long id = xcd_remap((long long)blockIdx.x, nwg);
     const int n_windows = p.n_blocks + p.partitions - 1;
-    tile_part_forward<GpuCtx, CS>(ctx, p, id / n_windows, (int)(id % n_windows));
+    const int per = INTERIOR ? p.tile_hi - p.tile_lo : n_windows - (p.tile_hi - p.tile_lo);
+    const long long stream = id / per;
+    int w = (int)(id - stream * per);
+    if (INTERIOR) w += p.tile_lo;
+    else if (w >= p.tile_lo) w += p.tile_hi - p.tile_lo;
+    tile_part_forward<GpuCtx, CS, INTERIOR>(ctx, p, stream, w);
 }
 
 // grid = (N / kCmacThreads, block groups, streams): one thread per bin of kCmacBlocks consecutive blocks
@@ -199,11 +206,14 @@ hipError_t prepare_kernels() {
 #undef AW_SET_BVEC
 #undef AW_SET_VEC
 #undef AW_SET_GEN
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_forward_kernel<8>),
+#define AW_SET_FWD(CS, NP)                                                                              \
+    if (e == hipSuccess)                                                                                \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_forward_kernel<CS, true>),      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    AW_FOR_EACH_VEC(AW_SET_FWD)
+#undef AW_SET_FWD
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_forward_kernel<0>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_forward_kernel<0, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_inverse_kernel),
@@ -291,14 +301,32 @@ hipError_t launch_fused_ols(const TileParams &p_in, int n_streams, hipStream_t s
     return hipGetLastError();
 }
 
-hipError_t launch_part_forward(const TileParams &p, int n_streams, hipStream_t stream) {
-    const long long nwg = (long long)n_streams * (p.n_blocks + p.partitions - 1);
-    if (nwg <= 0) return hipSuccess;
-    if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (p.n_channels == 8)
-        hipLaunchKernelGGL(aw_part_forward_kernel<8>, dim3((unsigned)nwg), dim3(kThreads), kLdsBytes, stream, p, nwg);
-    else
-        hipLaunchKernelGGL(aw_part_forward_kernel<0>, dim3((unsigned)nwg), dim3(kThreads), kLdsBytes, stream, p, nwg);
+hipError_t launch_part_forward(const TileParams &p_in, int n_streams, hipStream_t stream) {
+    TileParams p = p_in;
+    const int n_windows = p.n_blocks + p.partitions - 1;
+    if ((long long)n_streams * n_windows <= 0) return hipSuccess;
+    // window w covers frames [(w - P) B, (w - P) B + N): interior iff it starts at >= 0 and ends inside the input
+    // (one frame of slack for layouts whose frames are not whole float4s, see load_batch)
+    const long long usable = p.frames - ((p.n_channels % 4 != 0 && p.n_channels != 2) ? 1 : 0);
+    long long lo = p.partitions;
+    long long hi = usable >= kN ? (usable - kN) / p.hop + p.partitions + 1 : lo;
+    if (hi > n_windows) hi = n_windows;
+    if (lo > n_windows) lo = n_windows;
+    if (hi < lo) hi = lo;
+    if (!has_vec_variant(p.n_channels)) hi = lo;
+    p.tile_lo = (int)lo; p.tile_hi = (int)hi;
+    const long long n_int = (long long)n_streams * (hi - lo), n_bnd = (long long)n_streams * (n_windows - (hi - lo));
+    if (n_int > 0x7fffffffLL || n_bnd > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (n_int > 0) {
+        switch (p.n_channels) {
+#define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_part_forward_kernel<CS, true>), dim3((unsigned)n_int), dim3(kThreads), kLdsBytes, stream, p, n_int); break;
+            AW_FOR_EACH_VEC(AW_CASE)
+#undef AW_CASE
+            default: break;
+        }
+    }
+    if (n_bnd > 0)
+        hipLaunchKernelGGL((aw_part_forward_kernel<0, false>), dim3((unsigned)n_bnd), dim3(kThreads), kLdsBytes, stream, p, n_bnd);
     return hipGetLastError();
 }
 

@@ -462,7 +462,8 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
 // ---- partitioned path (taps too long for one window: Y[b] = sum_q X[b-q] . H_q, the same
 // frequency-domain delay line as ConvolutionEngine.swift:256-350 with B = N/2 = 4096) -----------
 // Kernel 1: spectra of one input window for every pair -> global scratch.
-template <class Ctx, int CS>
+// INTERIOR: the window lies inside the call's input (whole-frame vector loads off a uniform base).
+template <class Ctx, int CS, bool INTERIOR>
 AW_HD void tile_part_forward(Ctx &ctx, const TileParams &p, long long stream, int widx) {
     const int t = ctx.tid();
     const int lane = ctx.lane(), wave = ctx.wave();
@@ -478,7 +479,7 @@ AW_HD void tile_part_forward(Ctx &ctx, const TileParams &p, long long stream, in
     cf *spec_w = p.spec + ((stream * n_windows + widx) * p.n_pairs) * (long long)kN;
 
     float raw[16][kBatchCh];
-    load_batch<CS, false>(p, in_s, hist_s, f0, t, 0, raw);
+    load_batch<CS, INTERIOR>(p, in_s, hist_s, f0, t, 0, raw);
     const cf w1 = p.tw1[t];
     twa[t] = p.twa[t];
     if (t < kTwbElems) twb[t] = p.twb[t];
@@ -497,6 +498,8 @@ AW_HD void tile_part_forward(Ctx &ctx, const TileParams &p, long long stream, in
             for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][2], raw[j][3]);
             pair_pass1(x, pw, buf1, t);
         }
+        // the next batch's frames travel while this batch's sub-FFTs run (no accumulators or tables live here)
+        if (more) load_batch<CS, INTERIOR>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
         ctx.barrier();
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -515,7 +518,6 @@ AW_HD void tile_part_forward(Ctx &ctx, const TileParams &p, long long stream, in
 #pragma unroll
                 for (int kc = 0; kc < 8; ++kc) dst[wave_row(wave, s) * kSub + lane + 64 * kc] = z[s][kc];
         }
-        if (more) load_batch<CS, false>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
     }
 }
 

@@ -161,7 +161,20 @@ int emu_partitioned(const float *in, float *out, const float *hist, const float 
                 for (auto &x : th) x.join();
             }
     };
-    run([&](EmuCtx &ctx, int s, int w) { tile_part_forward<EmuCtx, 0>(ctx, p, s, w); }, n_windows);
+    {   // interior / boundary split of awk::launch_part_forward (vector variants exist for 7 and 8 channels here)
+        const long long usable = frames - ((n_channels % 4 != 0 && n_channels != 2) ? 1 : 0);
+        long long lo = P, hi = usable >= kN ? (usable - kN) / B + P + 1 : lo;
+        if (hi > n_windows) hi = n_windows;
+        if (lo > n_windows) lo = n_windows;
+        if (hi < lo) hi = lo;
+        if (n_channels != 7 && n_channels != 8) hi = lo;
+        run([&](EmuCtx &ctx, int s, int w) {
+            if (w >= lo && w < hi) {
+                if (n_channels == 7) tile_part_forward<EmuCtx, 7, true>(ctx, p, s, w);
+                else tile_part_forward<EmuCtx, 8, true>(ctx, p, s, w);
+            } else tile_part_forward<EmuCtx, 0, false>(ctx, p, s, w);
+        }, n_windows);
+    }
     std::vector<cf> wspec((size_t)n_streams * p.n_blocks * kN);
     p.wspec = wspec.data();
     for (int s = 0; s < n_streams; ++s)                       // kernel 2: one "thread" per bin and block group

@@ -60,3 +60,16 @@ def test_emulated_partitioned_long_hrir(oracle, golden_dir):
     y = emu.partitioned(x, h, g["left_track"], g["right_track"])
     assert not np.isnan(y).any()
     assert oracle.peak_rel_error(y[0], g["expected"]) < TOL
+
+
+@pytest.mark.parametrize("channels", [7, 8])
+def test_emulated_partitioned_interior_windows(oracle, channels):
+    """Long enough for interior windows of the forward kernel (whole-frame vector loads; 7-channel frames run into
+    the next frame) next to the boundary ones; 9000 taps = 3 partitions."""
+    h = oracle.synth_hrir(14, 9000, seed=5)
+    lt = (np.arange(channels) % 14).astype(np.int32)
+    rt = ((np.arange(channels) + 7) % 14).astype(np.int32)
+    x = oracle.synth_input(1, 13001, channels, seed=channels)
+    y = emu.partitioned(x, h, lt, rt)
+    assert not np.isnan(y).any()
+    assert oracle.peak_rel_error(y[0], oracle.spatialize_f64(x[0], h, lt, rt)) < TOL
