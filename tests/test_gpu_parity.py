@@ -249,3 +249,61 @@ def test_partitioned_path_lengths_chunks_and_state(aw, oracle, taps, channels, m
         pos += n
     assert pos == F
     assert np.max(np.abs(np.concatenate(parts, axis=1) - whole)) <= 3e-6 * np.abs(whole).max()
+
+
+def test_cfg4_shaped_chain_properties(aw, oracle, golden_dir):
+    """BASELINE cfg 4 shape at a reduced batch (96 kHz, 7 speakers, StageSH1.0 resampled x2 = 8640 taps ->
+    partitioned path, then the 10-band EQ in place on the same stream): spot streams against the oracle chain
+    (float64 convolution truth -> sequential Float64 EQ), split-call invariance of the whole chain, linearity."""
+    import torch
+    S, F, C, fs = 96, 200001, 7, 96000.0
+    ctx = aw.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    w = wav(oracle, golden_dir, "StageSH1.0.wav")
+    spk = ["FL", "FR", "FC", "BL", "BR", "SL", "SR"]
+    tracks, lt, rt = oracle.assemble_tracks(w, spk, target_rate=fs)
+    assert tracks.shape[1] == 8640
+    d = aw.EqualizerAPOParser.parse(open(os.path.join(golden_dir, "eq", "CCA CRA ParametricEq.txt"), "rb").read(), "f.txt")
+    od = oracle.eq_parse(open(os.path.join(golden_dir, "eq", "CCA CRA ParametricEq.txt"), "rb").read(), "f.txt")
+
+    def chain():
+        sp = aw.Spatializer(aw.HRIR(tracks, fs, ctx=ctx), lt, rt, n_streams=S, ctx=ctx)
+        return sp, aw.ParametricEqualizerState(d, fs, n_streams=S, ctx=ctx)
+
+    x = torch.empty((S, F, C), dtype=torch.float32, device="cuda")
+    ctx.synth_fill(x.data_ptr(), S, F, C, seed=4)
+    sp, eq = chain()
+    assert sp.info()["path"] == 1 and sp.info()["partitions"] == 3
+    y = torch.empty((S, F, 2), dtype=torch.float32, device="cuda")
+    sp.process_device(x.data_ptr(), y.data_ptr(), F)
+    eq.process_device(y.data_ptr(), y.data_ptr(), F)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    n = 30000
+    for s in (0, 47, 95):
+        xs = x[s, :n].cpu().numpy()
+        conv = oracle.spatialize_f64(xs, tracks, lt, rt).astype(np.float32)
+        el, er = oracle.eq_prepare(od, fs).process(conv[:, 0], conv[:, 1])
+        got = y[s, :n].cpu().numpy()
+        assert oracle.peak_rel_error(got, np.stack([el, er], axis=1)) < TOL
+    # the same timeline in two ragged calls continues both stages exactly
+    sp2, eq2 = chain()
+    cut = 77777
+    a, b = x[:, :cut].contiguous(), x[:, cut:].contiguous()
+    ya = torch.empty((S, cut, 2), dtype=torch.float32, device="cuda")
+    yb = torch.empty((S, F - cut, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for xi, yi, ni in ((a, ya, cut), (b, yb, F - cut)):
+        sp2.process_device(xi.data_ptr(), yi.data_ptr(), ni)
+        eq2.process_device(yi.data_ptr(), yi.data_ptr(), ni)
+    torch.cuda.synchronize()
+    peak = float(y.abs().max())
+    assert float((torch.cat([ya, yb], 1) - y).abs().max()) <= 2e-6 * peak
+    # linearity of the chain
+    sp3, eq3 = chain()
+    x.mul_(-0.5)
+    y3 = torch.empty_like(y)
+    torch.cuda.synchronize()
+    sp3.process_device(x.data_ptr(), y3.data_ptr(), F)
+    eq3.process_device(y3.data_ptr(), y3.data_ptr(), F)
+    torch.cuda.synchronize()
+    assert float((y3 + 0.5 * y).abs().max()) <= 2e-6 * peak
