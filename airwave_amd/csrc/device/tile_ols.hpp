@@ -528,7 +528,10 @@ AW_HD void tile_part_forward(Ctx &ctx, const TileParams &p, long long stream, in
 // the kernel reads (R+P-1)/R windows and P/R table sets instead of P and P (R = kCmacBlocks).  All
 // loads of a (pair, partition chunk) step are independent, and without LDS the kernel runs at full
 // occupancy — the fused CMAC+inverse kernel it replaces was load-latency bound at 8 waves per CU.
-constexpr int kCmacBlocks = 4;
+#ifndef AW_CMAC_BLOCKS
+#define AW_CMAC_BLOCKS 8      // measured cfg 4 / cfg 3 Gframes/s: 2 -> 11.8 / 10.1, 4 -> 13.4 / 12.4, 8 -> 13.8 / 13.4, 12 -> 13.8 / 13.8, 16 -> 13.5 / 13.6
+#endif
+constexpr int kCmacBlocks = AW_CMAC_BLOCKS;
 constexpr int kCmacQ = 8;
 constexpr int kCmacThreads = 256;
 
