@@ -8,6 +8,8 @@
 A "step" = one pass of the hot path (aw_spatializer_process through the C ABI) over one batch of
 synthetic input already resident in HBM.  Default workload = BASELINE.json configs[1] (cfg 2):
 128 streams x 10 s @ 48 kHz of 7.1 (8-ch) input -> RoomSH1.0 14-track HeSuVi HRIR -> stereo.
+The other BASELINE configs are parity-test cases; `--workload cfg3|cfg4|cfg5` benches them on request
+(long-tap partitioned path; 96 kHz + parametric EQ; mixed-rate buckets).
 Streams are independent, so N GPUs = N ranks each owning its own 128-stream batch (weak scaling,
 no data-path collective); RCCL carries only the final aggregate.  One JSON line on rank 0.
 """
@@ -248,7 +250,7 @@ def main() -> None:
             eq_ms = sum(a.elapsed_time(b) for a, b in eq_events) / args.steps
             result["roofline"]["eq_kernel_ms_per_step"] = eq_ms
             result["roofline"]["eq_achieved_GBs"] = 16.0 * frames_step / (eq_ms * 1e-3) / 1e9      # 8 B in + 8 B out per frame
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is reported at N = 1 only
             ns = max(1, min(g0["n"], args.cpu_sample_streams))
             Fc = g0["F"] if args.workload in ("cfg1", "cfg2") else min(g0["F"], int(g0["rate"]))     # long-tap configs: 1 s per stream
             x_host = g0["x"][:ns, :Fc].cpu().numpy()
