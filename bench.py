@@ -125,9 +125,16 @@ def main() -> None:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # Debug overrides (a 1-GPU box can still exercise the N > 1 code path: AW_BENCH_DEVICE=0 AW_BENCH_BACKEND=gloo).
+    if "AW_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["AW_BENCH_DEVICE"])
+    backend = os.environ.get("AW_BENCH_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import airwave_amd as aw
     from airwave_amd.sharding import aggregate_throughput, weak_shard
@@ -194,7 +201,8 @@ def main() -> None:
     frames_step = sum(g["n"] * g["F"] for g in legs)
 
     # RCCL over xGMI: the only collective of the run (sum of frames, max of elapsed)
-    frames_total, elapsed_max, _ = aggregate_throughput(float(frames_step) * args.steps, elapsed, device="cuda")
+    frames_total, elapsed_max, _ = aggregate_throughput(float(frames_step) * args.steps, elapsed,
+                                                             device="cuda" if backend == "nccl" else "cpu")
 
     if rank == 0:
         bytes_per_frame = 4 * C + 8                      # PCM in + stereo out
