@@ -307,3 +307,18 @@ def test_cfg4_shaped_chain_properties(aw, oracle, golden_dir):
     eq3.process_device(y3.data_ptr(), y3.data_ptr(), F)
     torch.cuda.synchronize()
     assert float((y3 + 0.5 * y).abs().max()) <= 2e-6 * peak
+
+
+def test_cfg1_full_length_against_the_cpu_reference_port(aw, oracle, golden_dir):
+    """BASELINE cfg 1 (the reference's own CPU-runnable case) at its full size: 1 stream, stereo, 10 s at 48 kHz
+    through NeutralSH1.0 — every one of the 480 000 output frames against the float32 port of the reference
+    algorithm (B = 512 blocks) and against the float64 truth."""
+    w = wav(oracle, golden_dir, "NeutralSH1.0.wav")
+    tracks, lt, rt = oracle.assemble_tracks(w, ["FL", "FR"])
+    x = oracle.synth_input(1, 480000, 2)
+    sp = aw.Spatializer(aw.HRIR(tracks), lt, rt, n_streams=1)
+    y = sp.process(x)[0]
+    port = oracle.spatialize_f32(x, tracks, lt, rt)[0]
+    truth = oracle.spatialize_f64(x[0], tracks, lt, rt)
+    assert oracle.peak_rel_error(y, port) < TOL and oracle.peak_rel_error(y, truth) < TOL
+    assert oracle.peak_rel_error(port, truth) < TOL          # the port itself sits inside the same budget
