@@ -169,6 +169,34 @@ __global__ void __launch_bounds__(kThreads) aw_part_inverse_kernel(TileParams p,
     tile_part_inverse<GpuCtx>(ctx, p, id / p.n_blocks, (int)(id % p.n_blocks));
 }
 
+// The 16384-frame window path (tile_ols2.hpp).  CS = real channels, NB = batches of four pseudo-channels.
+template <int CS, int NB, bool INTERIOR>
+__global__ void __launch_bounds__(kThreads) aw_fused_ols2_kernel(TileParams p, long long n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
+    const long long g = gridDim.x, b = blockIdx.x;
+    const long long xcd = b % 8, slot = b / 8;
+    const long long per_xcd_wg = (g - xcd + 7) / 8;
+    const long long q = n_tiles / 8, r = n_tiles % 8;
+    const long long lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const long long hi = lo + (xcd < r ? q + 1 : q);
+    tiles_fused_ols2<GpuCtx, CS, NB, INTERIOR>(ctx, p, lo + slot, per_xcd_wg, hi);
+}
+// (real channels, batches): 2C pseudo-channels in batches of four
+#define AW_FOR_EACH_VEC2(X) X(2, 1) X(4, 2) X(6, 3) X(7, 4) X(8, 4)
+
+const char *fused_ols2_kernel_name(int C) {
+    switch (C) {
+        case 2: return "aw_fused_ols2_kernel<2, 1, true>";
+        case 4: return "aw_fused_ols2_kernel<4, 2, true>";
+        case 6: return "aw_fused_ols2_kernel<6, 3, true>";
+        case 7: return "aw_fused_ols2_kernel<7, 4, true>";
+        case 8: return "aw_fused_ols2_kernel<8, 4, true>";
+        default: return "aw_fused_ols2_kernel<0, 0, false>";
+    }
+}
+static bool has_vec2_variant(int C) { return C == 2 || C == 4 || C == 6 || C == 7 || C == 8; }
+
 // Kernel variants.  Vectorised interior kernels <CS, NP, true> exist for the channel counts whose
 // frames are whole float4s/float2s (2, 4, 8, 12, 16 channels: stereo ... 7.1.4 + 4); every other
 // case — the few boundary tiles of those, and all tiles of the other channel counts — runs the
@@ -203,6 +231,15 @@ hipError_t prepare_kernels() {
     AW_FOR_EACH_VEC(AW_SET_VEC)
     AW_FOR_EACH_GEN(AW_SET_GEN)
     AW_FOR_EACH_BVEC(AW_SET_BVEC)
+#define AW_SET_VEC2(CS, NB)                                                                          \
+    if (e == hipSuccess)                                                                             \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols2_kernel<CS, NB, true>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    AW_FOR_EACH_VEC2(AW_SET_VEC2)
+#undef AW_SET_VEC2
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols2_kernel<0, 0, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
 #undef AW_SET_BVEC
 #undef AW_SET_VEC
 #undef AW_SET_GEN
@@ -296,6 +333,42 @@ hipError_t launch_fused_ols(const TileParams &p_in, int n_streams, hipStream_t s
         pb.dbg = nullptr;                 // diagnostic stamps describe the interior launch only
         if (ev0 && !dom_int) (void)hipEventRecord(ev0, stream);
         launch_gen(pb, n_bnd, stream);
+        if (ev1 && !dom_int) (void)hipEventRecord(ev1, stream);
+    }
+    return hipGetLastError();
+}
+
+// 16384-frame windows: same interior / boundary split, in real frames.
+hipError_t launch_fused_ols2(const TileParams &p_in, int n_streams, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
+                             long long *dominant_tiles) {
+    TileParams p = p_in;
+    long long lo = (p.hist_len + p.hop - 1) / p.hop;
+    const long long usable = p.frames - (((2 * p.n_channels) % 4 != 0) ? 1 : 0);
+    long long hi = (usable - kN2 + p.hist_len) >= 0 ? (usable - kN2 + p.hist_len) / p.hop + 1 : 0;
+    if (hi > p.tiles_per_stream) hi = p.tiles_per_stream;
+    if (hi < lo) hi = lo;
+    if (lo > p.tiles_per_stream) { lo = p.tiles_per_stream; hi = lo; }
+    if (!has_vec2_variant(p.n_channels)) { lo = 0; hi = 0; }
+    p.tile_lo = (int)lo; p.tile_hi = (int)hi;
+    const long long n_int = (long long)n_streams * (hi - lo);
+    const long long n_bnd = (long long)n_streams * (p.tiles_per_stream - (hi - lo));
+    if (n_int > 0x7fffffffLL || n_bnd > 0x7fffffffLL) return hipErrorInvalidValue;
+    const bool dom_int = n_int > 0;
+    if (dominant_tiles) *dominant_tiles = dom_int ? n_int : n_bnd;
+    if (n_int > 0) {
+        const dim3 grid = persistent_grid(n_int), block(kThreads);
+        if (ev0) (void)hipEventRecord(ev0, stream);
+        switch (p.n_channels) {
+#define AW_CASE(CS, NB) case CS: hipLaunchKernelGGL((aw_fused_ols2_kernel<CS, NB, true>), grid, block, kLdsBytes, stream, p, n_int); break;
+            AW_FOR_EACH_VEC2(AW_CASE)
+#undef AW_CASE
+            default: break;
+        }
+        if (ev1) (void)hipEventRecord(ev1, stream);
+    }
+    if (n_bnd > 0) {
+        if (ev0 && !dom_int) (void)hipEventRecord(ev0, stream);
+        hipLaunchKernelGGL((aw_fused_ols2_kernel<0, 0, false>), persistent_grid(n_bnd), dim3(kThreads), kLdsBytes, stream, p, n_bnd);
         if (ev1 && !dom_int) (void)hipEventRecord(ev1, stream);
     }
     return hipGetLastError();

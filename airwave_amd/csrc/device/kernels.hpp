@@ -4,7 +4,7 @@
 
 #include <cstdint>
 
-#include "tile_ols.hpp"
+#include "tile_ols2.hpp"
 
 namespace awk {
 
@@ -15,6 +15,10 @@ namespace awk {
 hipError_t launch_fused_ols(const TileParams &p, int n_streams, hipStream_t stream, hipEvent_t ev0 = nullptr,
                             hipEvent_t ev1 = nullptr, long long *dominant_tiles = nullptr);
 const char *fused_ols_kernel_name(int n_channels);
+// 16384-frame windows (tile_ols2.hpp); p.hop / p.hist_len in real frames, p.tab = cf4 tables, p.n_pairs = pseudo-pairs.
+hipError_t launch_fused_ols2(const TileParams &p, int n_streams, hipStream_t stream, hipEvent_t ev0 = nullptr,
+                             hipEvent_t ev1 = nullptr, long long *dominant_tiles = nullptr);
+const char *fused_ols2_kernel_name(int n_channels);
 
 // Partitioned (long-HRIR) path: window spectra -> scratch; per-bin CMAC over partitions for groups of
 // consecutive blocks -> W scratch; inverse transform of every block's W.

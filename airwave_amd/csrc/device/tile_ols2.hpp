@@ -1,0 +1,235 @@
+// tile_ols2.hpp — overlap-save on 16384-frame windows through the 8192-point machinery of tile_ols.hpp.
+//
+// A window of N2 = 16384 frames makes one tile emit hop = N2 - taps new frames instead of N - (taps-1)
+// of 8192 (12064 against 3873 for the bundled 4320-tap HRIRs: 74 % of every transform is new output
+// instead of 47 %), but an N2-point exchange buffer plus accumulators does not fit a CU.  Polyphase form:
+// two consecutive frames are ONE frame of a signal at half the rate with twice the channels,
+//     [frames][C]  ==  [frames/2][2C]           (same bytes; pseudo-channel c' = parity * C + c)
+// and the stereo output at the full rate is four output channels at half the rate,
+//     u_e[m] = y_L[2m] + i y_R[2m],   u_o[m] = y_L[2m+1] + i y_R[2m+1],
+// each of which is a sum over pseudo-channels of half-rate convolutions with the polyphase components of
+// the HRIRs (host/tables.cpp: build_poly_tables).  So a tile is: the 2C pseudo-channels in pairs through
+// the SAME forward transform (pass 1 + per-wave 512-point sub-FFTs), every pair accumulated into TWO
+// spectra W_e, W_o with two table sets, two inverse transforms, and the results interleaved back into
+// full-rate frames (16 bytes per thread and j: frames 2m and 2m+1).  The window is 8192 half-rate frames.
+#pragma once
+#include "tile_ols.hpp"
+
+namespace awk {
+
+constexpr int kN2 = 2 * kN;                      // full-rate frames per window
+
+struct alignas(16) cf4 {                         // one table entry of the two-output path: {A,B} for u_e, {A,B} for u_o
+    cf2 e, o;
+};
+
+// Pseudo-frame batch: thread t, j -> half-rate frame m = t + 512 j = full-rate frames f0 + 2m, f0 + 2m + 1;
+// four consecutive pseudo-channels starting at c0 (multiple of 4) of that 2C-float pseudo-frame.
+template <int CS, bool INTERIOR>
+AW_HD void load_batch2(const TileParams &p, const float *in_s, const float *hist_s, long long f0, int t, int c0,
+                       float (&raw)[16][kBatchCh]) {
+    const int C = CS > 0 ? CS : p.n_channels;
+    if constexpr (INTERIOR && CS > 0) {
+        const float *lane_base = in_s + f0 * CS + c0;          // uniform
+        const int lane_off = t * 2 * CS;                        // per lane, 32-bit
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float *src = lane_base + (long long)j * 512 * 2 * CS + lane_off;
+            // dword-aligned 16-byte load (frames of an odd stream offset are only 8-byte aligned); lanes past the
+            // 2C floats of the pseudo-frame belong to phantom pseudo-channels whose tables are zero
+            const f4u v = *reinterpret_cast<const f4u *>(src);
+            raw[j][0] = v.x; raw[j][1] = v.y; raw[j][2] = v.z; raw[j][3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const long long fe = f0 + 2 * (long long)(t + 512 * j);
+#pragma unroll
+            for (int c = 0; c < kBatchCh; ++c) {
+                const int cp = c0 + c;                           // pseudo-channel
+                const int par = cp >= C ? 1 : 0;
+                const int ch = cp - par * C;
+                const long long f = fe + par;
+                const float *src = f < 0 ? hist_s + ((long long)p.hist_len + f) * C + ch : in_s + f * C + ch;
+                if (cp >= 2 * C || f >= p.frames) src = p.zeros;
+                raw[j][c] = *src;
+            }
+        }
+    }
+}
+
+// pass 1 with the twiddle powers formed on the fly from w, w^2, w^4, w^8 (8 VGPRs instead of the 30 of the
+// product tree held across the butterfly; depth <= 4 multiplications per power as in the tree).
+AW_HD void pair_pass1_lean(cf (&x)[16], cf w, cf *buf, int t) {
+    fft16<false>(x);
+    const cf w2 = cmul(w, w), w4 = cmul(w2, w2), w8 = cmul(w4, w4);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) {
+        cf pw = (k1 & 8) ? w8 : mk(1.f, 0.f);
+        bool one = !(k1 & 8);
+        if (k1 & 4) { pw = one ? w4 : cmul(pw, w4); one = false; }
+        if (k1 & 2) { pw = one ? w2 : cmul(pw, w2); one = false; }
+        if (k1 & 1) { pw = one ? w : cmul(pw, w); one = false; }
+        x[k1] = cmul(x[k1], pw);
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) buf[k1 * kRowStride + t] = x[k1];
+}
+
+// One output set's table entries of one row: o = 0 (u_e) or 1 (u_o).
+AW_HD void load_tab2(const TileParams &p, int pair, int wave, int lane, int s, int o, cf2 (&tab)[8]) {
+    const cf2 *row = p.tab + (((long long)pair * kN + wave_row(wave, s) * kSub + lane) * 2 + o);
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) tab[kc] = row[64 * kc * 2];
+}
+
+// Per wave: the two 512-point sub-FFTs of its rows, then W_e, W_o += Z A + conj(Z[N-k]) B with their own tables.
+// One (row, output) at a time: 8 table entries (32 VGPRs) in flight instead of 32 entries — the accumulators of
+// this path already take 64 VGPRs.
+template <class Ctx>
+AW_HD void pair_subfft_cmac2(Ctx &ctx, const TileParams &p, int pair, cf *buf, const cf *twa, const cf *twb, int lane, int wave,
+                             cf (&we)[2][8], cf (&wo)[2][8]) {
+    cf *row0 = buf + wave_row(wave, 0) * kRowStride;
+    cf *row1 = buf + wave_row(wave, 1) * kRowStride;
+    cf z[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { z[0][j] = ctx.ld(row0 + lane + 64 * j); z[1][j] = ctx.ld(row1 + lane + 64 * j); }
+    ctx.wave_sync();
+    sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) { row0[lane + 64 * kc] = z[0][kc]; row1[lane + 64 * kc] = z[1][kc]; }
+    ctx.wave_sync();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const cf *prow = (wave == 0) ? (s == 0 ? row0 : row1) : (s == 0 ? row1 : row0);
+        const int bidx = 511 - lane + ((wave == 0 && s == 0) ? 1 : 0);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            cf2 tab[8];
+            load_tab2(p, pair, wave, lane, s, o, tab);
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                int idx = bidx - 64 * kc;
+                if (kc == 0) idx &= 511;
+                const cf zp = ctx.ld(prow + idx);
+                cf &w = o == 0 ? we[s][kc] : wo[s][kc];
+                w = cfma(z[s][kc], tab[kc].a, w);
+                w = cfmac(zp, tab[kc].b, w);
+            }
+        }
+    }
+    ctx.wave_sync();    // partner reads done before this wave reuses its rows as scratch
+}
+
+// Final pass of both inverse transforms: radix-16 across the rows of buf0 (u_e) and buf1 (u_o), then the
+// half-rate results interleaved into full-rate frames: window position 2m (+1) = frame f0 + 2m (+1).
+template <class Ctx, bool INTERIOR>
+AW_HD void tile_inverse_final2(Ctx &ctx, const TileParams &p, cf *buf0, cf *buf1, cf w1, int t, long long stream, long long f0,
+                               int first_valid) {
+    ctx.barrier();
+    cf ye[16], yo[16];
+    {
+        cf pw[16];
+        tw_powers(ctx.opaque(w1), pw);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) { ye[k1] = ctx.ld(buf0 + k1 * kRowStride + t); yo[k1] = ctx.ld(buf1 + k1 * kRowStride + t); }
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) { ye[k1] = cmulc(ye[k1], pw[k1]); yo[k1] = cmulc(yo[k1], pw[k1]); }
+    }
+    fft16<true>(ye);
+    fft16<true>(yo);
+    float *out_s = p.out + stream * p.frames * 2;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int n = 2 * (t + 512 * j);                 // window position of the even frame
+        const long long f = f0 + n;
+        if (n < first_valid) continue;                   // first_valid is even: both frames of the pair are new or neither
+        if (INTERIOR || f + 1 < p.frames) {
+            f4u v;
+            v.x = ye[j].x; v.y = ye[j].y; v.z = yo[j].x; v.w = yo[j].y;
+            *reinterpret_cast<f4u *>(out_s + f * 2) = v;
+        } else if (f < p.frames) {
+            *reinterpret_cast<cf *>(out_s + f * 2) = ye[j];
+        }
+    }
+}
+
+// Persistent tile loop, same shape as tiles_fused_ols.  CS: real channel count at compile time (0 = runtime),
+// NB: compile-time number of pseudo-channel batches (4 pseudo-channels = 2 pseudo-pairs each; 0 = runtime loop).
+// p.hop / p.hist_len / p.frames / f0 are in REAL frames; p.n_pairs = pseudo-pairs.
+template <class Ctx, int CS, int NB, bool INTERIOR>
+AW_HD void tiles_fused_ols2(Ctx &ctx, const TileParams &p, long long first, long long step, long long end) {
+    const int t0 = ctx.tid();
+    int t = t0, lane = ctx.lane();
+    const int wave = ctx.wave();
+    cf *buf0 = ctx.lds();
+    cf *buf1 = buf0 + kBufElems;
+    cf *twa = buf1 + kBufElems;
+    cf *twb = twa + kTwaElems;
+    const int Cn = CS > 0 ? CS : p.n_channels;
+    if (first >= end) return;
+    const cf w1 = p.tw1[t];
+    twa[t] = p.twa[t];
+    if (t < kTwbElems) twb[t] = p.twb[t];
+
+    float raw[16][kBatchCh];
+    {
+        const TileId id0 = tile_of<INTERIOR>(p, first);
+        load_batch2<CS, INTERIOR>(p, p.in + id0.stream * p.frames * Cn, p.hist + id0.stream * (long long)p.hist_len * Cn,
+                                  (long long)id0.tile * p.hop - p.hist_len, t, 0, raw);
+    }
+    for (long long id = first; id < end; id += step) {
+        t = ctx.opaque_i(t0);
+        lane = t & 63;
+        const TileId cur = tile_of<INTERIOR>(p, id);
+        const long long stream = cur.stream;
+        const float *in_s = p.in + stream * p.frames * Cn;
+        const float *hist_s = p.hist + stream * (long long)p.hist_len * Cn;
+        const long long f0 = (long long)cur.tile * p.hop - p.hist_len;     // real frame of window position 0
+
+        cf we[2][8], wo[2][8];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { we[s][i] = mk(0.f, 0.f); wo[s][i] = mk(0.f, 0.f); }
+
+        const int n_batches = NB > 0 ? NB : (p.n_pairs + 1) / 2;
+        auto batch = [&](int b, bool more) {
+            if (b > 0) ctx.barrier();                    // every wave is done reading buf0/buf1
+            t = ctx.opaque_i(t);                         // per-batch addresses are recomputed, not held across batches
+            lane = t & 63;
+            {
+                cf x[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][0], raw[j][1]);
+                pair_pass1_lean(x, ctx.opaque(w1), buf0, t);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][2], raw[j][3]);
+                pair_pass1_lean(x, ctx.opaque(w1), buf1, t);
+            }
+            ctx.barrier();
+            pair_subfft_cmac2(ctx, p, 2 * b, buf0, twa, twb, lane, wave, we, wo);
+            // the next batch's frames travel under the second pair's sub-FFTs
+            if (more) load_batch2<CS, INTERIOR>(p, in_s, hist_s, f0, t, 4 * (b + 1), raw);
+            pair_subfft_cmac2(ctx, p, 2 * b + 1, buf1, twa, twb, lane, wave, we, wo);   // a phantom pair hits the zero pair
+        };
+        if constexpr (NB > 0) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) batch(b, b + 1 < NB);
+        } else {
+            for (int b = 0; b < n_batches; ++b) batch(b, b + 1 < n_batches);
+        }
+
+        tile_inverse_rows(ctx, we, buf0, twa, twb);
+        tile_inverse_rows(ctx, wo, buf1, twa, twb);
+        {   // next tile's first batch (unconditional, see tiles_fused_ols)
+            const TileId nx = tile_of<INTERIOR>(p, id + step < end ? id + step : id);
+            load_batch2<CS, INTERIOR>(p, p.in + nx.stream * p.frames * Cn, p.hist + nx.stream * (long long)p.hist_len * Cn,
+                                      (long long)nx.tile * p.hop - p.hist_len, t, 0, raw);
+        }
+        tile_inverse_final2<Ctx, INTERIOR>(ctx, p, buf0, buf1, w1, t, stream, f0, p.hist_len);
+        ctx.barrier();
+    }
+}
+
+}  // namespace awk

@@ -83,4 +83,35 @@ void build_pair_tables(const float *tracks, int n_tracks, int taps, int n_channe
     }
 }
 
+void build_poly_tables(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
+                       const int32_t *right_track, std::vector<awk::cf4> &out) {
+    const int N = awk::kN;
+    const int Lh = taps / 2 + 1;
+    // polyphase bank [track][3][Lh]: 0: h[2j]   1: h[2j+1]   2: h[2j-1] (j >= 1)
+    std::vector<float> bank((size_t)n_tracks * 3 * Lh, 0.f);
+    for (int tr = 0; tr < n_tracks; ++tr) {
+        const float *h = tracks + (size_t)tr * taps;
+        float *he = &bank[((size_t)tr * 3 + 0) * Lh], *ho = he + Lh, *hd = ho + Lh;
+        for (int j = 0; j < Lh; ++j) {
+            if (2 * j < taps) he[j] = h[2 * j];
+            if (2 * j + 1 < taps) ho[j] = h[2 * j + 1];
+            if (j >= 1 && 2 * j - 1 < taps) hd[j] = h[2 * j - 1];
+        }
+    }
+    const int C2 = 2 * n_channels, n_pairs = (C2 + 1) / 2;
+    std::vector<awk::cf2> tab[2];
+    for (int o = 0; o < 2; ++o) {
+        std::vector<int32_t> l2(C2), r2(C2);
+        for (int cp = 0; cp < C2; ++cp) {
+            const int par = cp >= n_channels ? 1 : 0, c = cp - par * n_channels;
+            const int sel = o == 0 ? (par == 0 ? 0 : 2) : (par == 0 ? 1 : 0);
+            l2[cp] = left_track[c] < 0 || left_track[c] >= n_tracks ? -1 : left_track[c] * 3 + sel;
+            r2[cp] = right_track[c] < 0 || right_track[c] >= n_tracks ? -1 : right_track[c] * 3 + sel;
+        }
+        build_pair_tables(bank.data(), n_tracks * 3, Lh, C2, l2.data(), r2.data(), 0, Lh, tab[o]);
+    }
+    out.resize((size_t)n_pairs * N);
+    for (size_t i = 0; i < out.size(); ++i) { out[i].e = tab[0][i]; out[i].o = tab[1][i]; }
+}
+
 }  // namespace awh

@@ -7,7 +7,7 @@
 #include <cstdint>
 #include <vector>
 
-#include "../device/tile_ols.hpp"
+#include "../device/tile_ols2.hpp"
 
 namespace awh {
 
@@ -24,5 +24,14 @@ void build_twiddles(Twiddles &tw);
 void build_pair_tables(const float *tracks, int n_tracks, int taps, int n_channels,
                        const int32_t *left_track, const int32_t *right_track, int tap_offset,
                        int tap_count, std::vector<awk::cf2> &out);
+
+// Two-output (polyphase) tables of the 16384-frame window path (device/tile_ols2.hpp): the 2C pseudo-channels
+// (parity * C + channel) against the half-rate polyphase components of every HRIR,
+//   even outputs: even-frame channel -> h[2j],   odd-frame channel -> h[2j-1] (j >= 1)
+//   odd  outputs: even-frame channel -> h[2j+1], odd-frame channel -> h[2j]
+// laid out [pseudo-pair][k1][k2] of {A_e, B_e, A_o, B_o}.  Half-rate filter length = taps / 2 + 1.
+void build_poly_tables(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
+                       const int32_t *right_track, std::vector<awk::cf4> &out);
+inline int poly_history_frames(int taps) { return 2 * (taps / 2); }          // real frames kept between calls (= N2 - hop)
 
 }  // namespace awh

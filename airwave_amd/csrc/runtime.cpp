@@ -11,6 +11,11 @@
 
 #include "host/tables.hpp"
 
+// Default fused window: 8192 frames; 16384 (tile_ols2.hpp) where measurements favour it.
+#ifndef AW_DEFAULT_WINDOW
+#define AW_DEFAULT_WINDOW 8192
+#endif
+
 namespace awr {
 
 static thread_local std::string g_last_error;
@@ -223,7 +228,19 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
     sp->ctx = ctx; sp->n_channels = n_in; sp->n_pairs = (n_in + 1) / 2; sp->n_streams = n_streams;
     sp->taps = hrir->taps;
     const int N = awk::kN;
-    if (hrir->taps - 1 <= N - 2048) {
+    // Path choice.  AW_WINDOW=8192|16384 forces the fused window (tuning / A-B); default: see below.
+    int window = 0;
+    if (const char *e = getenv("AW_WINDOW")) window = atoi(e);
+    const int hist2 = awh::poly_history_frames(hrir->taps);          // 16384-frame windows (tile_ols2.hpp)
+    const bool fits1 = hrir->taps - 1 <= N - 2048, fits2 = hist2 <= awk::kN2 - 4096;
+    if (window == 0) window = AW_DEFAULT_WINDOW;
+    if ((window == awk::kN2 && fits2) || (!fits1 && fits2)) {
+        sp->path = 0; sp->fused2 = true;
+        sp->hist_len = hist2;
+        sp->hop = awk::kN2 - hist2;
+        sp->partitions = 1;
+        sp->n_pairs = (2 * n_in + 1) / 2;                            // pseudo-pairs of the half-rate 2C-channel view
+    } else if (fits1) {
         sp->path = 0;
         sp->hop = N - (hrir->taps - 1);
         sp->hist_len = N - sp->hop;
@@ -235,16 +252,24 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
         sp->hist_len = sp->partitions * sp->hop;
     }
     std::vector<awk::cf2> tab, all;
-    for (int q = 0; q < sp->partitions; ++q) {
-        const int off = sp->path == 0 ? 0 : q * sp->hop;
-        const int cnt = sp->path == 0 ? hrir->taps : sp->hop;
-        awh::build_pair_tables(hrir->tracks.data(), hrir->n_tracks, hrir->taps, n_in, left_track, right_track, off,
-                               cnt, tab);
-        all.insert(all.end(), tab.begin(), tab.end());
+    if (sp->fused2) {
+        std::vector<awk::cf4> t4;
+        awh::build_poly_tables(hrir->tracks.data(), hrir->n_tracks, hrir->taps, n_in, left_track, right_track, t4);
+        all.resize(t4.size() * 2);
+        std::memcpy(all.data(), t4.data(), t4.size() * sizeof(awk::cf4));
+        all.resize(all.size() + 2 * (size_t)awk::kN, awk::cf2{awk::mk(0.f, 0.f), awk::mk(0.f, 0.f)});   // the zero pair
+    } else {
+        for (int q = 0; q < sp->partitions; ++q) {
+            const int off = sp->path == 0 ? 0 : q * sp->hop;
+            const int cnt = sp->path == 0 ? hrir->taps : sp->hop;
+            awh::build_pair_tables(hrir->tracks.data(), hrir->n_tracks, hrir->taps, n_in, left_track, right_track, off,
+                                   cnt, tab);
+            all.insert(all.end(), tab.begin(), tab.end());
+        }
+        // fused path: one all-zero pair after the last one — a phantom pair (odd pair count in the runtime-loop
+        // kernels; stray lanes of non-float4 frames) multiplies it and contributes nothing
+        if (sp->path == 0) all.resize(all.size() + awk::kN, awk::cf2{awk::mk(0.f, 0.f), awk::mk(0.f, 0.f)});
     }
-    // fused path: one all-zero pair after the last one — a phantom pair (odd pair count in the runtime-loop
-    // kernels; stray lanes of non-float4 frames) multiplies it and contributes nothing
-    if (sp->path == 0) all.resize(all.size() + awk::kN, awk::cf2{awk::mk(0.f, 0.f), awk::mk(0.f, 0.f)});
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&sp->d_tab), all.size() * sizeof(awk::cf2));
     if (e == hipSuccess) e = hipMemcpy(sp->d_tab, all.data(), all.size() * sizeof(awk::cf2), hipMemcpyHostToDevice);
     if (e != hipSuccess) { aw_spatializer_destroy(sp); return awr::hip_fail(e, "filter tables"); }
@@ -281,7 +306,7 @@ int32_t aw_spatializer_channel_count(const aw_spatializer *sp) { return sp ? sp-
 int64_t aw_spatializer_info(const aw_spatializer *sp, int32_t what) {
     if (!sp) return -1;
     switch (what) {
-        case 0: return awk::kN;
+        case 0: return sp->fused2 ? awk::kN2 : awk::kN;
         case 1: return sp->hop;
         case 2: return sp->partitions;
         case 3: return sp->path;
@@ -323,7 +348,7 @@ int32_t aw_spatializer_kernel_time(aw_spatializer *sp, double *avg_ms, const cha
     }
     sp->pending.clear();
     if (avg_ms) *avg_ms = sp->kernel_launches ? sp->kernel_ms_sum / sp->kernel_launches : 0.0;
-    if (kernel_name) *kernel_name = sp->path == 0 ? awk::fused_ols_kernel_name(sp->n_channels) : "aw_part_forward_kernel + aw_part_cmac_kernel + aw_part_inverse_kernel";
+    if (kernel_name) *kernel_name = sp->path == 0 ? (sp->fused2 ? awk::fused_ols2_kernel_name(sp->n_channels) : awk::fused_ols_kernel_name(sp->n_channels)) : "aw_part_forward_kernel + aw_part_cmac_kernel + aw_part_inverse_kernel";
     const int n = sp->kernel_launches;
     sp->kernel_ms_sum = 0.0;
     sp->kernel_launches = 0;
@@ -378,7 +403,8 @@ static aw_status sp_process_fused(aw_spatializer *sp, const float *in, float *ou
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (sp->profiling) { e0 = sp_get_event(sp); e1 = sp_get_event(sp); }
     long long dom_tiles = 0;
-    AW_HIP_TRY(awk::launch_fused_ols(p, sp->n_streams, sp->ctx->stream, e0, e1, &dom_tiles));
+    if (sp->fused2) AW_HIP_TRY(awk::launch_fused_ols2(p, sp->n_streams, sp->ctx->stream, e0, e1, &dom_tiles));
+    else AW_HIP_TRY(awk::launch_fused_ols(p, sp->n_streams, sp->ctx->stream, e0, e1, &dom_tiles));
     // output frames the timed launch produced (tiles x hop, the last tile of a stream may be short)
     sp->dominant_frames = std::min<long long>(dom_tiles * (long long)sp->hop, (long long)sp->n_streams * frames);
     if (sp->profiling) sp->pending.emplace_back(e0, e1);

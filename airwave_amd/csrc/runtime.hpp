@@ -43,6 +43,7 @@ struct aw_spatializer {
     aw_context *ctx = nullptr;
     int n_channels = 0, n_pairs = 0, n_streams = 0, taps = 0;
     int path = 0;             // 0 fused single-partition overlap-save, 1 partitioned
+    bool fused2 = false;      // path 0 on 16384-frame windows (polyphase, two output spectra): device/tile_ols2.hpp
     int hop = 0, hist_len = 0, partitions = 1;
     awk::cf2 *d_tab = nullptr;          // [partitions][pairs][N]
     float *d_hist[2] = {nullptr, nullptr};

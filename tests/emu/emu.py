@@ -11,7 +11,7 @@ _DEFS = os.environ.get("AW_EMU_DEFINES", "").split()          # e.g. "-DAW_SUBFF
 _LIB = os.path.join(_HERE, "libemu.so" if not _DEFS else "libemu_variant.so")
 _SRCS = [os.path.join(_HERE, "emu_harness.cpp"), os.path.join(_ROOT, "airwave_amd/csrc/host/tables.cpp"),
          os.path.join(_ROOT, "airwave_amd/csrc/host/eq.cpp")]
-_DEPS = _SRCS + [os.path.join(_ROOT, "airwave_amd/csrc/device", f) for f in ("tile_ols.hpp", "cplx.hpp", "eq_cascade.hpp")] + [
+_DEPS = _SRCS + [os.path.join(_ROOT, "airwave_amd/csrc/device", f) for f in ("tile_ols.hpp", "tile_ols2.hpp", "cplx.hpp", "eq_cascade.hpp")] + [
     os.path.join(_ROOT, "airwave_amd/csrc/host/tables.hpp"), os.path.join(_ROOT, "airwave_amd/csrc/host/eq.hpp")]
 _lib = None
 
@@ -48,7 +48,7 @@ def fused_ols(x, tracks, left_track, right_track, hop=None, hist=None, variant=1
     h = None
     if hist is not None:
         h = np.ascontiguousarray(hist, dtype=np.float32)
-        assert h.shape == (S, 8192 - hop, C)
+        assert h.shape == ((S, 8192 - hop, C) if variant != 2 else (S, 2 * (tr.shape[1] // 2), C))
     rc = lib().emu_fused_ols(x.ctypes.data_as(fp), out.ctypes.data_as(fp), None if h is None else h.ctypes.data_as(fp),
                              tr.ctypes.data_as(fp), tr.shape[0], tr.shape[1], C, lt.ctypes.data_as(ip),
                              rt.ctypes.data_as(ip), F, S, hop, variant)

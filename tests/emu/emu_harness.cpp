@@ -55,10 +55,66 @@ extern "C" {
 
 // Builds tables + twiddles on the host and runs every tile of every stream through the emulated
 // workgroup.  Layouts as TileParams.  hist may be NULL (zeros).
+// The 16384-frame window path (tile_ols2.hpp): hop and history follow from the taps; hist is [stream][hist][C].
+static int emu_fused_ols2(const float *in, float *out, const float *hist, const float *tracks, int n_tracks, int taps,
+                          int n_channels, const int32_t *left_track, const int32_t *right_track, long long frames,
+                          int n_streams) {
+    using namespace awk;
+    awh::Twiddles tw;
+    awh::build_twiddles(tw);
+    std::vector<cf4> tab;
+    awh::build_poly_tables(tracks, n_tracks, taps, n_channels, left_track, right_track, tab);
+    tab.resize(tab.size() + kN, cf4{{mk(0, 0), mk(0, 0)}, {mk(0, 0), mk(0, 0)}});      // the zero pair
+    TileParams p{};
+    p.in = in; p.out = out; p.tab = reinterpret_cast<const cf2 *>(tab.data());
+    p.tw1 = tw.tw1.data(); p.twa = tw.twa.data(); p.twb = tw.twb.data(); p.zeros = g_zeros;
+    p.frames = frames; p.n_channels = n_channels; p.n_pairs = (2 * n_channels + 1) / 2;
+    p.hist_len = awh::poly_history_frames(taps); p.hop = kN2 - p.hist_len;
+    p.tiles_per_stream = (int)((frames + p.hop - 1) / p.hop);
+    std::vector<float> zero_hist;
+    if (!hist) { zero_hist.assign((size_t)n_streams * p.hist_len * n_channels + 4, 0.f); hist = zero_hist.data(); }
+    p.hist = hist;
+    const long long usable = frames - (((2 * n_channels) % 4 != 0) ? 1 : 0);
+    long long lo = (p.hist_len + p.hop - 1) / p.hop;
+    long long hi = (usable - kN2 + p.hist_len) >= 0 ? (usable - kN2 + p.hist_len) / p.hop + 1 : 0;
+    if (hi > p.tiles_per_stream) hi = p.tiles_per_stream;
+    if (hi < lo) hi = lo;
+    if (lo > p.tiles_per_stream) { lo = p.tiles_per_stream; hi = lo; }
+    const bool vec = n_channels == 2 || n_channels == 7 || n_channels == 8;
+    if (!vec) { lo = 0; hi = 0; }
+    p.tile_lo = (int)lo; p.tile_hi = (int)hi;
+    EmuShared sh;
+    auto run = [&](bool interior, long long n_tiles) {
+        const long long G = n_tiles < 3 ? n_tiles : 3;
+        for (long long g = 0; g < G; ++g) {
+            std::vector<std::thread> th;
+            th.reserve(kThreads);
+            for (int t = 0; t < kThreads; ++t)
+                th.emplace_back([&, t]() {
+                    EmuCtx ctx{t, &sh};
+                    if (interior) {
+                        switch (n_channels) {
+                            case 2: tiles_fused_ols2<EmuCtx, 2, 1, true>(ctx, p, g, G, n_tiles); break;
+                            case 7: tiles_fused_ols2<EmuCtx, 7, 4, true>(ctx, p, g, G, n_tiles); break;
+                            default: tiles_fused_ols2<EmuCtx, 8, 4, true>(ctx, p, g, G, n_tiles); break;
+                        }
+                    } else {
+                        tiles_fused_ols2<EmuCtx, 0, 0, false>(ctx, p, g, G, n_tiles);
+                    }
+                });
+            for (auto &x : th) x.join();
+        }
+    };
+    run(true, (long long)n_streams * (hi - lo));
+    run(false, (long long)n_streams * (p.tiles_per_stream - (hi - lo)));
+    return 0;
+}
+
 int emu_fused_ols(const float *in, float *out, const float *hist, const float *tracks, int n_tracks,
                   int taps, int n_channels, const int32_t *left_track, const int32_t *right_track,
                   long long frames, int n_streams, int hop, int variant) {
     using namespace awk;
+    if (variant == 2) return emu_fused_ols2(in, out, hist, tracks, n_tracks, taps, n_channels, left_track, right_track, frames, n_streams);
     if (hop <= 0 || hop > kN - (taps - 1)) return -1;
     awh::Twiddles tw;
     std::vector<cf2> tab;

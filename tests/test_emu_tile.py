@@ -73,3 +73,16 @@ def test_emulated_partitioned_interior_windows(oracle, channels):
     y = emu.partitioned(x, h, lt, rt)
     assert not np.isnan(y).any()
     assert oracle.peak_rel_error(y[0], oracle.spatialize_f64(x[0], h, lt, rt)) < TOL
+
+
+@pytest.mark.parametrize("channels,taps,frames", [(2, 300, 5000), (2, 4320, 40001), (8, 4320, 30011), (7, 4319, 29000), (5, 1001, 20000)])
+def test_emulated_16384_window_path(oracle, channels, taps, frames):
+    """tile_ols2.hpp: the polyphase (half-rate, 2C pseudo-channels, two output spectra) form of a 16384-frame window,
+    interior and boundary kernels, odd tap and frame counts."""
+    h = oracle.synth_hrir(14, taps, seed=3)
+    lt = (np.arange(channels) % 14).astype(np.int32)
+    rt = ((np.arange(channels) + 7) % 14).astype(np.int32)
+    x = oracle.synth_input(1, frames, channels, seed=channels)
+    y = emu.fused_ols(x, h, lt, rt, variant=2)
+    assert not np.isnan(y).any()
+    assert oracle.peak_rel_error(y[0], oracle.spatialize_f64(x[0], h, lt, rt)) < TOL

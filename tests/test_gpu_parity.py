@@ -228,23 +228,25 @@ def test_long_tap_partitioned_path(aw, oracle, golden_dir):
     assert oracle.peak_rel_error(sp.process(x)[0], g["expected"]) < TOL
 
 
-@pytest.mark.parametrize("taps,channels", [(6146, 2), (8640, 8), (12289, 5)])
-def test_partitioned_path_lengths_chunks_and_state(aw, oracle, taps, channels, monkeypatch):
-    """96 kHz-class HRIRs (cfg 4: 4320 taps resampled x2 = 8640) and stream chunking of the scratch."""
+@pytest.mark.parametrize("taps,channels,path,fft", [(6146, 2, 0, 16384), (8640, 8, 0, 16384), (12288, 7, 0, 16384),
+                                                    (12290, 5, 1, 8192), (20000, 3, 1, 8192)])
+def test_long_hrir_paths_chunks_and_state(aw, oracle, taps, channels, path, fft, monkeypatch):
+    """HRIRs beyond one 8192-frame window: up to 12288 taps (cfg 4: 4320 taps resampled x2 = 8640) run fused on
+    16384-frame windows, longer ones on the partitioned path (with stream chunking of its scratch)."""
     monkeypatch.setenv("AW_SPEC_SCRATCH_MB", "3")          # forces several stream chunks
     h = oracle.synth_hrir(14, taps, seed=taps)
     lt = np.array([0, 8, 6, 6, 4, 12, 2, 10][:channels], dtype=np.int32)
     rt = np.array([1, 7, 13, 13, 5, 11, 3, 9][:channels], dtype=np.int32)
-    S, F = 3, 10000
+    S, F = 3, 30000
     x = oracle.synth_input(S, F, channels, seed=21)
     sp = aw.Spatializer(aw.HRIR(h), lt, rt, n_streams=S)
-    assert sp.info()["path"] == 1
+    assert sp.info()["path"] == path and sp.info()["fft"] == fft
     whole = sp.process(x)
     for s in range(S):
         assert oracle.peak_rel_error(whole[s], oracle.spatialize_f64(x[s], h, lt, rt)) < TOL
     sp.reset()
     parts, pos = [], 0
-    for n in [1, 4095, 4097, 1000, 807]:
+    for n in [1, 4095, 4097, 1000, 807, 20000]:
         parts.append(sp.process(np.ascontiguousarray(x[:, pos:pos + n])))
         pos += n
     assert pos == F
@@ -253,7 +255,7 @@ def test_partitioned_path_lengths_chunks_and_state(aw, oracle, taps, channels, m
 
 def test_cfg4_shaped_chain_properties(aw, oracle, golden_dir):
     """BASELINE cfg 4 shape at a reduced batch (96 kHz, 7 speakers, StageSH1.0 resampled x2 = 8640 taps ->
-    partitioned path, then the 10-band EQ in place on the same stream): spot streams against the oracle chain
+    fused path on 16384-frame windows, then the 10-band EQ in place on the same stream): spot streams against the oracle chain
     (float64 convolution truth -> sequential Float64 EQ), split-call invariance of the whole chain, linearity."""
     import torch
     S, F, C, fs = 96, 200001, 7, 96000.0
@@ -272,7 +274,7 @@ def test_cfg4_shaped_chain_properties(aw, oracle, golden_dir):
     x = torch.empty((S, F, C), dtype=torch.float32, device="cuda")
     ctx.synth_fill(x.data_ptr(), S, F, C, seed=4)
     sp, eq = chain()
-    assert sp.info()["path"] == 1 and sp.info()["partitions"] == 3
+    assert sp.info()["path"] == 0 and sp.info()["fft"] == 16384 and sp.info()["hop"] == 16384 - 8640
     y = torch.empty((S, F, 2), dtype=torch.float32, device="cuda")
     sp.process_device(x.data_ptr(), y.data_ptr(), F)
     eq.process_device(y.data_ptr(), y.data_ptr(), F)

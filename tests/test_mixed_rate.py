@@ -34,8 +34,8 @@ def test_mixed_rate_batch_matches_truth_per_bucket(oracle, golden_dir):
     layout = aw.InputLayout(["FL", "FR", "FC", "BL", "BR", "SL", "SR"], "7 speakers")
     rates = [44100.0, 48000.0, 96000.0, 48000.0, 96000.0, 44100.0]
     batch = aw.MixedRateBatch(tr, 48000.0, layout, rates)
-    assert {r: (b.hrir_taps, b.spatializer.info()["path"]) for r, b in batch.buckets.items()} == {
-        44100.0: (3968, 0), 48000.0: (4320, 0), 96000.0: (8640, 1)}
+    assert {r: (b.hrir_taps, b.spatializer.info()["fft"]) for r, b in batch.buckets.items()} == {
+        44100.0: (3968, 8192), 48000.0: (4320, 8192), 96000.0: (8640, 16384)}
     frames = {44100.0: 9000, 48000.0: 10000, 96000.0: 12000}
     xs = [oracle.synth_input(1, frames[r], 7, seed=100 + i)[0] for i, r in enumerate(rates)]
     ys = batch.process(xs, rates)
