@@ -237,6 +237,12 @@ hipError_t prepare_kernels() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     AW_FOR_EACH_VEC2(AW_SET_VEC2)
 #undef AW_SET_VEC2
+#define AW_SET_BVEC2(CS, NB)                                                                          \
+    if (e == hipSuccess)                                                                              \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols2_kernel<CS, NB, false>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    AW_FOR_EACH_VEC2(AW_SET_BVEC2)
+#undef AW_SET_BVEC2
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols2_kernel<0, 0, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
@@ -368,7 +374,13 @@ hipError_t launch_fused_ols2(const TileParams &p_in, int n_streams, hipStream_t 
     }
     if (n_bnd > 0) {
         if (ev0 && !dom_int) (void)hipEventRecord(ev0, stream);
-        hipLaunchKernelGGL((aw_fused_ols2_kernel<0, 0, false>), persistent_grid(n_bnd), dim3(kThreads), kLdsBytes, stream, p, n_bnd);
+        const dim3 grid = persistent_grid(n_bnd), block(kThreads);
+        switch (p.n_channels) {      // compile-time channel and batch counts also for the boundary tiles (scalar loads)
+#define AW_CASE(CS, NB) case CS: hipLaunchKernelGGL((aw_fused_ols2_kernel<CS, NB, false>), grid, block, kLdsBytes, stream, p, n_bnd); break;
+            AW_FOR_EACH_VEC2(AW_CASE)
+#undef AW_CASE
+            default: hipLaunchKernelGGL((aw_fused_ols2_kernel<0, 0, false>), grid, block, kLdsBytes, stream, p, n_bnd); break;
+        }
         if (ev1 && !dom_int) (void)hipEventRecord(ev1, stream);
     }
     return hipGetLastError();

@@ -15,6 +15,10 @@
 #pragma once
 #include "tile_ols.hpp"
 
+#ifndef AW_OLS2_SPLIT
+#define AW_OLS2_SPLIT 4      // measured (cfg 2 on 16384 windows / cfg 4 kernel ms): 16 -> 2.17 / 9.1, 8 -> 2.17 / 9.1, 4 -> 1.85 / 7.5, 0 -> 1.83 / 7.9
+#endif
+
 namespace awk {
 
 constexpr int kN2 = 2 * kN;                      // full-rate frames per window
@@ -25,7 +29,8 @@ struct alignas(16) cf4 {                         // one table entry of the two-o
 
 // Pseudo-frame batch: thread t, j -> half-rate frame m = t + 512 j = full-rate frames f0 + 2m, f0 + 2m + 1;
 // four consecutive pseudo-channels starting at c0 (multiple of 4) of that 2C-float pseudo-frame.
-template <int CS, bool INTERIOR>
+// J0..J1: which of the thread's 16 pseudo-frames (a batch can be fetched in two halves to bound live registers).
+template <int CS, bool INTERIOR, int J0 = 0, int J1 = 16>
 AW_HD void load_batch2(const TileParams &p, const float *in_s, const float *hist_s, long long f0, int t, int c0,
                        float (&raw)[16][kBatchCh]) {
     const int C = CS > 0 ? CS : p.n_channels;
@@ -33,7 +38,7 @@ AW_HD void load_batch2(const TileParams &p, const float *in_s, const float *hist
         const float *lane_base = in_s + f0 * CS + c0;          // uniform
         const int lane_off = t * 2 * CS;                        // per lane, 32-bit
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = J0; j < J1; ++j) {
             const float *src = lane_base + (long long)j * 512 * 2 * CS + lane_off;
             // dword-aligned 16-byte load (frames of an odd stream offset are only 8-byte aligned); lanes past the
             // 2C floats of the pseudo-frame belong to phantom pseudo-channels whose tables are zero
@@ -42,7 +47,7 @@ AW_HD void load_batch2(const TileParams &p, const float *in_s, const float *hist
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = J0; j < J1; ++j) {
             const long long fe = f0 + 2 * (long long)(t + 512 * j);
 #pragma unroll
             for (int c = 0; c < kBatchCh; ++c) {
@@ -78,6 +83,11 @@ AW_HD void pair_pass1_lean(cf (&x)[16], cf w, cf *buf, int t) {
 
 // One output set's table entries of one row: o = 0 (u_e) or 1 (u_o).
 AW_HD void load_tab2(const TileParams &p, int pair, int wave, int lane, int s, int o, cf2 (&tab)[8]) {
+#ifdef AW_ABL_NOTAB      // timing ablation only (wrong results): no table traffic
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) { tab[kc].a = mk(1.0f + pair, 0.5f * lane + o); tab[kc].b = mk(0.25f * kc + s, 1.0f * wave); }
+    return;
+#endif
     const cf2 *row = p.tab + (((long long)pair * kN + wave_row(wave, s) * kSub + lane) * 2 + o);
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc) tab[kc] = row[64 * kc * 2];
@@ -209,9 +219,11 @@ AW_HD void tiles_fused_ols2(Ctx &ctx, const TileParams &p, long long first, long
             }
             ctx.barrier();
             pair_subfft_cmac2(ctx, p, 2 * b, buf0, twa, twb, lane, wave, we, wo);
-            // the next batch's frames travel under the second pair's sub-FFTs
-            if (more) load_batch2<CS, INTERIOR>(p, in_s, hist_s, f0, t, 4 * (b + 1), raw);
+            // the next batch's frames travel under the second pair's sub-FFTs, in two halves: all 16 pseudo-frames
+            // at once (64 VGPRs) on top of the 64 accumulator registers is what hipcc spills
+            if (more) load_batch2<CS, INTERIOR, 0, AW_OLS2_SPLIT>(p, in_s, hist_s, f0, t, 4 * (b + 1), raw);
             pair_subfft_cmac2(ctx, p, 2 * b + 1, buf1, twa, twb, lane, wave, we, wo);   // a phantom pair hits the zero pair
+            if (more) load_batch2<CS, INTERIOR, AW_OLS2_SPLIT, 16>(p, in_s, hist_s, f0, t, 4 * (b + 1), raw);
         };
         if constexpr (NB > 0) {
 #pragma unroll
