@@ -173,7 +173,8 @@ __global__ void __launch_bounds__(kThreads) aw_part_inverse_kernel(TileParams p,
 template <int CS, int NB, bool INTERIOR>
 __global__ void __launch_bounds__(kThreads) aw_fused_ols2_kernel(TileParams p, long long n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
+    GpuCtx ctx{reinterpret_cast<cf *>(smem), p.dbg ? p.dbg + (long long)blockIdx.x * kStamps : nullptr};
+    ctx.stamp_thread_ = p.stagger;
     const long long g = gridDim.x, b = blockIdx.x;
     const long long xcd = b % 8, slot = b / 8;
     const long long per_xcd_wg = (g - xcd + 7) / 8;
@@ -373,6 +374,7 @@ hipError_t launch_fused_ols2(const TileParams &p_in, int n_streams, hipStream_t 
         if (ev1) (void)hipEventRecord(ev1, stream);
     }
     if (n_bnd > 0) {
+        p.dbg = nullptr;                 // diagnostic stamps describe the interior launch only
         if (ev0 && !dom_int) (void)hipEventRecord(ev0, stream);
         const dim3 grid = persistent_grid(n_bnd), block(kThreads);
         switch (p.n_channels) {      // compile-time channel and batch counts also for the boundary tiles (scalar loads)

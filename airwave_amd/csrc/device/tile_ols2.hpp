@@ -15,6 +15,9 @@
 #pragma once
 #include "tile_ols.hpp"
 
+#ifndef AW_OLS2_TABPRE
+#define AW_OLS2_TABPRE 2     // table sets of a pair's first row issued before its sub-FFTs (0, 1 or 2)
+#endif
 #ifndef AW_OLS2_SPLIT
 #define AW_OLS2_SPLIT 4      // measured (cfg 2 on 16384 windows / cfg 4 kernel ms): 16 -> 2.17 / 9.1, 8 -> 2.17 / 9.1, 4 -> 1.85 / 7.5, 0 -> 1.83 / 7.9
 #endif
@@ -105,7 +108,16 @@ AW_HD void pair_subfft_cmac2(Ctx &ctx, const TileParams &p, int pair, cf *buf, c
 #pragma unroll
     for (int j = 0; j < 8; ++j) { z[0][j] = ctx.ld(row0 + lane + 64 * j); z[1][j] = ctx.ld(row1 + lane + 64 * j); }
     ctx.wave_sync();
+    // Row 0's table entries for both outputs are issued BEFORE the sub-FFTs (their L2 latency, ~2 k cycles each
+    // when exposed — phase stamps, tools/stamps2.py — hides under the three radix-8 passes); row 1's are issued
+    // into the same registers as soon as row 0's are consumed.  64 table VGPRs in flight at most.
+    cf2 ta[8], tb[8];
+    if (AW_OLS2_TABPRE >= 1) load_tab2(p, pair, wave, lane, 0, 0, ta);
+    if (AW_OLS2_TABPRE >= 2) load_tab2(p, pair, wave, lane, 0, 1, tb);
     sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
+    if (AW_OLS2_TABPRE < 1) load_tab2(p, pair, wave, lane, 0, 0, ta);
+    if (AW_OLS2_TABPRE < 2) load_tab2(p, pair, wave, lane, 0, 1, tb);
+    ctx.stamp(22);
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc) { row0[lane + 64 * kc] = z[0][kc]; row1[lane + 64 * kc] = z[1][kc]; }
     ctx.wave_sync();
@@ -113,22 +125,28 @@ AW_HD void pair_subfft_cmac2(Ctx &ctx, const TileParams &p, int pair, cf *buf, c
     for (int s = 0; s < 2; ++s) {
         const cf *prow = (wave == 0) ? (s == 0 ? row0 : row1) : (s == 0 ? row1 : row0);
         const int bidx = 511 - lane + ((wave == 0 && s == 0) ? 1 : 0);
+        cf zp[8];
 #pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            cf2 tab[8];
-            load_tab2(p, pair, wave, lane, s, o, tab);
-#pragma unroll
-            for (int kc = 0; kc < 8; ++kc) {
-                int idx = bidx - 64 * kc;
-                if (kc == 0) idx &= 511;
-                const cf zp = ctx.ld(prow + idx);
-                cf &w = o == 0 ? we[s][kc] : wo[s][kc];
-                w = cfma(z[s][kc], tab[kc].a, w);
-                w = cfmac(zp, tab[kc].b, w);
-            }
+        for (int kc = 0; kc < 8; ++kc) {
+            int idx = bidx - 64 * kc;
+            if (kc == 0) idx &= 511;
+            zp[kc] = ctx.ld(prow + idx);
         }
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            we[s][kc] = cfma(z[s][kc], ta[kc].a, we[s][kc]);
+            we[s][kc] = cfmac(zp[kc], ta[kc].b, we[s][kc]);
+        }
+        if (s == 0) load_tab2(p, pair, wave, lane, 1, 0, ta);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            wo[s][kc] = cfma(z[s][kc], tb[kc].a, wo[s][kc]);
+            wo[s][kc] = cfmac(zp[kc], tb[kc].b, wo[s][kc]);
+        }
+        if (s == 0) load_tab2(p, pair, wave, lane, 1, 1, tb);
     }
     ctx.wave_sync();    // partner reads done before this wave reuses its rows as scratch
+    ctx.stamp(23);
 }
 
 // Final pass of both inverse transforms: radix-16 across the rows of buf0 (u_e) and buf1 (u_o), then the
@@ -206,6 +224,7 @@ AW_HD void tiles_fused_ols2(Ctx &ctx, const TileParams &p, long long first, long
         const int n_batches = NB > 0 ? NB : (p.n_pairs + 1) / 2;
         auto batch = [&](int b, bool more) {
             if (b > 0) ctx.barrier();                    // every wave is done reading buf0/buf1
+            ctx.stamp(4 * (b & 3));                      // diagnostic builds: batch top / pass 1 done / barrier / first pair done
             t = ctx.opaque_i(t);                         // per-batch addresses are recomputed, not held across batches
             lane = t & 63;
             {
@@ -217,8 +236,11 @@ AW_HD void tiles_fused_ols2(Ctx &ctx, const TileParams &p, long long first, long
                 for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][2], raw[j][3]);
                 pair_pass1_lean(x, ctx.opaque(w1), buf1, t);
             }
+            ctx.stamp(4 * (b & 3) + 1);
             ctx.barrier();
+            ctx.stamp(4 * (b & 3) + 2);
             pair_subfft_cmac2(ctx, p, 2 * b, buf0, twa, twb, lane, wave, we, wo);
+            ctx.stamp(4 * (b & 3) + 3);
             // the next batch's frames travel under the second pair's sub-FFTs, in two halves: all 16 pseudo-frames
             // at once (64 VGPRs) on top of the 64 accumulator registers is what hipcc spills
             if (more) load_batch2<CS, INTERIOR, 0, AW_OLS2_SPLIT>(p, in_s, hist_s, f0, t, 4 * (b + 1), raw);
@@ -232,6 +254,7 @@ AW_HD void tiles_fused_ols2(Ctx &ctx, const TileParams &p, long long first, long
             for (int b = 0; b < n_batches; ++b) batch(b, b + 1 < n_batches);
         }
 
+        ctx.stamp(30);
         tile_inverse_rows(ctx, we, buf0, twa, twb);
         tile_inverse_rows(ctx, wo, buf1, twa, twb);
         {   // next tile's first batch (unconditional, see tiles_fused_ols)
@@ -240,6 +263,8 @@ AW_HD void tiles_fused_ols2(Ctx &ctx, const TileParams &p, long long first, long
                                       (long long)nx.tile * p.hop - p.hist_len, t, 0, raw);
         }
         tile_inverse_final2<Ctx, INTERIOR>(ctx, p, buf0, buf1, w1, t, stream, f0, p.hist_len);
+        ctx.stamp(31);
+        ctx.flush_stamps();
         ctx.barrier();
     }
 }
