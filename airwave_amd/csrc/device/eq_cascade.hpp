@@ -33,7 +33,10 @@
 namespace awk {
 
 constexpr int kEqThreads = 256;
-constexpr int kEqChunk = 16;
+#ifndef AW_EQ_CHUNK
+#define AW_EQ_CHUNK 16
+#endif
+constexpr int kEqChunk = AW_EQ_CHUNK;            // frames per thread and span (power of two)
 constexpr int kEqSpan = kEqThreads * kEqChunk;   // 4096 frames
 constexpr int kEqMaxFilters = 64;                // ParametricEqualizerState.maximumFilterCount :17
 constexpr int kEqScanSteps = 7;                  // P^(2^s), s = 0 .. 6 (6 = one whole wave of chunks)
@@ -124,7 +127,7 @@ template <class Ctx, int E> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParam
 #pragma unroll
         for (int j = 0; j < kEqChunk; ++j) {
             const int f = j * kEqThreads + tid;
-            float *dst = stage + (f >> 4) * kStride + (f & 15) * E;
+            float *dst = stage + (f / kEqChunk) * kStride + (f % kEqChunk) * E;
             if constexpr (E == 2) {
                 cf v = mk(0.f, 0.f);
                 if (f < nfr) v = *reinterpret_cast<const cf *>(in + (base + f) * 2);
@@ -229,7 +232,7 @@ template <class Ctx, int E> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParam
 #pragma unroll
         for (int j = 0; j < kEqChunk; ++j) {
             const int f = j * kEqThreads + tid;
-            const float *src = stage + (f >> 4) * kStride + (f & 15) * E;
+            const float *src = stage + (f / kEqChunk) * kStride + (f % kEqChunk) * E;
             if (f < nfr) {
                 if constexpr (E == 2) *reinterpret_cast<cf *>(out + (base + f) * 2) = *reinterpret_cast<const cf *>(src);
                 else out[(base + f) * 2] = *src;

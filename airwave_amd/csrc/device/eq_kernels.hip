@@ -31,7 +31,7 @@ struct EqGpuCtx {
 // index that is what lets hipcc read them with scalar loads.  in/out may alias (in place) and are not restrict.
 // E = 2: one workgroup per stream; E = 1: one per (stream, ear).
 template <int E>
-__global__ void __launch_bounds__(kEqThreads, 2) aw_eq_cascade_kernel(EqParams p, const double *__restrict__ tab,
+__global__ void __launch_bounds__(kEqThreads, AW_EQ_WAVES) aw_eq_cascade_kernel(EqParams p, const double *__restrict__ tab,
                                                                         const double *__restrict__ plane) {
     extern __shared__ __align__(16) unsigned char eq_lds[];
     EqGpuCtx ctx{reinterpret_cast<cf *>(eq_lds)};
