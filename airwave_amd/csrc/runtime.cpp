@@ -233,7 +233,14 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
     if (const char *e = getenv("AW_WINDOW")) window = atoi(e);
     const int hist2 = awh::poly_history_frames(hrir->taps);          // 16384-frame windows (tile_ols2.hpp)
     const bool fits1 = hrir->taps - 1 <= N - 2048, fits2 = hist2 <= awk::kN2 - 4096;
-    if (window == 0) window = AW_DEFAULT_WINDOW;
+    if (window == 0) {
+        // measured crossover of the two fused kernels (tools/window_sweep.py, 128 streams): stereo gains from the
+        // long window from ~2800 taps (one batch per tile, few spills: 4320 taps 84 -> 110 G frames/s), 3-6 channels
+        // from ~5400, 7-8 channels from ~5900; everything else only when one 8192-frame window cannot hold the HRIR
+        const int c = n_in;
+        const int from = c == 2 ? 2800 : (c >= 3 && c <= 6) ? 5400 : (c == 7 || c == 8) ? 5900 : (1 << 30);
+        window = hrir->taps >= from ? awk::kN2 : AW_DEFAULT_WINDOW;
+    }
     if ((window == awk::kN2 && fits2) || (!fits1 && fits2)) {
         sp->path = 0; sp->fused2 = true;
         sp->hist_len = hist2;
