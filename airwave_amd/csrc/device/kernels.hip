@@ -351,7 +351,8 @@ hipError_t launch_fused_ols2(const TileParams &p_in, int n_streams, hipStream_t 
                              long long *dominant_tiles) {
     TileParams p = p_in;
     long long lo = (p.hist_len + p.hop - 1) / p.hop;
-    const long long usable = p.frames - (((2 * p.n_channels) % 4 != 0) ? 1 : 0);
+    // the last batch of a pseudo-frame reads up to 2 floats past it (2C not a multiple of 4): keep that much input after the window
+    const long long usable = p.frames - (((2 * p.n_channels) % 4 != 0) ? (p.n_channels == 1 ? 2 : 1) : 0);
     long long hi = (usable - kN2 + p.hist_len) >= 0 ? (usable - kN2 + p.hist_len) / p.hop + 1 : 0;
     if (hi > p.tiles_per_stream) hi = p.tiles_per_stream;
     if (hi < lo) hi = lo;

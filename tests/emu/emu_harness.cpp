@@ -74,7 +74,7 @@ static int emu_fused_ols2(const float *in, float *out, const float *hist, const 
     std::vector<float> zero_hist;
     if (!hist) { zero_hist.assign((size_t)n_streams * p.hist_len * n_channels + 4, 0.f); hist = zero_hist.data(); }
     p.hist = hist;
-    const long long usable = frames - (((2 * n_channels) % 4 != 0) ? 1 : 0);
+    const long long usable = frames - (((2 * n_channels) % 4 != 0) ? (n_channels == 1 ? 2 : 1) : 0);
     long long lo = (p.hist_len + p.hop - 1) / p.hop;
     long long hi = (usable - kN2 + p.hist_len) >= 0 ? (usable - kN2 + p.hist_len) / p.hop + 1 : 0;
     if (hi > p.tiles_per_stream) hi = p.tiles_per_stream;
