@@ -119,3 +119,17 @@ def test_resampler_matches_oracle(oracle):
         y, oy = aw.Resampler.resampleHighQuality(x, fr, to), oracle.resample_intended(x, fr, to)
         assert y.size == oy.size == oracle.resample_output_count(x.size, fr, to) or abs(fr - to) < 0.01
         assert np.array_equal(y, oy)
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The boundary is a C ABI: include/airwave_hip.h must compile as strict C99 (what cgo / Swift's clang importer /
+    a ctypes generator see), with no C++ or HIP types in any signature."""
+    import subprocess
+    src = tmp_path / "abi_check.c"
+    src.write_text('#include "airwave_hip.h"\nint main(void) { aw_context *c = 0; aw_eq *e = 0; (void)c; (void)e; return AW_OK; }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
+                    "-c", str(src), "-o", str(tmp_path / "abi_check.o")], check=True)
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "airwave_hip.h")).read(), flags=re.S)   # comments may name them
+    for banned in ("hipStream_t", "torch", "std::", "template", "class "):
+        assert banned not in text, banned
