@@ -111,6 +111,13 @@ AW_HD void pair_subfft_cmac2(Ctx &ctx, const TileParams &p, int pair, cf *buf, c
     // Row 0's table entries for both outputs are issued BEFORE the sub-FFTs (their L2 latency, ~2 k cycles each
     // when exposed — phase stamps, tools/stamps2.py — hides under the three radix-8 passes); row 1's are issued
     // into the same registers as soon as row 0's are consumed.  64 table VGPRs in flight at most.
+#if defined(AW_ABL2) && (AW_ABL2 & 1)      // timing ablation only (wrong results): forward transform kept, CMAC phase dropped
+    sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) { we[0][kc] = we[0][kc] + z[0][kc]; wo[1][kc] = wo[1][kc] + z[1][kc]; }
+    ctx.wave_sync();
+    return;
+#endif
     cf2 ta[8], tb[8];
     if (AW_OLS2_TABPRE >= 1) load_tab2(p, pair, wave, lane, 0, 0, ta);
     if (AW_OLS2_TABPRE >= 2) load_tab2(p, pair, wave, lane, 0, 1, tb);
