@@ -56,17 +56,24 @@ std::string trim_ws(const std::string &s) {   // .whitespaces: space and tab
     return s.substr(a, b - a);
 }
 
-bool swift_int(const std::string &t, int *out) {   // Swift Int(String): optional sign + ASCII digits only
+// Swift Int(String): optional sign + ASCII digits only, nil on Int64 overflow.  The ABI carries indices as
+// int32: values beyond that range are kept as INT32_MAX / INT32_MIN — still integers, still out of range for
+// any HRIR, so activation reports invalidChannelMapping exactly where the reference does.
+bool swift_int(const std::string &t, int *out) {
     size_t i = 0;
     if (i < t.size() && (t[i] == '+' || t[i] == '-')) ++i;
     if (i >= t.size()) return false;
-    long long v = 0;
+    const bool neg = t[0] == '-';
+    unsigned long long v = 0;
+    const unsigned long long limit = neg ? 9223372036854775808ULL : 9223372036854775807ULL;
     for (size_t j = i; j < t.size(); ++j) {
         if (t[j] < '0' || t[j] > '9') return false;
-        v = v * 10 + (t[j] - '0');
-        if (v > 2147483647LL) return false;
+        const unsigned d = (unsigned)(t[j] - '0');
+        if (v > (limit - d) / 10) return false;          // Int64 overflow -> nil
+        v = v * 10 + d;
     }
-    *out = (int)(t[0] == '-' ? -v : v);
+    if (neg) *out = v > 2147483648ULL ? (-2147483647 - 1) : (int)(-(long long)v);
+    else *out = v > 2147483647ULL ? 2147483647 : (int)v;
     return true;
 }
 

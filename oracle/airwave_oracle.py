@@ -338,7 +338,8 @@ def _swift_int(text: str) -> Optional[int]:
         t = t[1:]
     if not t or not all("0" <= ch <= "9" for ch in t):
         return None
-    return int(text)
+    v = int(text)
+    return v if -(1 << 63) <= v < (1 << 63) else None          # Int(String) is nil on Int64 overflow
 
 
 def parse_hesuvi_format(text: str) -> ChannelMap:

@@ -133,3 +133,31 @@ def test_header_is_plain_c99(tmp_path):
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "airwave_hip.h")).read(), flags=re.S)   # comments may name them
     for banned in ("hipStream_t", "torch", "std::", "template", "class "):
         assert banned not in text, banned
+
+
+def test_hesuvi_text_parser_matches_oracle_on_mutated_maps(oracle):
+    """Token-level fuzz of parseHeSuViFormat (VirtualSpeaker.swift:301-346): names with aliases and odd case, comments,
+    missing / extra fields, signs, non-numeric and overflowing indices, every line-ending flavour — the library's
+    parser and the oracle's restatement must build the same map."""
+    import random
+    rng = random.Random(5)
+    names = ["L", "R", "C", "FL", "fr", "Fc", "LFE", "SUB", "BL", "RL", "rr", "SL", "sr", "TFL", "Mine", "Ch7", "", "A B", "#x", ";y", "FL "]
+    nums = ["0", "13", " 7", "+2", "-1", "007", "a", "1.5", "", "99999999999999999999", "1e2", "0x3", "٣", "5000000000",
+            "-3000000000", "9223372036854775807", "9223372036854775808", "-9223372036854775808", "-9223372036854775809"]
+    clamp = lambda v: max(-2**31, min(2**31 - 1, v))          # the ABI carries indices as int32 (out of range either way)
+    seps = ["=", " = ", "\t=\t", "==", ":", ""]
+    eols = ["\n", "\r\n", "\r"]
+    for _ in range(300):
+        lines = []
+        for _ in range(rng.randrange(1, 8)):
+            r = rng.random()
+            if r < 0.75:
+                k = rng.choice([2, 2, 2, 1, 3])
+                lines.append(rng.choice(["", " ", "\t"]) + rng.choice(names) + rng.choice(seps) + rng.choice([",", " , ", ",\t"]).join(rng.choice(nums) for _ in range(k)))
+            else:
+                lines.append(rng.choice(["# comment", "; note", "", "   ", "garbage", "L = 1, 2 = 3"]))
+        text = "".join(l + rng.choice(eols) for l in lines)
+        m, om = aw.HRIRChannelMap.parseHeSuViFormat(text), oracle.parse_hesuvi_format(text)
+        assert len(m) == len(om), (text, om)
+        for k, v in om.items():
+            assert m.getIndices(k) == (clamp(v[0]), clamp(v[1])), (text, k, v)
