@@ -161,3 +161,72 @@ def test_hesuvi_text_parser_matches_oracle_on_mutated_maps(oracle):
         assert len(m) == len(om), (text, om)
         for k, v in om.items():
             assert m.getIndices(k) == (clamp(v[0]), clamp(v[1])), (text, k, v)
+
+
+def test_wav_reader_matches_oracle_on_generated_files(oracle, tmp_path):
+    """Structure-level fuzz of the RIFF/WAVE reader: every sample format the loader knows, plain and EXTENSIBLE headers,
+    1..16 channels, extra chunks (odd sizes with their pad byte) before, between and after fmt/data, truncated data.
+    The library and the oracle's restatement of the decode contract (WAVLoader.swift:26-99) must agree bit for bit."""
+    import random
+    import struct
+    rng = random.Random(17)
+    nprng = np.random.default_rng(17)
+
+    def chunk(cid, body):
+        return cid + struct.pack("<I", len(body)) + body + (b"\x00" if len(body) & 1 else b"")
+
+    fmts = [(1, 8), (1, 16), (1, 24), (1, 32), (3, 32), (3, 64)]
+    for it in range(120):
+        tag, bits = rng.choice(fmts)
+        ch = rng.choice([1, 2, 3, 7, 8, 14, 16])
+        frames = rng.randrange(1, 40)
+        rate = rng.choice([8000, 44100, 48000, 96000, 192000])
+        n = frames * ch
+        if tag == 3:
+            vals = nprng.uniform(-1.5, 1.5, n)
+            payload = vals.astype("<f4" if bits == 32 else "<f8").tobytes()
+        elif bits == 8:
+            payload = bytes(nprng.integers(0, 256, n, dtype=np.uint8))
+        elif bits == 16:
+            payload = nprng.integers(-32768, 32768, n).astype("<i2").tobytes()
+        elif bits == 24:
+            payload = b"".join(int(v).to_bytes(3, "little", signed=True) for v in nprng.integers(-2 ** 23, 2 ** 23, n))
+        else:
+            payload = nprng.integers(-2 ** 31, 2 ** 31, n).astype("<i4").tobytes()
+        align = ch * bits // 8
+        if rng.random() < 0.4:      # WAVE_FORMAT_EXTENSIBLE: real tag in the SubFormat GUID
+            fmt = struct.pack("<HHIIHH", 0xFFFE, ch, rate, rate * align, align, bits) + struct.pack("<HHI", 22, bits, 0) + \
+                  struct.pack("<H", tag) + bytes.fromhex("000000001000800000aa00389b71")
+        else:
+            fmt = struct.pack("<HHIIHH", tag, ch, rate, rate * align, align, bits)
+        if rng.random() < 0.2:
+            payload = payload[: max(0, len(payload) - rng.randrange(1, align + 1))]     # truncated last frame(s)
+        extras = [chunk(b"LIST", bytes(rng.randrange(0, 9))), chunk(b"fact", struct.pack("<I", frames)),
+                  chunk(b"PEAK", bytes(rng.randrange(1, 24))), chunk(b"junk", b"x" * rng.randrange(0, 5))]
+        body = b"WAVE"
+        parts = [chunk(b"fmt ", fmt), chunk(b"data", payload)]
+        for e in extras:
+            if rng.random() < 0.5:
+                parts.insert(rng.randrange(0, len(parts) + 1), e)
+        if parts.index(chunk(b"fmt ", fmt)) > parts.index(chunk(b"data", payload)) and rng.random() < 0.7:
+            parts.remove(chunk(b"fmt ", fmt)); parts.insert(0, chunk(b"fmt ", fmt))         # mostly fmt first, sometimes not
+        body += b"".join(parts)
+        path = str(tmp_path / f"g{it}.wav")
+        open(path, "wb").write(b"RIFF" + struct.pack("<I", len(body)) + body)
+        try:
+            ow = oracle.wav_load(path)
+            oerr = None
+        except ValueError as e:
+            ow, oerr = None, str(e).split(":")[0]
+        try:
+            w = aw.WAVLoader.load(path)
+            perr = None
+        except aw.WAVError as e:
+            w, perr = None, e.name
+        if oerr is not None:
+            assert perr == {"emptyFile": "WAV_EMPTY_FILE", "unsupportedFormat": "WAV_UNSUPPORTED_FORMAT", "fileReadError": "WAV_FILE_READ",
+                            "invalidChannelCount": "INVALID_CHANNEL_COUNT"}[oerr], (it, oerr, perr)
+        else:
+            assert perr is None, (it, perr)
+            assert (w.sample_rate, w.channel_count, w.frame_count) == (ow.sample_rate, ow.channel_count, ow.frame_count)
+            assert np.array_equal(w.audio_data, ow.audio_data), it
