@@ -326,3 +326,27 @@ def test_cfg1_full_length_against_the_cpu_reference_port(aw, oracle, golden_dir)
     truth = oracle.spatialize_f64(x[0], tracks, lt, rt)
     assert oracle.peak_rel_error(y, port) < TOL and oracle.peak_rel_error(y, truth) < TOL
     assert oracle.peak_rel_error(port, truth) < TOL          # the port itself sits inside the same budget
+
+
+@pytest.mark.parametrize("taps,channels,seed", [(700, 3, 1), (4320, 2, 2), (4320, 8, 3), (9000, 7, 4), (15000, 4, 5)])
+def test_random_call_splits_on_every_path(aw, oracle, taps, channels, seed):
+    """Any split of a timeline into calls gives the same samples as one call, on all three paths (8192-frame windows,
+    16384-frame windows, partitioned), with call sizes around the hop/window/block boundaries."""
+    rng = np.random.default_rng(seed)
+    h = oracle.synth_hrir(14, taps, seed=taps)
+    lt = (np.arange(channels) % 14).astype(np.int32)
+    rt = ((np.arange(channels) + 5) % 14).astype(np.int32)
+    S, F = 2, 60000
+    x = oracle.synth_input(S, F, channels, seed=seed)
+    sp = aw.Spatializer(aw.HRIR(h), lt, rt, n_streams=S)
+    info = sp.info()
+    whole = sp.process(x)
+    assert oracle.peak_rel_error(whole[1], oracle.spatialize_f64(x[1], h, lt, rt)) < TOL
+    sp.reset()
+    parts, pos = [], 0
+    specials = [1, 2, info["hop"] - 1, info["hop"], info["hop"] + 1, info["fft"], info["history"] + 1, 4096, 4097]
+    while pos < F:
+        n = int(min(F - pos, rng.choice(specials + [int(rng.integers(1, 20000))])))
+        parts.append(sp.process(np.ascontiguousarray(x[:, pos:pos + n])))
+        pos += n
+    assert np.max(np.abs(np.concatenate(parts, axis=1) - whole)) <= 3e-6 * np.abs(whole).max()

@@ -169,3 +169,26 @@ def test_realtime_matches_oracle_on_real_hrir(aw, oracle, golden_dir):
         gl.append(np.stack(a, 1)); ol.append(np.stack(b, 1))
     g, o = np.concatenate(gl), np.concatenate(ol)
     assert oracle.peak_rel_error(g, o) < 1e-5
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_realtime_random_callback_sequences_match_oracle(aw, oracle, golden_dir, seed):
+    """Random callback sizes (1..4096, with mono callbacks and a reset in the middle) through the pending/FIFO adapter:
+    every output sample against the oracle's restatement of RealtimeAudioProcessor (:77-190)."""
+    import os
+    wav = oracle.wav_load(os.path.join(golden_dir, "hrtf", "RoomSH1.0.wav"))
+    hrir = aw.HRIR(wav.audio_data)
+    gp = aw.RealtimeAudioProcessor(hrir, [(0, 1), (8, 7)], 512, 4096)
+    op = oracle.RealtimeAudioProcessor([(wav.audio_data[0], wav.audio_data[1]), (wav.audio_data[8], wav.audio_data[7])], 512, 4096)
+    rng = np.random.default_rng(seed)
+    g, o = [], []
+    for i in range(14):
+        size = int(rng.choice([1, 7, 64, 511, 512, 513, 1000, 2048, 4095, 4096, int(rng.integers(1, 4097))]))
+        l = rng.uniform(-0.5, 0.5, size).astype(np.float32)
+        r = None if rng.random() < 0.2 else rng.uniform(-0.5, 0.5, size).astype(np.float32)
+        if i == 8:
+            gp.reset(); op.reset()
+        a, b = gp.process(l, r), op.process(l, r)
+        g.append(np.stack(a, 1)); o.append(np.stack(b, 1))
+    g, o = np.concatenate(g), np.concatenate(o)
+    assert oracle.peak_rel_error(g, o) < 1e-5
