@@ -62,7 +62,7 @@ def build(force: bool = False, verbose: bool = False, stamps: bool = False, defi
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     common = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"--offload-arch={ARCH}",
-              "-Wall", "-Wno-unused-result", "-ffp-contract=fast"] + [f"-D{d}" for d in defines]
+              "-Wall", "-Wno-unused-result", "-ffp-contract=fast"] + [f"-D{d}" for d in defines] + os.environ.get("AW_EXTRA_HIPCC_FLAGS", "").split()
     objs = []
     for src in SOURCES:
         spath = os.path.join(CSRC, src)
