@@ -86,3 +86,15 @@ def test_emulated_16384_window_path(oracle, channels, taps, frames):
     y = emu.fused_ols(x, h, lt, rt, variant=2)
     assert not np.isnan(y).any()
     assert oracle.peak_rel_error(y[0], oracle.spatialize_f64(x[0], h, lt, rt)) < TOL
+
+
+def test_emulated_partitioned_more_than_eight_partitions(oracle):
+    """P = 10 partitions: the per-bin CMAC kernel walks the partitions in chunks of 8, so this exercises a second,
+    partial chunk (and block groups that straddle it)."""
+    h = oracle.synth_hrir(14, 40000, seed=8)
+    lt = np.array([0, 3, 5], np.int32)
+    rt = np.array([1, 4, 13], np.int32)
+    x = oracle.synth_input(1, 50001, 3, seed=2)
+    y = emu.partitioned(x, h, lt, rt)
+    assert not np.isnan(y).any()
+    assert oracle.peak_rel_error(y[0], oracle.spatialize_f64(x[0], h, lt, rt)) < TOL

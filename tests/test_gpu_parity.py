@@ -231,7 +231,8 @@ def test_long_tap_partitioned_path(aw, oracle, golden_dir):
 
 
 @pytest.mark.parametrize("taps,channels,path,fft", [(6146, 2, 0, 16384), (8640, 8, 0, 16384), (12288, 7, 0, 16384),
-                                                    (12290, 5, 1, 8192), (20000, 3, 1, 8192)])
+                                                    (12290, 5, 1, 8192), (20000, 3, 1, 8192), (40000, 2, 1, 8192),
+                                                    (70000, 7, 1, 8192)])
 def test_long_hrir_paths_chunks_and_state(aw, oracle, taps, channels, path, fft, monkeypatch):
     """HRIRs beyond one 8192-frame window: up to 12288 taps (cfg 4: 4320 taps resampled x2 = 8640) run fused on
     16384-frame windows, longer ones on the partitioned path (with stream chunking of its scratch)."""
