@@ -41,7 +41,10 @@ constexpr int kEqSpan = kEqThreads * kEqChunk;   // 4096 frames
 constexpr int kEqMaxFilters = 64;                // ParametricEqualizerState.maximumFilterCount :17
 constexpr int kEqScanSteps = 7;                  // P^(2^s), s = 0 .. 6 (6 = one whole wave of chunks)
 // LDS map (bytes)
-constexpr int kEqStageBytes = kEqThreads * (kEqChunk * 2 + 4) * 4;        // 36,864: [chunk][32 + 4] floats (both ears)
+#ifndef AW_EQ_STAGE_EARS
+#define AW_EQ_STAGE_EARS 2       // 1: stage sized for the per-ear workgroups only (tuning builds with bigger chunks)
+#endif
+constexpr int kEqStageBytes = ((kEqThreads * (kEqChunk * AW_EQ_STAGE_EARS + (AW_EQ_STAGE_EARS == 2 ? 4 : 1)) * 4 + 15) / 16) * 16;   // 36,864: [chunk][32 + 4] floats (both ears)
 constexpr int kEqScanBytes = 4 * kEqThreads * 8;                          // [4][thread] double (component-major: conflict-free 8-B accesses)
 constexpr int kEqTotalsBytes = 2 * (kEqThreads / 64) * 4 * 8;             // ping-pong [wave][4]
 constexpr int kEqCarryBytes = 2 * kEqMaxFilters * 4 * 8;                  // ping-pong [filter][4]
