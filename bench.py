@@ -254,6 +254,19 @@ def main() -> None:
                 "frames_per_launch": dom_frames,
             },
         }
+        # Second roof (report which one binds): FP32 vector.  Algorithmic flops of the transforms this
+        # implementation runs per output frame: (pairs + outputs) complex FFTs of 8192 points at 5 N log2 N, and
+        # pairs x N x outputs complex multiply-accumulate pairs (16 flop) per tile of `hop` frames.
+        if len(legs) == 1 and paths[0]["path"].startswith("fused"):
+            n8 = 8192
+            long_win = paths[0]["fft"] == 16384
+            pairs = (2 * C + 1) // 2 if long_win else (C + 1) // 2
+            outs = 2 if long_win else 1
+            flops_per_frame = ((pairs + outs) * 5 * n8 * 13 + pairs * n8 * 16 * outs) / paths[0]["hop"]
+            tfl = flops_per_frame * dom_frames / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+            result["fp32_roof"] = {"flops_per_frame": flops_per_frame, "achieved": tfl, "peak": 157.3, "unit": "TFLOP/s", "frac": tfl / 157.3,
+                                   "intensity_flop_per_byte": flops_per_frame / bytes_per_frame, "ridge_flop_per_byte": 157.3e12 / (HBM_PEAK_GBS * 1e9),
+                                   "note": "MI355X FP32 vector peak (MI355X_MICROARCH.md); at this intensity both roofs bind within 5 %"}
         if eq_events:
             eq_ms = sum(a.elapsed_time(b) for a, b in eq_events) / args.steps
             result["roofline"]["eq_kernel_ms_per_step"] = eq_ms
