@@ -266,7 +266,10 @@ def main() -> None:
             tfl = flops_per_frame * dom_frames / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
             result["fp32_roof"] = {"flops_per_frame": flops_per_frame, "achieved": tfl, "peak": 157.3, "unit": "TFLOP/s", "frac": tfl / 157.3,
                                    "intensity_flop_per_byte": flops_per_frame / bytes_per_frame, "ridge_flop_per_byte": 157.3e12 / (HBM_PEAK_GBS * 1e9),
-                                   "note": "MI355X FP32 vector peak (MI355X_MICROARCH.md); at this intensity both roofs bind within 5 %"}
+                                   "note": "MI355X FP32 vector peak (MI355X_MICROARCH.md); " +
+                                           ("the HBM roof binds" if flops_per_frame / bytes_per_frame < 0.95 * 157.3e12 / (HBM_PEAK_GBS * 1e9)
+                                            else "the FP32 roof binds" if flops_per_frame / bytes_per_frame > 1.05 * 157.3e12 / (HBM_PEAK_GBS * 1e9)
+                                            else "at this intensity both roofs bind within 5 %")}
         if eq_events:
             eq_ms = sum(a.elapsed_time(b) for a, b in eq_events) / args.steps
             result["roofline"]["eq_kernel_ms_per_step"] = eq_ms
