@@ -81,6 +81,25 @@ struct GpuCtx {
     }
     // Scheduling fence (no instruction): keeps hipcc from interleaving the two rows' butterflies,
     // which doubles their temporaries at the register-pressure peak.
+    // Cross-lane swap primitive of the register<->lane-field transposes (semantics checked by tools/ubench/xlane_swap.hip):
+    //   lanes with bit b = 0: hi' = partner.lo ;  lanes with bit b = 1: lo' = partner.hi ;  partner = lane ^ (1 << b)
+    __device__ __forceinline__ void xswap32(unsigned &lo, unsigned &hi, int bit) const {
+        if (bit == 5) { auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false); lo = r[0]; hi = r[1]; }
+        else if (bit == 4) { auto r = __builtin_amdgcn_permlane16_swap(lo, hi, false, false); lo = r[0]; hi = r[1]; }
+        else {
+            const unsigned t = hi;
+            hi = __builtin_amdgcn_update_dpp(hi, lo, 0x128, 0xf, 0x3, false);   // lanes 0-7 of every row: hi <- lo of lane + 8
+            lo = __builtin_amdgcn_update_dpp(lo, t, 0x128, 0xf, 0xc, false);    // lanes 8-15: lo <- old hi of lane - 8
+        }
+    }
+    __device__ __forceinline__ void xswap(cf &lo, cf &hi, int bit) const {
+        unsigned a = __float_as_uint(lo.x), b = __float_as_uint(hi.x);
+        xswap32(a, b, bit);
+        lo.x = __uint_as_float(a); hi.x = __uint_as_float(b);
+        a = __float_as_uint(lo.y); b = __float_as_uint(hi.y);
+        xswap32(a, b, bit);
+        lo.y = __uint_as_float(a); hi.y = __uint_as_float(b);
+    }
     // unconditional scheduling fence (bounds how far loads are hoisted)
     __device__ __forceinline__ void sched_fence_hard() const {
         asm volatile("" ::: "memory");

@@ -46,6 +46,9 @@ constexpr int kTwaElems = 8 * 64;                      // [ka][lane]  W_512^{lan
 constexpr int kTwbElems = 8 * 8;                       // [kb][l0]    W_64^{l0 kb}
 constexpr int kLdsElems = 2 * kBufElems + kTwaElems + kTwbElems;
 constexpr int kLdsBytes = kLdsElems * 8;               // 152064 B (<= 160 KiB)
+#ifndef AW_XA_REG
+#define AW_XA_REG 0      // 1: first sub-FFT exchange through cross-lane swaps instead of LDS (correct; measured 1.54 -> 1.68 ms: +735 VALU instructions per tile and wave for -120 LDS ones)
+#endif
 #ifndef AW_PREFETCH_RAW_EARLY
 #define AW_PREFETCH_RAW_EARLY 1
 #endif
@@ -133,14 +136,31 @@ AW_HD void sub_fft512x2(Ctx &ctx, cf (&a)[2][8], cf *scr0, cf *scr1, const cf *t
         a[1][ka] = twmul<INV>(a[1][ka], w);
     }
     ctx.stamp(SB + 1);
-    // exchange A: write [ka][lane] (row stride 72), read [ka'][l0' + 8 l1] with lane = l0' + 8 ka'
+    // exchange A: element (ka, lane = l0 + 8 l1) -> (register l1, lane = l0 + 8 ka): an 8x8 transpose between the
+    // register index and lane bits 3-5.
+    const int l0 = lane & 7, kap = lane >> 3;
+#if AW_XA_REG
+    // In registers: three swap stages, one per (register bit, lane bit) pair — v_permlane32_swap, v_permlane16_swap
+    // and a bank-masked DPP row_ror:8.  No LDS traffic: the LDS store path (6 cycles per ds_write_b64 for the whole CU)
+    // is this kernel's busiest resource, VALU issue is not.
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ctx.xswap(a[s][r], a[s][r + 4], 5);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ctx.xswap(a[s][(r & 1) + 4 * (r >> 1)], a[s][(r & 1) + 4 * (r >> 1) + 2], 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ctx.xswap(a[s][2 * r], a[s][2 * r + 1], 3);
+    }
+#else
+    // through LDS: write [ka][lane] (row stride 72), read [ka'][l0' + 8 l1] with lane = l0' + 8 ka'
 #pragma unroll
     for (int ka = 0; ka < 8; ++ka) { scr0[ka * 72 + lane] = a[0][ka]; scr1[ka * 72 + lane] = a[1][ka]; }
     ctx.wave_sync();
-    const int l0 = lane & 7, kap = lane >> 3;
 #pragma unroll
     for (int l1 = 0; l1 < 8; ++l1) { a[0][l1] = ctx.ld(scr0 + kap * 72 + l0 + 8 * l1); a[1][l1] = ctx.ld(scr1 + kap * 72 + l0 + 8 * l1); }
     ctx.wave_sync();
+#endif
     ctx.stamp(SB + 2);
     // pass B: radix-8 over l1 -> kb, twiddle W_64^{l0 kb}
     fft8<INV>(a[0]);

@@ -25,7 +25,8 @@ struct EmuShared {
     std::barrier<> wg;
     std::vector<std::unique_ptr<std::barrier<>>> wave;
     std::vector<awk::cf> lds;
-    explicit EmuShared(int threads = awk::kThreads, size_t lds_elems = (size_t)awk::kLdsElems) : wg(threads), lds(lds_elems) {
+    std::vector<awk::cf> xs;      // cross-lane swap mailbox: [thread][2]
+    explicit EmuShared(int threads = awk::kThreads, size_t lds_elems = (size_t)awk::kLdsElems) : wg(threads), lds(lds_elems), xs((size_t)threads * 2) {
         for (int w = 0; w < threads / 64; ++w) wave.emplace_back(new std::barrier<>(64));
     }
 };
@@ -46,6 +47,14 @@ struct EmuCtx {
     awk::cf ld(const awk::cf *p) const { return *p; }
     void stagger(int, int) const {}
     void barrier() const { sh->wg.arrive_and_wait(); }
+    // lanes with bit b = 0: hi' = partner.lo ; lanes with bit b = 1: lo' = partner.hi ; partner = lane ^ (1 << b)
+    void xswap(awk::cf &lo, awk::cf &hi, int bit) const {
+        sh->xs[(size_t)tid_ * 2] = lo; sh->xs[(size_t)tid_ * 2 + 1] = hi;
+        sh->wave[tid_ >> 6]->arrive_and_wait();
+        const int p = tid_ ^ (1 << bit);
+        if ((tid_ >> bit) & 1) lo = sh->xs[(size_t)p * 2 + 1]; else hi = sh->xs[(size_t)p * 2];
+        sh->wave[tid_ >> 6]->arrive_and_wait();
+    }
     void wave_sync() const { sh->wave[tid_ >> 6]->arrive_and_wait(); }
 };
 
