@@ -22,6 +22,7 @@ class SpatialSpy:
 class EqualizerSpy:
     def __init__(self, multiplier=1.0):
         self.multiplier, self.processCount, self.preparedSampleRates, self.error = np.float32(multiplier), 0, [], None
+        self.setTargetError = None
 
     def prepare(self, definition, sampleRate):
         self.preparedSampleRates.append(sampleRate)
@@ -29,8 +30,8 @@ class EqualizerSpy:
             raise self.error
 
     def setTarget(self, definition):
-        if self.error is not None:
-            raise self.error
+        if self.setTargetError is not None:
+            raise self.setTargetError
 
     def process(self, l, r=None):
         self.processCount += 1
@@ -93,6 +94,41 @@ def test_update_keeps_equalizer_in_path_and_callback_guard():
         g.process(np.zeros(9, np.float32))
     with pytest.raises(ValueError):
         aw.AudioEffectGraph(SpatialSpy(False), eq, 4097)
+
+
+def test_invalid_live_target_keeps_equalizer_in_callback_for_unity_crossfade():
+    eq = EqualizerSpy(2)                                                              # :165-188
+    g = aw.AudioEffectGraph(SpatialSpy(True), eq, 8)
+    g.prepare(48000.0, aw.EqualizerDefinition(3.0))
+    g.process([1], [1])
+    assert eq.processCount == 1
+    eq.setTargetError = aw.EqualizerAudioEffectError("invalidFilter", "frequency is above Nyquist", 31)
+    res = g.updateEqualizer(aw.EqualizerDefinition(0.0, [aw.EqualizerFilter(31, None, True, 0, 30000.0, 1.0, 1.0)]))
+    assert not res.noEffectCanRun and res.runnableEffects == {"spatial"}
+    assert res.equalizerWarning.filterLine == 31
+    g.process([1], [1])
+    assert eq.processCount == 2
+
+
+@pytest.mark.gpu
+def test_production_equalizer_can_reenable_after_none_selection():
+    g = aw.AudioEffectGraph(SpatialSpy(False), aw.EqualizerRuntimeEffect(), 4096)     # :113-163
+    a, b = aw.EqualizerDefinition(6.0), aw.EqualizerDefinition(-6.0)
+    pos, neg = np.float32(10 ** (6 / 20)), np.float32(10 ** (-6 / 20))
+    ones = np.ones(960, np.float32)
+    last = lambda: g.process(ones, ones)[0][-1]
+    assert g.prepare(48000.0, a).runnableEffects == {"equalizer"}
+    assert abs(last() - pos) < 1e-5
+    assert g.updateEqualizer(None).noEffectCanRun
+    assert abs(last() - 1) < 1e-5
+    assert g.updateEqualizer(a).runnableEffects == {"equalizer"}
+    assert abs(last() - pos) < 1e-5
+    g.updateEqualizer(None)
+    last()
+    assert g.prepare(48000.0, a).runnableEffects == {"equalizer"}
+    assert abs(last() - pos) < 1e-5
+    assert g.updateEqualizer(b).runnableEffects == {"equalizer"}
+    assert abs(last() - neg) < 1e-5
 
 
 @pytest.mark.gpu

@@ -192,3 +192,13 @@ def test_realtime_random_callback_sequences_match_oracle(aw, oracle, golden_dir,
         g.append(np.stack(a, 1)); o.append(np.stack(b, 1))
     g, o = np.concatenate(g), np.concatenate(o)
     assert oracle.peak_rel_error(g, o) < 1e-5
+
+
+def test_one_second_of_stereo_input_across_performance_callback_sizes(aw):
+    """RealtimeAudioProcessorTests.swift:128-... (ten seconds per size upstream; one second here keeps the suite short):
+    128-, 512- and 1024-frame callbacks stay finite and keep producing output."""
+    for size in (128, 512, 1024):
+        p = make_processor(aw)
+        for _ in range(48000 // size):
+            l, r = run(p, size)
+        assert np.all(np.isfinite(l)) and np.all(np.isfinite(r)) and abs(float(l[-1])) > 0
