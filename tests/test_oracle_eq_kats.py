@@ -174,3 +174,30 @@ def test_parser_cases(oracle):
     reasons = [r for _, r in e.value.issues]
     assert "duplicate Preamp directive" in reasons and "unsupported directive" in reasons and "malformed Filter directive" in reasons
     assert "frequency must be positive" in reasons and "gain must be a finite number" in reasons and "Q must be positive" in reasons
+
+
+def test_in_place_processing_preserves_canaries(oracle):
+    import ctypes
+    st = oracle.eq_prepare(oracle.EqualizerDefinition(0.0, [mk(oracle, HSC, 6000, -5, 0.8)]), 48000)     # :154-190
+    size, canary = 4096, np.float32(12345)
+    left = np.full(size + 2, canary, np.float32)
+    right = np.full(size + 2, canary, np.float32)
+    i = np.arange(size)
+    left[1:-1] = (i % 17).astype(np.float32) / 17
+    right[1:-1] = -(i % 13).astype(np.float32) / 13
+    fp = ctypes.POINTER(ctypes.c_float)
+    lp = ctypes.cast(left.ctypes.data + 4, fp)
+    rp = ctypes.cast(right.ctypes.data + 4, fp)
+    oracle._eq_lib().orc_eq_state_process(st._h, lp, rp, lp, rp, size)            # in place, one sample into the buffers
+    assert left[0] == canary and left[-1] == canary and right[0] == canary and right[-1] == canary
+    assert np.isfinite(left).all() and np.isfinite(right).all()
+
+
+def test_ten_filter_workload_stays_finite_across_callback_sizes(oracle):
+    fl = [mk(oracle, PK if i % 2 == 0 else HSC, 250 + i * 1000, (i % 3) - 1, 0.8) for i in range(10)]   # :317-357 (1 s per size)
+    for size in (128, 512, 1024):
+        st = oracle.eq_prepare(oracle.EqualizerDefinition(-3.0, fl), 48000)
+        x = np.full(size, 0.25, np.float32)
+        for _ in range(48000 // size):
+            l, r = st.process(x, x)
+        assert np.isfinite(l).all() and np.isfinite(r).all()
