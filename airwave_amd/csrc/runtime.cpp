@@ -201,6 +201,13 @@ static aw_status sp_alloc_hist(aw_spatializer *sp) {
     return AW_OK;
 }
 
+// Tiles start on 64-frame boundaries of the timeline: a shorter hop costs < 2 % more tiles and makes every tile's
+// loads and stores start line-aligned (measured cfg 2: 1.555 -> 1.530 ms per call).  AW_HOP_ALIGN overrides (1 = off).
+static int align_hop(int hop) {
+    static const int al = [] { const char *e = getenv("AW_HOP_ALIGN"); return e ? atoi(e) : 64; }();
+    return (al > 1 && hop > 16 * al) ? hop - hop % al : hop;
+}
+
 aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_in, const int32_t *left_track,
                                 const int32_t *right_track, int32_t n_streams, int32_t block_hint,
                                 aw_spatializer **out) {
@@ -243,13 +250,13 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
     }
     if ((window == awk::kN2 && fits2) || (!fits1 && fits2)) {
         sp->path = 0; sp->fused2 = true;
-        sp->hist_len = hist2;
-        sp->hop = awk::kN2 - hist2;
+        sp->hop = align_hop(awk::kN2 - hist2);
+        sp->hist_len = awk::kN2 - sp->hop;                           // even, >= 2 * floor(taps / 2)
         sp->partitions = 1;
         sp->n_pairs = (2 * n_in + 1) / 2;                            // pseudo-pairs of the half-rate 2C-channel view
     } else if (fits1) {
         sp->path = 0;
-        sp->hop = N - (hrir->taps - 1);
+        sp->hop = align_hop(N - (hrir->taps - 1));
         sp->hist_len = N - sp->hop;
         sp->partitions = 1;
     } else {
