@@ -26,9 +26,7 @@ SOURCES = [
     "host/tables.cpp",
     "host/host_api.cpp",
 ]
-HEADERS = [
-    "device/cplx.hpp", "device/tile_ols.hpp", "device/kernels.hpp", "device/eq_cascade.hpp", "device/eq_kernels.hpp",
-    "runtime.hpp", "host/tables.hpp", "host/eq.hpp",
+HEADERS = sorted(os.path.relpath(os.path.join(d, f), CSRC) for d, _, fs in os.walk(CSRC) for f in fs if f.endswith((".hpp", ".h"))) + [
     "../../include/airwave_hip.h",
 ]
 

@@ -1,0 +1,176 @@
+// gpu_ctx.hpp — the GPU execution context of the tile code (LDS, barriers, fences); the CPU emulation harness has its
+// own (tests/emu/emu_harness.cpp).  Included by kernels.hip only (and by one-kernel probe builds under tools/).
+#pragma once
+#include "tile_ols.hpp"
+
+namespace awk {
+
+#ifndef AW_STAGGER_SLOTS
+#define AW_STAGGER_SLOTS 0       // s_sleep argument (x64 cycles) for waves 4-7 after a barrier; 0 = off
+#endif
+#ifndef AW_LDS_NO_READ2
+#define AW_LDS_NO_READ2 0
+#endif
+#ifndef AW_SCHED_FENCE
+#define AW_SCHED_FENCE 0
+#endif
+#ifndef AW_STAMPS
+#define AW_STAMPS 0
+#endif
+
+struct GpuCtx {
+    cf *lds_;
+    unsigned long long *dbg_;
+    // Phase stamps (diagnostic build only: -DAW_STAMPS=1; never in the shipped kernel).  Every wave
+    // reads the shader clock into SGPRs (uniform, no VGPRs, no branches in the timed code); thread 0
+    // stores them once at the end into a buffer nothing else reads.
+#if AW_STAMPS
+    unsigned long long st_[kStamps];
+#endif
+    __device__ __forceinline__ void stamp(int i) {
+#if AW_STAMPS
+        unsigned long long tm;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm)::"memory");
+        st_[i] = tm;
+#else
+        (void)i;
+#endif
+    }
+    int stamp_thread_ = 0;
+    __device__ __forceinline__ void flush_stamps() {
+#if AW_STAMPS
+        if ((int)threadIdx.x == stamp_thread_ && dbg_)
+            for (int i = 0; i < kStamps; ++i) dbg_[i] = st_[i];
+#endif
+    }
+    __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
+    __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
+    // wave id as a provably wave-uniform (SGPR) value: row bases become scalar
+    __device__ __forceinline__ int wave() const { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+    __device__ __forceinline__ cf *lds() const { return lds_; }
+    __device__ __forceinline__ void barrier() const { __syncthreads(); }
+    // Phase offset between the two waves of each SIMD (waves w and w+4): the younger half idles a
+    // little after a barrier so that its LDS-exchange phases fall into the older half's butterfly
+    // phases instead of colliding with them (MI355X_MICROARCH "Two waves per SIMD", item 9).
+    __device__ __forceinline__ void stagger(int wave, int slots) const {
+        (void)slots;
+#if AW_STAGGER_SLOTS > 0
+        // one opaque asm statement: a real branch here splits the block and wrecks register allocation
+        asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 1f\n\ts_sleep %1\n1:" ::"s"(wave), "n"(AW_STAGGER_SLOTS) : "scc");
+#else
+        (void)wave;
+#endif
+    }
+    // LDS read of one complex value as a single ds_read_b64.  AW_LDS_NO_READ2: volatile 64-bit
+    // access, which keeps hipcc from fusing neighbours into ds_read2_b64 / ds_read2st64_b64
+    // (measured 8.3 cycles per wave-instruction against 2 x 2.6 for two ds_read_b64, tools/ubench/lds_rate.hip).
+    __device__ __forceinline__ cf ld(const cf *p) const {
+#if AW_LDS_NO_READ2
+        const unsigned long long v = *reinterpret_cast<const volatile unsigned long long *>(p);
+        cf r;
+        r.x = __uint_as_float((unsigned)v);
+        r.y = __uint_as_float((unsigned)(v >> 32));
+        return r;
+#else
+        return *p;
+#endif
+    }
+    // Scheduling fence (no instruction): keeps hipcc from interleaving the two rows' butterflies,
+    // which doubles their temporaries at the register-pressure peak.
+    // Cross-lane swap primitive of the register<->lane-field transposes (semantics checked by tools/ubench/xlane_swap.hip):
+    //   lanes with bit b = 0: hi' = partner.lo ;  lanes with bit b = 1: lo' = partner.hi ;  partner = lane ^ (1 << b)
+    __device__ __forceinline__ void xswap32(unsigned &lo, unsigned &hi, int bit) const {
+        if (bit == 5) { auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false); lo = r[0]; hi = r[1]; }
+        else if (bit == 4) { auto r = __builtin_amdgcn_permlane16_swap(lo, hi, false, false); lo = r[0]; hi = r[1]; }
+        else {
+            const unsigned t = hi;
+            hi = __builtin_amdgcn_update_dpp(hi, lo, 0x128, 0xf, 0x3, false);   // lanes 0-7 of every row: hi <- lo of lane + 8
+            lo = __builtin_amdgcn_update_dpp(lo, t, 0x128, 0xf, 0xc, false);    // lanes 8-15: lo <- old hi of lane - 8
+        }
+    }
+    __device__ __forceinline__ void xswap(cf &lo, cf &hi, int bit) const {
+        unsigned a = __float_as_uint(lo.x), b = __float_as_uint(hi.x);
+        xswap32(a, b, bit);
+        lo.x = __uint_as_float(a); hi.x = __uint_as_float(b);
+        a = __float_as_uint(lo.y); b = __float_as_uint(hi.y);
+        xswap32(a, b, bit);
+        lo.y = __uint_as_float(a); hi.y = __uint_as_float(b);
+    }
+    // unconditional scheduling fence (bounds how far loads are hoisted)
+    __device__ __forceinline__ void sched_fence_hard() const {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void sched_fence() const {
+#if AW_SCHED_FENCE
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    // Hides a value's provenance from the optimiser (no instruction emitted): stops LICM/CSE from
+    // keeping re-computable values live across the whole tile.
+    __device__ __forceinline__ int opaque_i(int v) const {
+        asm volatile("" : "+v"(v));
+        return v;
+    }
+    __device__ __forceinline__ cf opaque(cf v) const {
+        asm volatile("" : "+v"(v.x), "+v"(v.y));
+        return v;
+    }
+    // Tile flags of the sibling-workgroup kernels (tile_olsh.hpp): the even-bin workgroup publishes its stores, the
+    // odd-bin one (dispatched later: higher workgroup id) waits for them.  Agent scope: siblings may sit on different CUs.
+    // AW_SIB_SYNC: 2 = agent-scope release/acquire fences (portable, but on gfx950 they write back / invalidate the whole L2:
+    // measured 7.5 ms per cfg-2 launch), 1 = same-XCD protocol (siblings share one L2: stores are complete at L2 after
+    // vmcnt(0), the flag is an L2 atomic, the sibling reads the output around its L1), 0 = no synchronisation (timing only).
+#ifndef AW_SIB_SYNC
+#define AW_SIB_SYNC 1
+#endif
+    __device__ __forceinline__ void flag_release(int *flag, int epoch) const {
+#if AW_SIB_SYNC == 2
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#elif AW_SIB_SYNC == 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's output stores are acknowledged by the L2
+        __syncthreads();
+        if (threadIdx.x == 0) (void)__hip_atomic_exchange(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        (void)flag; (void)epoch;
+#endif
+    }
+    __device__ __forceinline__ void flag_acquire(int *flag, int epoch) const {
+#if AW_SIB_SYNC == 2
+        if (threadIdx.x == 0)
+            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(4);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#elif AW_SIB_SYNC == 1
+        if (threadIdx.x == 0)
+            while (__hip_atomic_fetch_add(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+        __syncthreads();
+#else
+        (void)flag; (void)epoch;
+#endif
+    }
+    // the odd-bin sibling's read of what its partner stored: around the L1 (sc0), from the XCD's L2
+    __device__ __forceinline__ cf ld_out(const float *p) const {
+#if AW_SIB_SYNC == 1
+        // a relaxed agent-scope atomic load: hipcc emits a cache-bypassing global_load_dwordx2 and tracks its vmcnt
+        const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cf r;
+        r.x = __uint_as_float((unsigned)v);
+        r.y = __uint_as_float((unsigned)(v >> 32));
+        return r;
+#else
+        return *reinterpret_cast<const cf *>(p);
+#endif
+    }
+    // Exchanges inside one wave need no s_barrier: a wave's LDS instructions execute in issue
+    // order.  The fences only stop the compiler from moving LDS accesses across the exchange.
+    __device__ __forceinline__ void wave_sync() const {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
+
+}  // namespace awk

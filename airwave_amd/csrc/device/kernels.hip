@@ -4,130 +4,12 @@
 // GPU execution context (LDS, barriers), the XCD-aware workgroup -> tile mapping and the small
 // utility kernels (history carry, synthetic fill, planar<->interleaved).
 #include "kernels.hpp"
+#include "gpu_ctx.hpp"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace awk {
-
-#ifndef AW_STAGGER_SLOTS
-#define AW_STAGGER_SLOTS 0       // s_sleep argument (x64 cycles) for waves 4-7 after a barrier; 0 = off
-#endif
-#ifndef AW_LDS_NO_READ2
-#define AW_LDS_NO_READ2 0
-#endif
-#ifndef AW_SCHED_FENCE
-#define AW_SCHED_FENCE 0
-#endif
-#ifndef AW_STAMPS
-#define AW_STAMPS 0
-#endif
-
-struct GpuCtx {
-    cf *lds_;
-    unsigned long long *dbg_;
-    // Phase stamps (diagnostic build only: -DAW_STAMPS=1; never in the shipped kernel).  Every wave
-    // reads the shader clock into SGPRs (uniform, no VGPRs, no branches in the timed code); thread 0
-    // stores them once at the end into a buffer nothing else reads.
-#if AW_STAMPS
-    unsigned long long st_[kStamps];
-#endif
-    __device__ __forceinline__ void stamp(int i) {
-#if AW_STAMPS
-        unsigned long long tm;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm)::"memory");
-        st_[i] = tm;
-#else
-        (void)i;
-#endif
-    }
-    int stamp_thread_ = 0;
-    __device__ __forceinline__ void flush_stamps() {
-#if AW_STAMPS
-        if ((int)threadIdx.x == stamp_thread_ && dbg_)
-            for (int i = 0; i < kStamps; ++i) dbg_[i] = st_[i];
-#endif
-    }
-    __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
-    __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
-    // wave id as a provably wave-uniform (SGPR) value: row bases become scalar
-    __device__ __forceinline__ int wave() const { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
-    __device__ __forceinline__ cf *lds() const { return lds_; }
-    __device__ __forceinline__ void barrier() const { __syncthreads(); }
-    // Phase offset between the two waves of each SIMD (waves w and w+4): the younger half idles a
-    // little after a barrier so that its LDS-exchange phases fall into the older half's butterfly
-    // phases instead of colliding with them (MI355X_MICROARCH "Two waves per SIMD", item 9).
-    __device__ __forceinline__ void stagger(int wave, int slots) const {
-        (void)slots;
-#if AW_STAGGER_SLOTS > 0
-        // one opaque asm statement: a real branch here splits the block and wrecks register allocation
-        asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 1f\n\ts_sleep %1\n1:" ::"s"(wave), "n"(AW_STAGGER_SLOTS) : "scc");
-#else
-        (void)wave;
-#endif
-    }
-    // LDS read of one complex value as a single ds_read_b64.  AW_LDS_NO_READ2: volatile 64-bit
-    // access, which keeps hipcc from fusing neighbours into ds_read2_b64 / ds_read2st64_b64
-    // (measured 8.3 cycles per wave-instruction against 2 x 2.6 for two ds_read_b64, tools/ubench/lds_rate.hip).
-    __device__ __forceinline__ cf ld(const cf *p) const {
-#if AW_LDS_NO_READ2
-        const unsigned long long v = *reinterpret_cast<const volatile unsigned long long *>(p);
-        cf r;
-        r.x = __uint_as_float((unsigned)v);
-        r.y = __uint_as_float((unsigned)(v >> 32));
-        return r;
-#else
-        return *p;
-#endif
-    }
-    // Scheduling fence (no instruction): keeps hipcc from interleaving the two rows' butterflies,
-    // which doubles their temporaries at the register-pressure peak.
-    // Cross-lane swap primitive of the register<->lane-field transposes (semantics checked by tools/ubench/xlane_swap.hip):
-    //   lanes with bit b = 0: hi' = partner.lo ;  lanes with bit b = 1: lo' = partner.hi ;  partner = lane ^ (1 << b)
-    __device__ __forceinline__ void xswap32(unsigned &lo, unsigned &hi, int bit) const {
-        if (bit == 5) { auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false); lo = r[0]; hi = r[1]; }
-        else if (bit == 4) { auto r = __builtin_amdgcn_permlane16_swap(lo, hi, false, false); lo = r[0]; hi = r[1]; }
-        else {
-            const unsigned t = hi;
-            hi = __builtin_amdgcn_update_dpp(hi, lo, 0x128, 0xf, 0x3, false);   // lanes 0-7 of every row: hi <- lo of lane + 8
-            lo = __builtin_amdgcn_update_dpp(lo, t, 0x128, 0xf, 0xc, false);    // lanes 8-15: lo <- old hi of lane - 8
-        }
-    }
-    __device__ __forceinline__ void xswap(cf &lo, cf &hi, int bit) const {
-        unsigned a = __float_as_uint(lo.x), b = __float_as_uint(hi.x);
-        xswap32(a, b, bit);
-        lo.x = __uint_as_float(a); hi.x = __uint_as_float(b);
-        a = __float_as_uint(lo.y); b = __float_as_uint(hi.y);
-        xswap32(a, b, bit);
-        lo.y = __uint_as_float(a); hi.y = __uint_as_float(b);
-    }
-    // unconditional scheduling fence (bounds how far loads are hoisted)
-    __device__ __forceinline__ void sched_fence_hard() const {
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __device__ __forceinline__ void sched_fence() const {
-#if AW_SCHED_FENCE
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
-    // Hides a value's provenance from the optimiser (no instruction emitted): stops LICM/CSE from
-    // keeping re-computable values live across the whole tile.
-    __device__ __forceinline__ int opaque_i(int v) const {
-        asm volatile("" : "+v"(v));
-        return v;
-    }
-    __device__ __forceinline__ cf opaque(cf v) const {
-        asm volatile("" : "+v"(v.x), "+v"(v.y));
-        return v;
-    }
-    // Exchanges inside one wave need no s_barrier: a wave's LDS instructions execute in issue
-    // order.  The fences only stop the compiler from moving LDS accesses across the exchange.
-    __device__ __forceinline__ void wave_sync() const {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-};
 
 // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group).  Give
 // each XCD a contiguous run of tiles so that consecutive tiles of a stream, whose input windows
@@ -159,6 +41,21 @@ __global__ void __launch_bounds__(kThreads) aw_fused_ols_kernel(TileParams p, lo
 }
 
 static int g_persistent_wgs = 256;      // one resident workgroup per CU (152 KB LDS each)
+
+// Sibling form (tile_olsh.hpp): workgroups 2s and 2s + 1 of an XCD group take the even and the odd bins of the same
+// tiles.  blockIdx = 8 * slot + xcd, so the odd-bin sibling has the higher id and is dispatched after its partner.
+template <int CS, int NP, bool INTERIOR>
+__global__ void __launch_bounds__(kThreads, 4) aw_fused_olsq_kernel(TileParams p, long long n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
+    const long long g = gridDim.x, b = blockIdx.x;          // g is a multiple of 16
+    const long long xcd = b % 8, slot = b / 8;
+    const long long pairs_per_xcd = g / 16;
+    const long long q8 = n_tiles / 8, r8 = n_tiles % 8;
+    const long long lo = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const long long hi = lo + (xcd < r8 ? q8 + 1 : q8);
+    tiles_fused_olsq<GpuCtx, CS, NP, INTERIOR>(ctx, p, lo + slot / 2, pairs_per_xcd, hi, (int)(slot & 1));
+}
 
 // Windows [tile_lo, tile_hi) of every stream lie inside the call's input (INTERIOR), the others touch the
 // history or the zero page.  p.tile_lo/hi carry the window range here.
@@ -252,6 +149,24 @@ hipError_t prepare_kernels() {
     AW_FOR_EACH_VEC(AW_SET_VEC)
     AW_FOR_EACH_GEN(AW_SET_GEN)
     AW_FOR_EACH_BVEC(AW_SET_BVEC)
+#define AW_SET_Q(CS, NP)                                                                                \
+    if (e == hipSuccess)                                                                                \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_olsq_kernel<CS, NP, true>),    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kHLdsBytes);
+#define AW_SET_QGEN(NP)                                                                                 \
+    if (e == hipSuccess)                                                                                \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_olsq_kernel<0, NP, false>),    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kHLdsBytes);
+#define AW_SET_QB(CS, NP)                                                                               \
+    if (e == hipSuccess)                                                                                \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_olsq_kernel<CS, NP, false>),   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kHLdsBytes);
+    AW_FOR_EACH_VEC(AW_SET_Q)
+    AW_FOR_EACH_GEN(AW_SET_QGEN)
+    AW_FOR_EACH_BVEC(AW_SET_QB)
+#undef AW_SET_Q
+#undef AW_SET_QGEN
+#undef AW_SET_QB
 #define AW_SET_VEC2(CS, NB)                                                                          \
     if (e == hipSuccess)                                                                             \
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols2_kernel<CS, NB, true>), \
@@ -363,6 +278,92 @@ hipError_t launch_fused_ols(const TileParams &p_in, int n_streams, hipStream_t s
         if (ev1 && !dom_int) (void)hipEventRecord(ev1, stream);
     }
     return hipGetLastError();
+}
+
+// The same split for the sibling-workgroup kernels (tile_olsh.hpp): grid = 2 workgroups per CU.
+const char *fused_olsh_kernel_name(int C) {
+    switch (C) {
+        case 2: return "aw_fused_olsq_kernel<2, 1, true>";
+        case 4: return "aw_fused_olsq_kernel<4, 2, true>";
+        case 6: return "aw_fused_olsq_kernel<6, 3, true>";
+        case 7: return "aw_fused_olsq_kernel<7, 4, true>";
+        case 8: return "aw_fused_olsq_kernel<8, 4, true>";
+        case 14: return "aw_fused_olsq_kernel<14, 0, true>";
+        case 12: return "aw_fused_olsq_kernel<12, 0, true>";
+        case 16: return "aw_fused_olsq_kernel<16, 0, true>";
+        default: return "aw_fused_olsq_kernel<0, NP, false>";
+    }
+}
+
+static int g_olsh_wgs_per_cu = 2;
+
+hipError_t launch_fused_olsh(const TileParams &p_in, int n_streams, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
+                             long long *dominant_tiles) {
+    TileParams p = p_in;
+    long long lo = (p.hist_len + p.hop - 1) / p.hop;
+    const long long usable = p.frames - ((p.n_channels % 4 != 0 && p.n_channels != 2) ? 1 : 0);
+    long long hi = (usable - kN + p.hist_len) >= 0 ? (usable - kN + p.hist_len) / p.hop + 1 : 0;
+    if (hi > p.tiles_per_stream) hi = p.tiles_per_stream;
+    if (hi < lo) hi = lo;
+    if (lo > p.tiles_per_stream) { lo = p.tiles_per_stream; hi = lo; }
+    if (!has_vec_variant(p.n_channels)) { lo = 0; hi = 0; }
+    p.tile_lo = (int)lo; p.tile_hi = (int)hi;
+    const long long n_int = (long long)n_streams * (hi - lo);
+    const long long n_bnd = (long long)n_streams * (p.tiles_per_stream - (hi - lo));
+    if (n_int > 0x7fffffffLL || n_bnd > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (const char *e = getenv("AW_OLSH_WGS_PER_CU")) g_olsh_wgs_per_cu = atoi(e) > 0 ? atoi(e) : 2;
+    if (getenv("AW_DEBUG_OCCUPANCY")) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&aw_fused_olsq_kernel<8, 4, true>), kThreads, kHLdsBytes);
+        hipFuncAttributes fa{};
+        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&aw_fused_olsq_kernel<8, 4, true>));
+        fprintf(stderr, "[aw] olsq<8,4,true>: %d workgroups per CU (regs %d, static LDS %zu, scratch %zu)\n", nb, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes);
+    }
+    const long long max_wgs = (long long)g_persistent_wgs * g_olsh_wgs_per_cu;
+    const dim3 block(kThreads);
+    const bool dom_int = n_int > 0;
+    if (dominant_tiles) *dominant_tiles = dom_int ? n_int : n_bnd;
+    if (!p.flags) return hipErrorInvalidValue;
+    {                                    // sibling workgroups: grid = 2 x (tile slots rounded up to a multiple of 8)
+        auto sib_grid = [&](long long n) {
+            long long slots = n < max_wgs / 2 ? n : max_wgs / 2;
+            slots = (slots + 7) / 8 * 8;
+            return dim3((unsigned)(2 * slots));
+        };
+        if (n_int > 0) {
+            const dim3 grid = sib_grid(n_int);
+            if (ev0) (void)hipEventRecord(ev0, stream);
+            switch (p.n_channels) {
+#define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_fused_olsq_kernel<CS, NP, true>), grid, block, kHLdsBytes, stream, p, n_int); break;
+                AW_FOR_EACH_VEC(AW_CASE)
+#undef AW_CASE
+                default: break;
+            }
+            if (ev1) (void)hipEventRecord(ev1, stream);
+        }
+        if (n_bnd > 0) {
+            p.epoch += 1;
+            const dim3 grid = sib_grid(n_bnd);
+            if (ev0 && !dom_int) (void)hipEventRecord(ev0, stream);
+            bool done = false;
+            switch (p.n_channels) {
+#define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_fused_olsq_kernel<CS, NP, false>), grid, block, kHLdsBytes, stream, p, n_bnd); done = true; break;
+                AW_FOR_EACH_BVEC(AW_CASE)
+#undef AW_CASE
+                default: break;
+            }
+            if (!done) {
+                switch (p.n_pairs <= 4 ? p.n_pairs : 0) {
+#define AW_CASE(NP) case NP: hipLaunchKernelGGL((aw_fused_olsq_kernel<0, NP, false>), grid, block, kHLdsBytes, stream, p, n_bnd); break;
+                    AW_FOR_EACH_GEN(AW_CASE)
+#undef AW_CASE
+                    default: break;
+                }
+            }
+            if (ev1 && !dom_int) (void)hipEventRecord(ev1, stream);
+        }
+        return hipGetLastError();
+    }
 }
 
 // 16384-frame windows: same interior / boundary split, in real frames.

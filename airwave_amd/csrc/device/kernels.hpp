@@ -5,6 +5,7 @@
 #include <cstdint>
 
 #include "tile_ols2.hpp"
+#include "tile_olsh.hpp"
 
 namespace awk {
 
@@ -15,6 +16,10 @@ namespace awk {
 hipError_t launch_fused_ols(const TileParams &p, int n_streams, hipStream_t stream, hipEvent_t ev0 = nullptr,
                             hipEvent_t ev1 = nullptr, long long *dominant_tiles = nullptr);
 const char *fused_ols_kernel_name(int n_channels);
+// the two-workgroups-per-CU cut of the 8192-frame tile (tile_olsh.hpp); same TileParams as launch_fused_ols
+hipError_t launch_fused_olsh(const TileParams &p, int n_streams, hipStream_t stream, hipEvent_t ev0 = nullptr,
+                             hipEvent_t ev1 = nullptr, long long *dominant_tiles = nullptr);
+const char *fused_olsh_kernel_name(int n_channels);
 // 16384-frame windows (tile_ols2.hpp); p.hop / p.hist_len in real frames, p.tab = cf4 tables, p.n_pairs = pseudo-pairs.
 hipError_t launch_fused_ols2(const TileParams &p, int n_streams, hipStream_t stream, hipEvent_t ev0 = nullptr,
                              hipEvent_t ev1 = nullptr, long long *dominant_tiles = nullptr);

@@ -88,6 +88,9 @@ struct TileParams {
     int first_valid;        // first window position that is stored (N - hop)
     int stagger;            // tuning: waves 4-7 idle this many 64-cycle slots after each barrier (phase offset)
     unsigned long long *dbg; // diagnostic builds only (AW_STAMPS): [workgroup][16] s_memtime stamps of wave 0
+    // sibling-workgroup kernels (tile_olsh.hpp) only:
+    int *flags;             // [tiles of the launch]: set to `epoch` by the even-bin workgroup once its output is stored
+    int epoch;              // launch sequence number of this spatializer (flags are never reset)
 };
 constexpr int kStamps = 32;
 
