@@ -35,6 +35,9 @@ WORKLOADS = {
     # the other BASELINE configs (parity-test cases first; benched on request: --workload cfg3|cfg4|cfg5)
     "cfg3": dict(streams=1024, channels=7, hrir=None, taps=32768, seconds=10.0,
                  desc="cfg3: 7 speakers [FL,FR,FC,BL,BR,SL,SR] 48 kHz -> synthetic 14 x 32768-tap HRIR (seed 1234), 1024-stream batch x 10 s"),
+    "cfg3-14ch": dict(streams=1024, channels=14, hrir=None, taps=32768, seconds=10.0, text_map="hesuvi14_custom_map.txt",
+                      desc="cfg3, 14-ch-input reading: InputLayout.detect(14) custom channels through the committed parseHeSuViFormat "
+                           "text map -> synthetic 14 x 32768-tap HRIR (seed 1234), 1024-stream batch x 10 s"),
     "cfg4": dict(streams=512, channels=7, hrir="StageSH1.0.wav", taps=4320, seconds=10.0, rates=[96000], eq=True,
                  desc="cfg4: 7 speakers 96 kHz -> StageSH1.0 resampled x2 (8640 taps) + 10-band parametric EQ, 512 streams/GPU x 10 s"),
     "cfg5": dict(streams=1024, channels=7, hrir="StageSH1.0.wav", taps=4320, seconds=10.0, rates=[44100, 48000, 96000],
@@ -92,8 +95,14 @@ def cpu_baseline(x_host, tracks, lt, rt, frames: int, eq_definition=None, rate: 
         for s in range(y.shape[0]):
             orc.eq_prepare(od, rate).process(y[s, :, 0], y[s, :, 1])
     dt = time.perf_counter() - t0
+    # (i) of SURVEY 8d: one thread = the reference's single audio thread, on one stream and at most 2 s of it
+    f1 = min(frames, int(2 * rate))
+    t1 = time.perf_counter()
+    orc.spatialize_f32(x_host[:1, :f1], tracks, lt, rt, threads=1)
+    dt1 = time.perf_counter() - t1
     return {
         "value": x_host.shape[0] * frames / dt, "unit": "stereo frames/s", "cores": threads, "kind": "port",
+        "single_thread_value": f1 / dt1,
         "sample": f"{x_host.shape[0]} of the batch's streams x {frames} frames (same synthetic input), "
                   f"one stream per thread, oracle/airwave_oracle.c (reference algorithm, B=512); "
                   f"the Swift/vDSP reference itself cannot run on Linux",
@@ -156,7 +165,10 @@ def main() -> None:
 
     # One leg per sample rate (cfg 5 buckets streams by rate; every other workload has one leg).
     stream_rates = [rates[i * len(rates) // S] for i in range(S)] if len(rates) > 1 else [rates[0]] * S
-    batch = aw.MixedRateBatch(tracks, 48000.0, layout, stream_rates, ctx=ctx)
+    cmap = None
+    if wl.get("text_map"):            # the 14-channel reading of cfg 3: custom channels mapped by a HeSuVi-style text map
+        cmap = aw.HRIRChannelMap.parseHeSuViFormat(open(os.path.join(ROOT, "tests", "golden", wl["text_map"])).read())
+    batch = aw.MixedRateBatch(tracks, 48000.0, layout, stream_rates, hrirMap=cmap, ctx=ctx)
     eq_def = None
     if wl.get("eq"):
         eq_def = aw.EqualizerAPOParser.parse(open(os.path.join(ROOT, "tests", "golden", "eq", "CCA CRA ParametricEq.txt"), "rb").read(), "CCA CRA ParametricEq.txt")
