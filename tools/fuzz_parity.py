@@ -1,0 +1,56 @@
+"""Randomised GPU parity sweep (run on the GPU box; not part of the test suite): random channel counts, HRIR lengths,
+stream counts, call splits and kernel choices against the float64 oracle.  Prints every failure and a summary."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import airwave_amd as aw
+import airwave_oracle as orc
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 240.0
+rng = np.random.default_rng(seed)
+TOL = 1e-5
+fails, n = [], 0
+t_end = time.time() + budget
+while time.time() < t_end:
+    C = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 14, 16]))
+    taps = int(rng.choice([1, 2, 3, 17, 255, 256, 1000, 2799, 2800, 4096, 4320, 5399, 5400, 5900, 6145, 6146, 8640, 12289, 12290, 16000]))
+    if rng.random() < 0.3:
+        taps = int(rng.integers(1, 14000))
+    S = int(rng.choice([1, 2, 3, 5]))
+    total = int(rng.integers(1, 60000)) if rng.random() < 0.8 else int(rng.choice([1, 2, 3839, 3840, 3841, 8191, 8192, 8193, 16384]))
+    env = {}
+    r = rng.random()
+    if r < 0.25: env["AW_WINDOW"] = "8192"
+    elif r < 0.5: env["AW_WINDOW"] = "16384"
+    if rng.random() < 0.25: env["AW_KERNEL_H"] = "2"
+    for k in ("AW_WINDOW", "AW_KERNEL_H"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    n_tracks = int(rng.choice([2, 7, 14]))
+    h = orc.synth_hrir(n_tracks, taps, seed=int(rng.integers(1 << 30)))
+    lt = rng.integers(-1 if rng.random() < 0.2 else 0, n_tracks, size=C).astype(np.int32)
+    rt = rng.integers(0, n_tracks, size=C).astype(np.int32)
+    rt[lt < 0] = -1                                   # an unmapped channel is skipped (both ears)
+    if (lt < 0).all():
+        lt[0], rt[0] = 0, n_tracks - 1
+    x = orc.synth_input(S, total, C, seed=int(rng.integers(1 << 30)))
+    cuts = sorted(set(int(c) for c in rng.integers(0, total + 1, size=int(rng.integers(0, 4))))) if total > 1 else []
+    bounds = [0] + [c for c in cuts if 0 < c < total] + [total]
+    try:
+        sp = aw.Spatializer(aw.HRIR(h), lt, rt, n_streams=S)
+        info = sp.info()
+        y = np.concatenate([sp.process(x[:, a:b]) for a, b in zip(bounds[:-1], bounds[1:])], axis=1)
+        err = 0.0
+        for s in range(S):
+            ref = orc.spatialize_f64(x[s], h, lt, rt)
+            err = max(err, orc.peak_rel_error(y[s], ref))
+        ok = np.isfinite(y).all() and err < TOL
+    except Exception as e:                              # noqa: BLE001
+        ok, err, info = False, repr(e), None
+    n += 1
+    if not ok:
+        fails.append((C, taps, S, total, bounds, env, n_tracks, lt.tolist(), rt.tolist(), info, err))
+        print("FAIL", fails[-1], flush=True)
+print(f"seed {seed}: {n} cases, {len(fails)} failures")
