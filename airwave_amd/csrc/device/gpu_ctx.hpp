@@ -28,7 +28,9 @@ struct GpuCtx {
     unsigned long long st_[kStamps];
 #endif
     __device__ __forceinline__ void stamp(int i) {
-#if AW_STAMPS
+#if defined(AW_MARK_STAMPS)       // probe builds: an assembler comment per stamp, to find the phases in the ISA listing
+        asm volatile("; AW_STAMP %0" ::"s"(i));
+#elif AW_STAMPS
         unsigned long long tm;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm)::"memory");
         st_[i] = tm;
