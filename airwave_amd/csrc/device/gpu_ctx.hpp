@@ -139,18 +139,26 @@ struct GpuCtx {
         (void)flag; (void)epoch;
 #endif
     }
-    __device__ __forceinline__ void flag_acquire(int *flag, int epoch) const {
+    // Every spin is bounded (~1 s): a sibling that never arrives sets the launch's error word instead of hanging the GPU;
+    // the host reports it at the next call (runtime.cpp).
+    __device__ __forceinline__ void flag_acquire(int *flag, int epoch, int *error_word) const {
 #if AW_SIB_SYNC == 2
-        if (threadIdx.x == 0)
-            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(4);
+        if (threadIdx.x == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(4);
+            if (spins >= (1 << 22)) (void)__hip_atomic_exchange(error_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #elif AW_SIB_SYNC == 1
-        if (threadIdx.x == 0)
-            while (__hip_atomic_fetch_add(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+        if (threadIdx.x == 0) {
+            int spins = 0;
+            while (__hip_atomic_fetch_add(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(4);
+            if (spins >= (1 << 22)) (void)__hip_atomic_exchange(error_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
 #else
-        (void)flag; (void)epoch;
+        (void)flag; (void)epoch; (void)error_word;
 #endif
     }
     // the odd-bin sibling's read of what its partner stored: around the L1 (sc0), from the XCD's L2

@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 namespace awk {
 
@@ -278,6 +279,38 @@ hipError_t launch_fused_ols(const TileParams &p_in, int n_streams, hipStream_t s
         if (ev1 && !dom_int) (void)hipEventRecord(ev1, stream);
     }
     return hipGetLastError();
+}
+
+// Placement probe for the sibling kernels: their cheap flag protocol needs workgroups b and b + 8 on one XCD (one L2).
+// HIP does not promise that, so it is measured, with the launch shape the kernels use, before they are enabled.
+__global__ void __launch_bounds__(kThreads, 4) aw_xcc_probe_kernel(int *out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (threadIdx.x == 0) {
+        smem[0] = 1;                                                    // the LDS allocation is part of the launch shape
+        out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 0xf);   // HW_REG_XCC_ID[3:0]
+    }
+}
+
+hipError_t probe_sibling_placement(hipStream_t stream, bool *ok) {
+    *ok = false;
+    const int grid = 2 * g_persistent_wgs / 16 * 16;
+    if (grid < 16) return hipSuccess;
+    int *d = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d), grid * sizeof(int));
+    if (e != hipSuccess) return e;
+    std::vector<int> h((size_t)grid, -1);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_xcc_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kHLdsBytes);
+    for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) {
+        hipLaunchKernelGGL(aw_xcc_probe_kernel, dim3((unsigned)grid), dim3(kThreads), kHLdsBytes, stream, d);
+        e = hipMemcpyAsync(h.data(), d, grid * sizeof(int), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) break;
+        bool good = true;
+        for (int b = 8; b < grid; ++b) good = good && h[b] == h[b - 8] && h[b] >= 0;
+        if (rep == 0) *ok = good; else *ok = *ok && good;
+    }
+    (void)hipFree(d);
+    return e;
 }
 
 // The same split for the sibling-workgroup kernels (tile_olsh.hpp): grid = 2 workgroups per CU.

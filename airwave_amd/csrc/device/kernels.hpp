@@ -20,6 +20,8 @@ const char *fused_ols_kernel_name(int n_channels);
 hipError_t launch_fused_olsh(const TileParams &p, int n_streams, hipStream_t stream, hipEvent_t ev0 = nullptr,
                              hipEvent_t ev1 = nullptr, long long *dominant_tiles = nullptr);
 const char *fused_olsh_kernel_name(int n_channels);
+// measures whether workgroups b and b + 8 of the sibling kernels' launch shape share an XCD (two probe launches, synchronous)
+hipError_t probe_sibling_placement(hipStream_t stream, bool *ok);
 // 16384-frame windows (tile_ols2.hpp); p.hop / p.hist_len in real frames, p.tab = cf4 tables, p.n_pairs = pseudo-pairs.
 hipError_t launch_fused_ols2(const TileParams &p, int n_streams, hipStream_t stream, hipEvent_t ev0 = nullptr,
                              hipEvent_t ev1 = nullptr, long long *dominant_tiles = nullptr);

@@ -89,7 +89,7 @@ struct TileParams {
     int stagger;            // tuning: waves 4-7 idle this many 64-cycle slots after each barrier (phase offset)
     unsigned long long *dbg; // diagnostic builds only (AW_STAMPS): [workgroup][16] s_memtime stamps of wave 0
     // sibling-workgroup kernels (tile_olsh.hpp) only:
-    int *flags;             // [tiles of the launch]: set to `epoch` by the even-bin workgroup once its output is stored
+    int *flags;             // [tiles of the launch]: set to `epoch` by the even-bin workgroup once its output is stored; flags[-1] = error word
     int epoch;              // launch sequence number of this spatializer (flags are never reset)
 };
 constexpr int kStamps = 32;

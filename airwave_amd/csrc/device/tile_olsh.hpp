@@ -117,7 +117,9 @@ AW_HD void load_fold4(const TileParams &p, const float *in_s, const float *hist_
 // for the flag and adds its term (it is dispatched after its sibling — higher workgroup id — so the wait cannot
 // deadlock).  CAVEAT: the cheap flag protocol (gpu_ctx.hpp, AW_SIB_SYNC=1) relies on both siblings sharing one L2,
 // i.e. on workgroup id % 8 selecting the XCD; agent-scope fences (AW_SIB_SYNC=2) are portable but write back and
-// invalidate the whole L2 on gfx950 (7.5 ms per launch).  One more reason this variant is opt-in.
+// invalidate the whole L2 on gfx950 (7.5 ms per launch).  Guards: the runtime enables these kernels only after a probe
+// launch of the same shape has shown blocks b and b + 8 on one XCD (kernels.hip: probe_sibling_placement, HW_REG_XCC_ID),
+// and every flag wait is bounded — a timeout sets the launch's error word, which the next call turns into an error.
 template <bool INV, class Ctx>
 AW_HD void sub_fft512x1(Ctx &ctx, cf (&a)[8], cf *scr, const cf *twa, const cf *twb, int lane) {
     fft8<INV>(a);
@@ -301,7 +303,7 @@ AW_HD void tiles_fused_olsq_half(Ctx &ctx, const TileParams &p, long long first,
             }
             ctx.flag_release(p.flags + id, p.epoch);
         } else {
-            ctx.flag_acquire(p.flags + id, p.epoch);
+            ctx.flag_acquire(p.flags + id, p.epoch, p.flags - 1);      // p.flags[-1]: the launch error word
             cf a[8], b[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {

@@ -257,6 +257,10 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
     } else if (fits1) {
         sp->path = 0;
         if (const char *e = getenv("AW_KERNEL_H")) sp->fusedh = atoi(e) == 2 ? 2 : 0;     // experimental sibling-workgroup kernels (tile_olsh.hpp)
+        if (sp->fusedh) {           // ... only where the dispatcher is measured to co-locate siblings (their flag protocol needs one L2)
+            bool ok = false;
+            if (awk::probe_sibling_placement(ctx->stream, &ok) != hipSuccess || !ok) sp->fusedh = 0;
+        }
         sp->hop = align_hop(N - (hrir->taps - 1));
         sp->hist_len = N - sp->hop;
         sp->partitions = 1;
@@ -417,7 +421,13 @@ static aw_status sp_process_fused(aw_spatializer *sp, const float *in, float *ou
     }
 #endif
     if (sp->fusedh == 2) {
-        const size_t need = (size_t)sp->n_streams * p.tiles_per_stream;
+        const size_t need = (size_t)sp->n_streams * p.tiles_per_stream + 1;       // word 0: error word of the bounded spins
+        if (sp->d_flags && sp->epoch > 0) {      // a sibling timed out in an earlier call: its output is not trustworthy
+            int err = 0;
+            AW_HIP_TRY(hipMemcpyAsync(&err, sp->d_flags, sizeof(int), hipMemcpyDeviceToHost, sp->ctx->stream));
+            AW_HIP_TRY(hipStreamSynchronize(sp->ctx->stream));
+            if (err) return fail(AW_ERR_HIP, "sibling-workgroup kernel: a tile flag wait timed out in a previous call (AW_KERNEL_H=2 is experimental; unset it)");
+        }
         if (sp->flags_cap < need) {
             if (sp->d_flags) AW_HIP_TRY(hipFree(sp->d_flags));
             sp->d_flags = nullptr; sp->flags_cap = 0;
@@ -425,11 +435,11 @@ static aw_status sp_process_fused(aw_spatializer *sp, const float *in, float *ou
             AW_HIP_TRY(hipMemsetAsync(sp->d_flags, 0, need * sizeof(int), sp->ctx->stream));
             sp->flags_cap = need;
         }
-        p.flags = sp->d_flags;
+        p.flags = sp->d_flags + 1;
         p.epoch = sp->epoch + 1;          // the launcher uses epoch and epoch + 1 (interior, boundary launch)
         sp->epoch += 2;
         if (sp->epoch > 0x7ffffff0) {     // wrap: start over with cleared flags
-            AW_HIP_TRY(hipMemsetAsync(sp->d_flags, 0, sp->flags_cap * sizeof(int), sp->ctx->stream));
+            AW_HIP_TRY(hipMemsetAsync(sp->d_flags + 1, 0, (sp->flags_cap - 1) * sizeof(int), sp->ctx->stream));
             sp->epoch = 0;
         }
     }

@@ -61,7 +61,7 @@ struct EmuCtx {
     // sibling flags: the emulation runs workgroups one after the other, the even-bin one first
     void flag_release(int *flag, int epoch) const { sh->wg.arrive_and_wait(); if (tid_ == 0) *flag = epoch; }
     awk::cf ld_out(const float *q) const { return *reinterpret_cast<const awk::cf *>(q); }
-    void flag_acquire(int *flag, int epoch) const { if (*flag != epoch) std::abort(); sh->wg.arrive_and_wait(); }
+    void flag_acquire(int *flag, int epoch, int *) const { if (*flag != epoch) std::abort(); sh->wg.arrive_and_wait(); }
 };
 
 }  // namespace
@@ -161,7 +161,7 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
     p.tile_lo = (int)lo; p.tile_hi = (int)hi;
     EmuShared sh;
     std::vector<int> flags((size_t)n_streams * p.tiles_per_stream + 1, 0);
-    p.flags = flags.data();
+    p.flags = flags.data() + 1;
     // emulate a persistent launch with a few workgroups, each walking several tiles
     auto run = [&](bool interior, long long n_tiles) {
         const long long G = n_tiles < 3 ? n_tiles : 3;
