@@ -109,6 +109,7 @@ SIGNATURES = {
     "aw_eq_drain_retired": (_I32, [_V]),
     "aw_eq_process": (_I32, [_V, _V, _V, _I64]),
     "aw_eq_process_planar": (_I32, [_V, c_float_p, c_float_p, c_float_p, c_float_p, _I32]),
+    "aw_eq_debug_hold_publication_lock": (_I32, [_V, _I32]),
     "aw_eq_transition_length": (_I32, [_V]),
     "aw_eq_is_transitioning": (_I32, [_V]),
 }

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 
@@ -126,7 +127,11 @@ struct aw_eq {
     int n_streams = 0, max_frames = 0;
     double sample_rate = 0;
     long long transition_length = 1, transition_frame = 0;
-    EqStatePtr unity, active, from, to, pending_target, observed, published, audio_target, pending_retirement, retired;
+    // render-thread state (touched by aw_eq_process only)
+    EqStatePtr unity, active, from, to, pending_target, observed, audio_target, pending_retirement;
+    // shared with the control thread, each behind its own lock (targetLock, retirementLock, resetLock :129-131)
+    std::mutex target_lock, retirement_lock, reset_lock;
+    EqStatePtr published, retired;
     bool reset_requested = false;
     float *d_old = nullptr, *d_new = nullptr;   // [stream][transition_length][2] crossfade scratch (oldScratch/newScratch :137-140)
     float *d_stage = nullptr;                   // planar host entry staging
@@ -281,21 +286,29 @@ aw_status aw_eq_set_target(aw_eq *eq, const aw_eq_definition *def) {            
     EqStatePtr s;
     const aw_status st = prepare_state(eq->ctx, def ? &def->def : nullptr, eq->sample_rate, eq->n_streams, s);
     if (st != AW_OK) return st;
+    std::lock_guard<std::mutex> g(eq->target_lock);                                         // publish :219-227
     eq->published = std::move(s);
     return AW_OK;
 }
 aw_status aw_eq_reset(aw_eq *eq) {                                                          // :230-234
     if (!eq) return fail(AW_ERR_INVALID_ARGUMENT, "eq is NULL");
+    std::lock_guard<std::mutex> g(eq->reset_lock);
     eq->reset_requested = true;
     return AW_OK;
 }
 aw_status aw_eq_drain_retired(aw_eq *eq) {                                                  // :237-241
     if (!eq) return fail(AW_ERR_INVALID_ARGUMENT, "eq is NULL");
-    if (eq->retired) {
+    EqStatePtr gone;
+    {
+        std::lock_guard<std::mutex> g(eq->retirement_lock);
+        gone = std::move(eq->retired);
+        eq->retired.reset();
+    }
+    if (gone) {
         // the state's buffers may still be read by queued kernels: let the stream finish before freeing
         AW_HIP_TRY(hipSetDevice(eq->ctx->device));
         AW_HIP_TRY(hipStreamSynchronize(eq->ctx->stream));
-        eq->retired.reset();
+        gone.reset();
     }
     return AW_OK;
 }
@@ -308,7 +321,12 @@ static void eq_begin_transition(aw_eq *eq, const EqStatePtr &target) {          
 }
 static bool eq_retire(aw_eq *eq, const EqStatePtr &state) {                                 // :373-386
     if (eq->pending_retirement) return false;
-    if (!eq->retired) { eq->retired = state; return true; }
+    bool parked = false;
+    if (eq->retirement_lock.try_lock()) {                                                   // withLockIfAvailable :380
+        if (!eq->retired) { eq->retired = state; parked = true; }
+        eq->retirement_lock.unlock();
+    }
+    if (parked) return true;
     eq->pending_retirement = state;
     return false;
 }
@@ -328,7 +346,10 @@ static void eq_finish_transition(aw_eq *eq) {                                   
     eq_start_pending(eq);
 }
 static void eq_observe(aw_eq *eq) {                                                         // :311-333
-    if (eq->published) eq->audio_target = eq->published;
+    if (eq->target_lock.try_lock()) {                                                       // withLockIfAvailable :322: contended -> keep the prior target
+        if (eq->published) eq->audio_target = eq->published;
+        eq->target_lock.unlock();
+    }
     const EqStatePtr &t = eq->audio_target;
     if (!t || t == eq->observed) return;
     eq->observed = t;
@@ -341,8 +362,13 @@ static void eq_observe(aw_eq *eq) {                                             
     }
 }
 static void eq_flush_pending_retirement(aw_eq *eq) {                                        // :388-406
-    if (!eq->pending_retirement || eq->retired) return;
-    eq->retired = std::move(eq->pending_retirement);
+    if (!eq->pending_retirement) return;
+    bool parked = false;
+    if (eq->retirement_lock.try_lock()) {                                                   // :393
+        if (!eq->retired) { eq->retired = eq->pending_retirement; parked = true; }
+        eq->retirement_lock.unlock();
+    }
+    if (!parked) return;
     eq->pending_retirement.reset();
     eq_start_pending(eq);
 }
@@ -355,8 +381,13 @@ aw_status aw_eq_process(aw_eq *eq, const float *in, float *out, int64_t frames) 
     AW_HIP_TRY(hipSetDevice(eq->ctx->device));
     eq_observe(eq);
     eq_flush_pending_retirement(eq);
-    if (eq->reset_requested) {                                                              // applyPendingReset :335-347
+    bool do_reset = false;
+    if (eq->reset_lock.try_lock()) {                                                        // applyPendingReset :335-347 (:342: contended -> next call)
+        do_reset = eq->reset_requested;
         eq->reset_requested = false;
+        eq->reset_lock.unlock();
+    }
+    if (do_reset) {
         for (const EqStatePtr *s : {&eq->active, &eq->from, &eq->to})
             if (*s) {
                 const aw_status st = state_reset(**s);
@@ -404,6 +435,14 @@ aw_status aw_eq_process_planar(aw_eq *eq, const float *in_l, const float *in_r, 
     AW_HIP_TRY(hipMemcpyAsync(out_l, d_l, sizeof(float) * frames, hipMemcpyDeviceToHost, s));
     AW_HIP_TRY(hipMemcpyAsync(out_r, d_r, sizeof(float) * frames, hipMemcpyDeviceToHost, s));
     AW_HIP_TRY(hipStreamSynchronize(s));
+    return AW_OK;
+}
+
+// withPublicationLockForTesting (:229-233, DEBUG builds of the reference): hold = 1 takes the publication lock, 0 releases it
+// (same thread).  Lets a test show that a render call under contention keeps its prior target.
+aw_status aw_eq_debug_hold_publication_lock(aw_eq *eq, int32_t hold) {
+    if (!eq) return fail(AW_ERR_INVALID_ARGUMENT, "eq is NULL");
+    if (hold) eq->target_lock.lock(); else eq->target_lock.unlock();
     return AW_OK;
 }
 

@@ -227,6 +227,13 @@ class ParametricEqualizerProcessor:
     def drainRetiredStates(self) -> None:
         _check(self._lib.aw_eq_drain_retired(self._h))
 
+    def withPublicationLockForTesting(self, body) -> None:      # ParametricEqualizerProcessor.swift:229-233 (DEBUG)
+        _check(self._lib.aw_eq_debug_hold_publication_lock(self._h, 1))
+        try:
+            body()
+        finally:
+            _check(self._lib.aw_eq_debug_hold_publication_lock(self._h, 0))
+
     @property
     def isTransitioning(self) -> bool:
         return bool(self._lib.aw_eq_is_transitioning(self._h))

@@ -261,7 +261,10 @@ AW_API double aw_eq_state_preamp_linear(const aw_eq_state *s);
  * target that the next process call crossfades to over max(1, round(0.020 * sample_rate)) frames
  * (:155); newest target wins while a fade runs (:311-333); a finished fade parks the old state in a
  * one-slot retirement box that aw_eq_drain_retired empties, and a full box holds the next fade back
- * (:373-406).  max_frames_per_callback: 0 = unlimited (batch); otherwise the reference's guard
+ * (:373-406).  Threads, as in the reference: aw_eq_set_target / aw_eq_reset / aw_eq_drain_retired may be called
+ * from a control thread while ONE other thread is inside aw_eq_process*, which only tries the publication, reset and
+ * retirement locks (:322,:342,:380,:393) and, when one is contended, keeps its prior target / applies the reset on a
+ * later call / defers the retirement.  max_frames_per_callback: 0 = unlimited (batch); otherwise the reference's guard
  * 1..4096 (:148-150, AW_ERR_EQ_TOO_MANY_FILTERS as there) and process() rejects longer calls. */
 typedef struct aw_eq aw_eq;
 AW_API aw_status aw_eq_create(aw_context *ctx, double sample_rate, int32_t n_streams, int32_t max_frames_per_callback,
@@ -275,6 +278,8 @@ AW_API aw_status aw_eq_process(aw_eq *eq, const float *in_device, float *out_dev
  * in_right may be NULL (left is duplicated, :68); synchronous. */
 AW_API aw_status aw_eq_process_planar(aw_eq *eq, const float *in_left, const float *in_right, float *out_left,
                                       float *out_right, int32_t frames);
+/* withPublicationLockForTesting :229-233: hold != 0 takes the publication lock, 0 releases it (same thread). */
+AW_API aw_status aw_eq_debug_hold_publication_lock(aw_eq *eq, int32_t hold);
 AW_API int32_t aw_eq_transition_length(const aw_eq *eq);
 AW_API int32_t aw_eq_is_transitioning(const aw_eq *eq);
 

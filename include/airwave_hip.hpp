@@ -152,6 +152,11 @@ class ParametricEqualizerProcessor {
     ParametricEqualizerProcessor(const ParametricEqualizerProcessor &) = delete;
     void setTarget(const EqualizerDefinition *definition) { check(aw_eq_set_target(h_, definition ? definition->get() : nullptr)); }   // :226
     void reset() { check(aw_eq_reset(h_)); }                                                                                          // :230
+    template <class F> void withPublicationLockForTesting(F body) {                                                                   // :229-233
+        check(aw_eq_debug_hold_publication_lock(h_, 1));
+        body();
+        check(aw_eq_debug_hold_publication_lock(h_, 0));
+    }
     void drainRetiredStates() { check(aw_eq_drain_retired(h_)); }                                                                     // :237
     void process(const float *inputLeft, const float *inputRight, float *leftOutput, float *rightOutput, int frameCount) {          // :253
         check(aw_eq_process_planar(h_, inputLeft, inputRight, leftOutput, rightOutput, frameCount));

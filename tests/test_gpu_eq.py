@@ -142,6 +142,70 @@ def test_rapid_publication_queues_newest(aw):
     assert abs(run(p, 960)[0][-1] - db(-6)) < 1e-5
 
 
+def test_render_callback_keeps_prior_target_when_publication_lock_is_contended(aw):
+    """ParametricEqualizerProcessorTests.swift:285-302: a control thread sits inside the publication lock; the render call
+    must not wait for it and keeps its prior (unity) target although a new one has been published."""
+    import threading
+    p = aw.ParametricEqualizerProcessor(48000.0)
+    p.setTarget(aw.EqualizerDefinition(0.0, [flt(aw, 0, 1000.0, 6.0, 0.707)]))      # published, not yet observed
+    entered, release = threading.Event(), threading.Event()
+
+    def hold():
+        p.withPublicationLockForTesting(lambda: (entered.set(), release.wait(5.0)))
+
+    th = threading.Thread(target=hold)
+    th.start()
+    assert entered.wait(5.0)
+    try:
+        left, right = p.process(np.full(128, 1.0, np.float32), np.full(128, 2.0, np.float32))
+    finally:
+        release.set()
+        th.join()
+    assert np.array_equal(left, np.full(128, 1.0, np.float32)) and np.array_equal(right, np.full(128, 2.0, np.float32))
+    assert not p.isTransitioning
+    # lock released: the next call observes the published target and starts the fade
+    left2, _ = p.process(np.full(128, 1.0, np.float32), np.full(128, 2.0, np.float32))
+    assert p.isTransitioning and not np.array_equal(left2, left)
+
+
+def test_control_thread_calls_run_beside_the_render_loop(aw):
+    """setTarget / reset / drainRetiredStates from a second thread while the first keeps calling process (the reference's
+    threading model, ParametricEqualizerProcessor.swift:120-131): no deadlock, finite output, the last target wins."""
+    import threading
+    p = aw.ParametricEqualizerProcessor(48000.0)
+    stop = threading.Event()
+    errors = []
+
+    def control():
+        try:
+            i = 0
+            while not stop.is_set():
+                p.setTarget(aw.EqualizerDefinition(-1.0, [flt(aw, i % 3, 200.0 + 50.0 * (i % 40), 3.0, 1.0)]) if i % 5 else None)
+                p.drainRetiredStates()
+                if i % 7 == 0:
+                    p.reset()
+                i += 1
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(e)
+
+    th = threading.Thread(target=control)
+    th.start()
+    try:
+        x = np.linspace(-0.5, 0.5, 480, dtype=np.float32)
+        for _ in range(300):
+            l, r = p.process(x, x)
+            assert np.isfinite(l).all() and np.isfinite(r).all()
+    finally:
+        stop.set()
+        th.join()
+    assert not errors
+    p.setTarget(None)
+    for _ in range(6):
+        p.drainRetiredStates()
+        l, r = p.process(x, x)
+    assert np.array_equal(l, x) and np.array_equal(r, x)             # settled on unity
+
+
 def test_retirement_pressure(aw):
     p = aw.ParametricEqualizerProcessor(48000.0)                                                # :268-293
     g1, g2, g3 = db(6), db(-6), db(12)
