@@ -247,6 +247,10 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
         const int c = n_in;
         const int from = c == 2 ? 2800 : (c >= 3 && c <= 6) ? 5400 : (c == 7 || c == 8) ? 5900 : (1 << 30);
         window = hrir->taps >= from ? awk::kN2 : AW_DEFAULT_WINDOW;
+        // small batches cannot fill 256 CUs with 16384-frame tiles (a 10 s stereo stream is 40 of them): the 8192-frame
+        // kernels give three times the tiles.  Measured (stereo, 4320 taps, 10 s): 1 stream 7.9 -> 14.1, 4 streams
+        // 28.9 -> 41.4 G frames/s, 16 streams equal, 64 streams 16384 ahead (80 -> 97)
+        if (window == awk::kN2 && n_streams < 16 && fits1) window = awk::kN;
     }
     if ((window == awk::kN2 && fits2) || (!fits1 && fits2)) {
         sp->path = 0; sp->fused2 = true;

@@ -39,9 +39,8 @@ def test_goldens_via_preset_activation(aw, oracle, golden_dir, gold, wavname, sp
     layout = aw.InputLayout.detect(speakers) if isinstance(speakers, int) else aw.InputLayout(speakers, "custom")
     mgr = aw.HRIRManager()
     sp = mgr.activatePreset(os.path.join(golden_dir, "hrtf", wavname), 48000.0, layout)
-    # 4320 taps: stereo runs on 16384-frame windows (hop 16384 - 4320), wider layouts on 8192-frame ones
-    two = len(layout.channels) == 2
-    assert mgr.isReady and sp.info()["path"] == 0 and sp.info()["hop"] == _aligned(16384 - 4320 if two else 8192 - 4319)
+    # 4320 taps, one stream: 8192-frame windows for every layout (stereo moves to 16384-frame windows from 16 streams)
+    assert mgr.isReady and sp.info()["path"] == 0 and sp.info()["hop"] == _aligned(8192 - 4319)
     x = oracle.synth_input(1, int(g["frames"]), len(layout.channels), seed=int(g["seed"]))
     y = sp.process(x)
     assert not np.isnan(y).any()
@@ -117,10 +116,26 @@ def test_hrir_lengths_on_the_fused_path(aw, oracle, taps):
     h = oracle.synth_hrir(4, taps, seed=taps)
     x = oracle.synth_input(1, 2 * (8192 - taps + 1) + 5, 2, seed=9)
     sp = aw.Spatializer(aw.HRIR(h), [0, 2], [1, 3])
-    assert sp.info()["path"] == 0 and sp.info()["hop"] == _aligned(8192 - (taps - 1) if taps < 2800 else 16384 - 2 * (taps // 2))
+    assert sp.info()["path"] == 0 and sp.info()["hop"] == _aligned(8192 - (taps - 1))
     y = sp.process(x)
     ref = oracle.spatialize_f64(x[0], h, [0, 2], [1, 3])
     assert oracle.peak_rel_error(y[0], ref) < TOL
+
+
+@pytest.mark.parametrize("channels,taps,streams,fft", [(2, 4320, 1, 8192), (2, 4320, 15, 8192), (2, 4320, 16, 16384), (2, 2799, 64, 8192),
+                                                       (8, 4320, 128, 8192), (8, 5900, 16, 16384), (8, 5900, 4, 8192), (2, 6146, 1, 16384)])
+def test_window_policy(aw, oracle, channels, taps, streams, fft):
+    """runtime.cpp: the measured crossover of the two fused kernels by layout and HRIR length, 8192-frame windows for
+    batches too small to fill the chip with 16384-frame tiles, 16384 whenever one 8192-frame window cannot hold the HRIR."""
+    h = oracle.synth_hrir(14, taps, seed=1)
+    lt = (np.arange(channels) % 14).astype(np.int32)
+    rt = ((np.arange(channels) + 7) % 14).astype(np.int32)
+    sp = aw.Spatializer(aw.HRIR(h), lt, rt, n_streams=streams)
+    assert sp.info()["path"] == 0 and sp.info()["fft"] == fft
+    x = oracle.synth_input(streams, 20011, channels, seed=3)
+    y = sp.process(x)
+    s = streams - 1
+    assert oracle.peak_rel_error(y[s], oracle.spatialize_f64(x[s], h, lt, rt)) < TOL
 
 
 def test_ragged_call_sizes_carry_state_exactly(aw, oracle, golden_dir):
