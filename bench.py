@@ -207,9 +207,10 @@ def main() -> None:
     for _ in range(args.steps):
         step(timed=True)
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1:                     # the timed region ends, like it starts, with a barrier + synchronize on every rank
         dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
     frames_step = sum(g["n"] * g["F"] for g in legs)
 
     # RCCL over xGMI: the only collective of the run (sum of frames, max of elapsed)
