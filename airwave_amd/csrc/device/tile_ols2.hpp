@@ -234,14 +234,19 @@ AW_HD void tiles_fused_ols2(Ctx &ctx, const TileParams &p, long long first, long
             ctx.stamp(4 * (b & 3));                      // diagnostic builds: batch top / pass 1 done / barrier / first pair done
             t = ctx.opaque_i(t);                         // per-batch addresses are recomputed, not held across batches
             lane = t & 63;
+            // an odd pseudo-pair count (odd channel counts: 7 pseudo-pairs for 7 channels, 1 for mono) leaves the last
+            // batch with one pair; with a compile-time layout its phantom partner is skipped instead of transformed
+            const bool two = !(CS > 0 && NB > 0 && CS % 2 == 1 && b == NB - 1);
             {
                 cf x[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][0], raw[j][1]);
                 pair_pass1_lean(x, ctx.opaque(w1), buf0, t);
+                if (two) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][2], raw[j][3]);
-                pair_pass1_lean(x, ctx.opaque(w1), buf1, t);
+                    for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][2], raw[j][3]);
+                    pair_pass1_lean(x, ctx.opaque(w1), buf1, t);
+                }
             }
             ctx.stamp(4 * (b & 3) + 1);
             ctx.barrier();
@@ -251,7 +256,7 @@ AW_HD void tiles_fused_ols2(Ctx &ctx, const TileParams &p, long long first, long
             // the next batch's frames travel under the second pair's sub-FFTs, in two halves: all 16 pseudo-frames
             // at once (64 VGPRs) on top of the 64 accumulator registers is what hipcc spills
             if (more) load_batch2<CS, INTERIOR, 0, AW_OLS2_SPLIT>(p, in_s, hist_s, f0, t, 4 * (b + 1), raw);
-            pair_subfft_cmac2(ctx, p, 2 * b + 1, buf1, twa, twb, lane, wave, we, wo);   // a phantom pair hits the zero pair
+            if (two) pair_subfft_cmac2(ctx, p, 2 * b + 1, buf1, twa, twb, lane, wave, we, wo);   // run-time layouts: a phantom pair hits the zero pair
             if (more) load_batch2<CS, INTERIOR, AW_OLS2_SPLIT, 16>(p, in_s, hist_s, f0, t, 4 * (b + 1), raw);
         };
         if constexpr (NB > 0) {
