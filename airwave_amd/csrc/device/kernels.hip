@@ -101,20 +101,22 @@ __global__ void __launch_bounds__(kThreads) aw_fused_ols2_kernel(TileParams p, l
     tiles_fused_ols2<GpuCtx, CS, NB, INTERIOR>(ctx, p, lo + slot, per_xcd_wg, hi);
 }
 // (real channels, batches): 2C pseudo-channels in batches of four
-#define AW_FOR_EACH_VEC2(X) X(1, 1) X(2, 1) X(4, 2) X(6, 3) X(7, 4) X(8, 4)
+#define AW_FOR_EACH_VEC2(X) X(1, 1) X(2, 1) X(3, 2) X(4, 2) X(5, 3) X(6, 3) X(7, 4) X(8, 4)
 
 const char *fused_ols2_kernel_name(int C) {
     switch (C) {
         case 1: return "aw_fused_ols2_kernel<1, 1, true>";
         case 2: return "aw_fused_ols2_kernel<2, 1, true>";
+        case 3: return "aw_fused_ols2_kernel<3, 2, true>";
         case 4: return "aw_fused_ols2_kernel<4, 2, true>";
+        case 5: return "aw_fused_ols2_kernel<5, 3, true>";
         case 6: return "aw_fused_ols2_kernel<6, 3, true>";
         case 7: return "aw_fused_ols2_kernel<7, 4, true>";
         case 8: return "aw_fused_ols2_kernel<8, 4, true>";
         default: return "aw_fused_ols2_kernel<0, 0, false>";
     }
 }
-static bool has_vec2_variant(int C) { return C == 1 || C == 2 || C == 4 || C == 6 || C == 7 || C == 8; }
+static bool has_vec2_variant(int C) { return C >= 1 && C <= 8; }
 
 // Kernel variants.  Vectorised interior kernels <CS, NP, true> exist for the channel counts whose
 // frames are whole float4s/float2s (2, 4, 8, 12, 16 channels: stereo ... 7.1.4 + 4); every other

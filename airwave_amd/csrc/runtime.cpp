@@ -241,11 +241,13 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
     const int hist2 = awh::poly_history_frames(hrir->taps);          // 16384-frame windows (tile_ols2.hpp)
     const bool fits1 = hrir->taps - 1 <= N - 2048, fits2 = hist2 <= awk::kN2 - 4096;
     if (window == 0) {
-        // measured crossover of the two fused kernels (tools/window_sweep.py, 128 streams): stereo gains from the
-        // long window from ~2800 taps (one batch per tile, few spills: 4320 taps 84 -> 110 G frames/s), 3-6 channels
-        // from ~5400, 7-8 channels from ~5900; everything else only when one 8192-frame window cannot hold the HRIR
+        // measured crossover of the two fused kernels (tools/window_sweep.py, 128 streams x 4 s, G frames/s 8192 / 16384):
+        // mono always (4320 taps 76 / 172), stereo from ~2800 taps (84 / 110), 3 channels from ~1000 (4320 taps 50 / 80),
+        // 5 from ~2700 (34 / 43), 7 from ~4800, 4 and 6 from ~5400, 8 from ~5900.  Odd counts cross early: the
+        // 8192-frame kernels pad them to whole pairs, the polyphase view has 2C pseudo-channels — always whole pairs.
+        // Everything else (9+ channels: no vector variant) only when one 8192-frame window cannot hold the HRIR.
         const int c = n_in;
-        const int from = c == 2 ? 2800 : (c >= 3 && c <= 6) ? 5400 : (c == 7 || c == 8) ? 5900 : (1 << 30);
+        const int from = c == 1 ? 0 : c == 2 ? 2800 : c == 3 ? 1000 : c == 5 ? 2700 : c == 7 ? 4800 : (c == 4 || c == 6) ? 5400 : c == 8 ? 5900 : (1 << 30);
         window = hrir->taps >= from ? awk::kN2 : AW_DEFAULT_WINDOW;
         // small batches cannot fill 256 CUs with 16384-frame tiles (a 10 s stereo stream is 40 of them): the 8192-frame
         // kernels give three times the tiles.  Measured (stereo, 4320 taps, 10 s): 1 stream 7.9 -> 14.1, 4 streams

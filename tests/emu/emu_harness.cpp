@@ -95,7 +95,7 @@ static int emu_fused_ols2(const float *in, float *out, const float *hist, const 
     if (hi > p.tiles_per_stream) hi = p.tiles_per_stream;
     if (hi < lo) hi = lo;
     if (lo > p.tiles_per_stream) { lo = p.tiles_per_stream; hi = lo; }
-    const bool vec = n_channels == 1 || n_channels == 2 || n_channels == 7 || n_channels == 8;
+    const bool vec = n_channels == 1 || n_channels == 2 || n_channels == 3 || n_channels == 5 || n_channels == 7 || n_channels == 8;
     if (!vec) { lo = 0; hi = 0; }
     p.tile_lo = (int)lo; p.tile_hi = (int)hi;
     EmuShared sh;
@@ -111,6 +111,8 @@ static int emu_fused_ols2(const float *in, float *out, const float *hist, const 
                         switch (n_channels) {
                             case 1: tiles_fused_ols2<EmuCtx, 1, 1, true>(ctx, p, g, G, n_tiles); break;
                             case 2: tiles_fused_ols2<EmuCtx, 2, 1, true>(ctx, p, g, G, n_tiles); break;
+                            case 3: tiles_fused_ols2<EmuCtx, 3, 2, true>(ctx, p, g, G, n_tiles); break;
+                            case 5: tiles_fused_ols2<EmuCtx, 5, 3, true>(ctx, p, g, G, n_tiles); break;
                             case 7: tiles_fused_ols2<EmuCtx, 7, 4, true>(ctx, p, g, G, n_tiles); break;
                             default: tiles_fused_ols2<EmuCtx, 8, 4, true>(ctx, p, g, G, n_tiles); break;
                         }

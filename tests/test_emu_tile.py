@@ -75,7 +75,7 @@ def test_emulated_partitioned_interior_windows(oracle, channels):
     assert oracle.peak_rel_error(y[0], oracle.spatialize_f64(x[0], h, lt, rt)) < TOL
 
 
-@pytest.mark.parametrize("channels,taps,frames", [(1, 700, 21000), (2, 300, 5000), (2, 4320, 40001), (8, 4320, 30011), (7, 4319, 29000), (5, 1001, 20000)])
+@pytest.mark.parametrize("channels,taps,frames", [(1, 700, 21000), (2, 300, 5000), (2, 4320, 40001), (8, 4320, 30011), (7, 4319, 29000), (5, 1001, 20000), (5, 4320, 30001), (3, 6001, 29001), (4, 777, 17000)])
 def test_emulated_16384_window_path(oracle, channels, taps, frames):
     """tile_ols2.hpp: the polyphase (half-rate, 2C pseudo-channels, two output spectra) form of a 16384-frame window,
     interior and boundary kernels, odd tap and frame counts."""

@@ -123,7 +123,9 @@ def test_hrir_lengths_on_the_fused_path(aw, oracle, taps):
 
 
 @pytest.mark.parametrize("channels,taps,streams,fft", [(2, 4320, 1, 8192), (2, 4320, 15, 8192), (2, 4320, 16, 16384), (2, 2799, 64, 8192),
-                                                       (8, 4320, 128, 8192), (8, 5900, 16, 16384), (8, 5900, 4, 8192), (2, 6146, 1, 16384)])
+                                                       (8, 4320, 128, 8192), (8, 5900, 16, 16384), (8, 5900, 4, 8192), (2, 6146, 1, 16384),
+                                                       (1, 512, 16, 16384), (3, 900, 128, 8192), (3, 4320, 128, 16384), (5, 4320, 32, 16384),
+                                                       (7, 4320, 128, 8192), (7, 5000, 16, 16384), (12, 6000, 16, 8192)])
 def test_window_policy(aw, oracle, channels, taps, streams, fft):
     """runtime.cpp: the measured crossover of the two fused kernels by layout and HRIR length, 8192-frame windows for
     batches too small to fill the chip with 16384-frame tiles, 16384 whenever one 8192-frame window cannot hold the HRIR."""
