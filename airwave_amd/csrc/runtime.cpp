@@ -240,6 +240,13 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
     if (const char *e = getenv("AW_WINDOW")) window = atoi(e);
     const int hist2 = awh::poly_history_frames(hrir->taps);          // 16384-frame windows (tile_ols2.hpp)
     const bool fits1 = hrir->taps - 1 <= N - 2048, fits2 = hist2 <= awk::kN2 - 4096;
+    // ... and of the 16384-frame windows against the partitioned path at the long end (tools/path_sweep.py: the hop shrinks to
+    // 4096 frames at 12 289 taps): 1, 2, 3 and 5 channels stay fused to the window's limit (mono 12 289 taps: 64 / 34 G frames/s),
+    // 4 channels up to ~9000 taps, 6 and 8 up to ~10 000, 7 up to ~11 800; layouts without a vector variant of the 16384-frame
+    // kernels (9+ channels) take the partitioned path as soon as one 8192-frame window cannot hold the HRIR (12 ch, 8640 taps:
+    // 3.0 on the generic kernel against 10.2 G frames/s).
+    const int upto = (n_in <= 3 || n_in == 5) ? 12289 : n_in == 4 ? 9000 : (n_in == 6 || n_in == 8) ? 10000 : n_in == 7 ? 11800 : 0;
+    const bool fused2_ok = fits2 && hrir->taps <= upto;
     if (window == 0) {
         // measured crossover of the two fused kernels (tools/window_sweep.py, 128 streams x 4 s, G frames/s 8192 / 16384):
         // mono always (4320 taps 76 / 172), stereo from ~2800 taps (84 / 110), 3 channels from ~1000 (4320 taps 50 / 80),
@@ -248,19 +255,20 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
         // Everything else (9+ channels: no vector variant) only when one 8192-frame window cannot hold the HRIR.
         const int c = n_in;
         const int from = c == 1 ? 0 : c == 2 ? 2800 : c == 3 ? 1000 : c == 5 ? 2700 : c == 7 ? 4800 : (c == 4 || c == 6) ? 5400 : c == 8 ? 5900 : (1 << 30);
-        window = hrir->taps >= from ? awk::kN2 : AW_DEFAULT_WINDOW;
+        window = (hrir->taps >= from && fused2_ok) ? awk::kN2 : AW_DEFAULT_WINDOW;
         // small batches cannot fill 256 CUs with 16384-frame tiles (a 10 s stereo stream is 40 of them): the 8192-frame
         // kernels give three times the tiles.  Measured (stereo, 4320 taps, 10 s): 1 stream 7.9 -> 14.1, 4 streams
         // 28.9 -> 41.4 G frames/s, 16 streams equal, 64 streams 16384 ahead (80 -> 97)
         if (window == awk::kN2 && n_streams < 16 && fits1) window = awk::kN;
     }
-    if ((window == awk::kN2 && fits2) || (!fits1 && fits2)) {
+    const bool force_partitioned = window == 4096;                   // AW_WINDOW=4096: the partitioned path (A/B only)
+    if (!force_partitioned && ((window == awk::kN2 && fits2) || (!fits1 && fused2_ok))) {
         sp->path = 0; sp->fused2 = true;
         sp->hop = align_hop(awk::kN2 - hist2);
         sp->hist_len = awk::kN2 - sp->hop;                           // even, >= 2 * floor(taps / 2)
         sp->partitions = 1;
         sp->n_pairs = (2 * n_in + 1) / 2;                            // pseudo-pairs of the half-rate 2C-channel view
-    } else if (fits1) {
+    } else if (fits1 && !force_partitioned) {
         sp->path = 0;
         if (const char *e = getenv("AW_KERNEL_H")) sp->fusedh = atoi(e) == 2 ? 2 : 0;     // experimental sibling-workgroup kernels (tile_olsh.hpp)
         if (sp->fusedh) {           // ... only where the dispatcher is measured to co-locate siblings (their flag protocol needs one L2)

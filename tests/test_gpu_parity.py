@@ -271,12 +271,13 @@ def test_long_tap_partitioned_path(aw, oracle, golden_dir):
     assert oracle.peak_rel_error(sp.process(x)[0], g["expected"]) < TOL
 
 
-@pytest.mark.parametrize("taps,channels,path,fft", [(6146, 2, 0, 16384), (8640, 8, 0, 16384), (12288, 7, 0, 16384),
-                                                    (12290, 5, 1, 8192), (20000, 3, 1, 8192), (40000, 2, 1, 8192),
-                                                    (70000, 7, 1, 8192)])
+@pytest.mark.parametrize("taps,channels,path,fft", [(6146, 2, 0, 16384), (8640, 8, 0, 16384), (11800, 7, 0, 16384), (12288, 5, 0, 16384),
+                                                    (12288, 7, 1, 8192), (9001, 4, 1, 8192), (12290, 5, 1, 8192), (20000, 3, 1, 8192),
+                                                    (40000, 2, 1, 8192), (70000, 7, 1, 8192)])
 def test_long_hrir_paths_chunks_and_state(aw, oracle, taps, channels, path, fft, monkeypatch):
     """HRIRs beyond one 8192-frame window: up to 12288 taps (cfg 4: 4320 taps resampled x2 = 8640) run fused on
-    16384-frame windows, longer ones on the partitioned path (with stream chunking of its scratch)."""
+    16384-frame windows where that measures faster (runtime.cpp: per channel count), longer ones — and the long end
+    of the wider layouts — on the partitioned path (with stream chunking of its scratch)."""
     monkeypatch.setenv("AW_SPEC_SCRATCH_MB", "3")          # forces several stream chunks
     h = oracle.synth_hrir(14, taps, seed=taps)
     lt = np.array([0, 8, 6, 6, 4, 12, 2, 10][:channels], dtype=np.int32)
