@@ -58,6 +58,10 @@ constexpr bool kPrefetchRawEarly = AW_PREFETCH_RAW_EARLY != 0;
 #endif
 constexpr bool kTabEarly0 = (AW_TAB_EARLY & 1) != 0;   // first pair of a batch: table loads issued before the barrier
 constexpr bool kTabEarly1 = (AW_TAB_EARLY & 2) != 0;   // second pair: issued right after the first pair's CMAC   // issue the next batch's frame loads before pair 1's sub-FFTs
+#ifndef AW_SKIP_PHANTOM
+#define AW_SKIP_PHANTOM 1
+#endif
+constexpr bool kSkipPhantom = AW_SKIP_PHANTOM != 0;   // run-time batch loop: an odd pair count's last batch transforms one pair, not a phantom second one
 constexpr int kBatchCh = 4;       // input channels held in registers at once (two pairs)
 
 struct alignas(16) cf2 {          // one table entry: A[k], B[k]
@@ -467,7 +471,11 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
 #pragma unroll
         for (int b = 0; b < (NP + 1) / 2; ++b) batch(2 * b, 2 * b + 1 < NP, 2 * b + 2 < NP);
     } else {
-        for (int pair0 = 0; pair0 < n_pairs; pair0 += 2) batch(pair0, true, pair0 + 2 < n_pairs);
+        // an odd pair count's last batch transforms one pair, not a phantom second one (9, 10, 13, 14 channels: +5-10 %);
+        // layouts known at compile time to have an even pair count keep the branch-free body
+        constexpr bool kEvenPairs = CS > 0 && ((CS + 1) / 2) % 2 == 0;
+        for (int pair0 = 0; pair0 < n_pairs; pair0 += 2)
+            batch(pair0, (kSkipPhantom && !kEvenPairs) ? pair0 + 1 < n_pairs : true, pair0 + 2 < n_pairs);
     }
 
     tile_inverse_rows(ctx, wacc, buf0, twa, twb);
