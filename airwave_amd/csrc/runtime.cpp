@@ -256,10 +256,11 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
         const int c = n_in;
         const int from = c == 1 ? 0 : c == 2 ? 2800 : c == 3 ? 1000 : c == 5 ? 2700 : c == 7 ? 4800 : (c == 4 || c == 6) ? 5400 : c == 8 ? 5900 : (1 << 30);
         window = (hrir->taps >= from && fused2_ok) ? awk::kN2 : AW_DEFAULT_WINDOW;
-        // small batches cannot fill 256 CUs with 16384-frame tiles (a 10 s stereo stream is 40 of them): the 8192-frame
-        // kernels give three times the tiles.  Measured (stereo, 4320 taps, 10 s): 1 stream 7.9 -> 14.1, 4 streams
-        // 28.9 -> 41.4 G frames/s, 16 streams equal, 64 streams 16384 ahead (80 -> 97)
-        if (window == awk::kN2 && n_streams < 16 && fits1) window = awk::kN;
+        // small batches cannot fill 256 CUs with 16384-frame tiles (a 10 s stream is 40 of them): the 8192-frame kernels
+        // give three times the tiles.  Measured crossover in streams (tools/small_batch_sweep.py, 4320 taps, 10 s per
+        // stream): mono 8 (1 stream 13 -> 25 G frames/s on 8192), stereo 20, 3 channels 16, 5 channels 24; 16 elsewhere
+        const int min_streams = c == 1 ? 8 : c == 2 ? 20 : c == 5 ? 24 : 16;
+        if (window == awk::kN2 && n_streams < min_streams && fits1) window = awk::kN;
     }
     const bool force_partitioned = window == 4096;                   // AW_WINDOW=4096: the partitioned path (A/B only)
     if (!force_partitioned && ((window == awk::kN2 && fits2) || (!fits1 && fused2_ok))) {

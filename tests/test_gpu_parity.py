@@ -122,7 +122,7 @@ def test_hrir_lengths_on_the_fused_path(aw, oracle, taps):
     assert oracle.peak_rel_error(y[0], ref) < TOL
 
 
-@pytest.mark.parametrize("channels,taps,streams,fft", [(2, 4320, 1, 8192), (2, 4320, 15, 8192), (2, 4320, 16, 16384), (2, 2799, 64, 8192),
+@pytest.mark.parametrize("channels,taps,streams,fft", [(2, 4320, 1, 8192), (2, 4320, 19, 8192), (2, 4320, 20, 16384), (2, 2799, 64, 8192), (1, 4320, 7, 8192), (1, 4320, 8, 16384),
                                                        (8, 4320, 128, 8192), (8, 5900, 16, 16384), (8, 5900, 4, 8192), (2, 6146, 1, 16384),
                                                        (1, 512, 16, 16384), (3, 900, 128, 8192), (3, 4320, 128, 16384), (5, 4320, 32, 16384),
                                                        (7, 4320, 128, 8192), (7, 5000, 16, 16384), (12, 6000, 16, 8192)])
