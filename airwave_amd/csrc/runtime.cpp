@@ -262,7 +262,10 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
         const int min_streams = c == 1 ? 8 : c == 2 ? 20 : c == 5 ? 24 : 16;
         if (window == awk::kN2 && n_streams < min_streams && fits1) window = awk::kN;
     }
-    const bool force_partitioned = window == 4096;                   // AW_WINDOW=4096: the partitioned path (A/B only)
+    // 9+ channels near the end of the 8192-frame window's range (hop down to 2048 frames): the partitioned path is faster from
+    // ~5300 taps (9-11 channels) / ~5800 (12-16) — 9 channels, 6145 taps: 8.7 -> 11.8 G frames/s (tools/path_sweep.py)
+    const bool prefer_partitioned = getenv("AW_WINDOW") == nullptr && n_in >= 9 && hrir->taps >= (n_in <= 11 ? 5300 : 5800);
+    const bool force_partitioned = window == 4096 || prefer_partitioned;       // AW_WINDOW=4096: the partitioned path (A/B)
     if (!force_partitioned && ((window == awk::kN2 && fits2) || (!fits1 && fused2_ok))) {
         sp->path = 0; sp->fused2 = true;
         sp->hop = align_hop(awk::kN2 - hist2);

@@ -125,7 +125,7 @@ def test_hrir_lengths_on_the_fused_path(aw, oracle, taps):
 @pytest.mark.parametrize("channels,taps,streams,fft", [(2, 4320, 1, 8192), (2, 4320, 19, 8192), (2, 4320, 20, 16384), (2, 2799, 64, 8192), (1, 4320, 7, 8192), (1, 4320, 8, 16384),
                                                        (8, 4320, 128, 8192), (8, 5900, 16, 16384), (8, 5900, 4, 8192), (2, 6146, 1, 16384),
                                                        (1, 512, 16, 16384), (3, 900, 128, 8192), (3, 4320, 128, 16384), (5, 4320, 32, 16384),
-                                                       (7, 4320, 128, 8192), (7, 5000, 16, 16384), (12, 6000, 16, 8192)])
+                                                       (7, 4320, 128, 8192), (7, 5000, 16, 16384), (12, 5700, 16, 8192)])
 def test_window_policy(aw, oracle, channels, taps, streams, fft):
     """runtime.cpp: the measured crossover of the two fused kernels by layout and HRIR length, 8192-frame windows for
     batches too small to fill the chip with 16384-frame tiles, 16384 whenever one 8192-frame window cannot hold the HRIR."""
@@ -272,7 +272,7 @@ def test_long_tap_partitioned_path(aw, oracle, golden_dir):
 
 
 @pytest.mark.parametrize("taps,channels,path,fft", [(6146, 2, 0, 16384), (8640, 8, 0, 16384), (11800, 7, 0, 16384), (12288, 5, 0, 16384),
-                                                    (12288, 7, 1, 8192), (9001, 4, 1, 8192), (12290, 5, 1, 8192), (20000, 3, 1, 8192),
+                                                    (12288, 7, 1, 8192), (9001, 4, 1, 8192), (12290, 5, 1, 8192), (5800, 12, 1, 8192), (5300, 9, 1, 8192), (20000, 3, 1, 8192),
                                                     (40000, 2, 1, 8192), (70000, 7, 1, 8192)])
 def test_long_hrir_paths_chunks_and_state(aw, oracle, taps, channels, path, fft, monkeypatch):
     """HRIRs beyond one 8192-frame window: up to 12288 taps (cfg 4: 4320 taps resampled x2 = 8640) run fused on
@@ -280,8 +280,8 @@ def test_long_hrir_paths_chunks_and_state(aw, oracle, taps, channels, path, fft,
     of the wider layouts — on the partitioned path (with stream chunking of its scratch)."""
     monkeypatch.setenv("AW_SPEC_SCRATCH_MB", "3")          # forces several stream chunks
     h = oracle.synth_hrir(14, taps, seed=taps)
-    lt = np.array([0, 8, 6, 6, 4, 12, 2, 10][:channels], dtype=np.int32)
-    rt = np.array([1, 7, 13, 13, 5, 11, 3, 9][:channels], dtype=np.int32)
+    lt = np.resize(np.array([0, 8, 6, 6, 4, 12, 2, 10], dtype=np.int32), channels)
+    rt = np.resize(np.array([1, 7, 13, 13, 5, 11, 3, 9], dtype=np.int32), channels)
     S, F = 3, 30000
     x = oracle.synth_input(S, F, channels, seed=21)
     sp = aw.Spatializer(aw.HRIR(h), lt, rt, n_streams=S)

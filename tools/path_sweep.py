@@ -16,7 +16,7 @@ for C in (int(a) for a in (sys.argv[1:] or ["9", "12", "14", "16"])):
     for taps in [int(a) for a in os.environ.get("TAPS", "6146,8640,12289").split(",")]:
         h = (rng.standard_normal((14, taps)) * np.exp(-np.arange(taps) / (taps / 6.0))).astype(np.float32)
         row = []
-        for win in ("16384", "4096"):
+        for win in os.environ.get("WINS", "16384,4096").split(","):
             os.environ["AW_WINDOW"] = win
             sp = aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=S, ctx=ctx)
             for _ in range(2):
@@ -28,5 +28,5 @@ for C in (int(a) for a in (sys.argv[1:] or ["9", "12", "14", "16"])):
             torch.cuda.synchronize()
             row.append(S * F * 4 / (time.perf_counter() - t0) / 1e9)
             del sp
-        print(f"C={C:2d} taps {taps:5d}: 16384-window {row[0]:6.2f}  partitioned {row[1]:6.2f} Gframes/s  -> {'16384' if row[0] > row[1] else 'partitioned'}", flush=True)
+        print(f"C={C:2d} taps {taps:5d}: first {row[0]:6.2f}  second {row[1]:6.2f} Gframes/s (WINS order)  -> {'first' if row[0] > row[1] else 'second'}", flush=True)
     del x, y
