@@ -1,5 +1,6 @@
-"""Long HRIRs (one 8192-frame window cannot hold them): 16384-frame windows against the partitioned path (AW_WINDOW=4096),
-frames/s by channel count and HRIR length.  Run on the GPU box."""
+"""Path choice by channel count and HRIR length: two AW_WINDOW settings side by side (default WINS=16384,4096: the 16384-frame
+window kernels against the partitioned path, which AW_WINDOW=4096 forces; WINS=8192,4096 for the end of the 8192-frame
+window's range).  TAPS=a,b,c overrides the HRIR lengths.  Run on the GPU box."""
 import os, sys, time
 import numpy as np
 import torch
