@@ -235,12 +235,12 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
     sp->ctx = ctx; sp->n_channels = n_in; sp->n_pairs = (n_in + 1) / 2; sp->n_streams = n_streams;
     sp->taps = hrir->taps;
     const int N = awk::kN;
-    // Path choice.  AW_WINDOW=8192|16384 forces the fused window (tuning / A-B); default: see below.
+    // Path choice.  AW_WINDOW=8192|16384 forces the fused window, 4096 the partitioned path (tuning / A-B); default: see below.
     int window = 0;
     if (const char *e = getenv("AW_WINDOW")) window = atoi(e);
     const int hist2 = awh::poly_history_frames(hrir->taps);          // 16384-frame windows (tile_ols2.hpp)
     const bool fits1 = hrir->taps - 1 <= N - 2048, fits2 = hist2 <= awk::kN2 - 4096;
-    // ... and of the 16384-frame windows against the partitioned path at the long end (tools/path_sweep.py: the hop shrinks to
+    // Long end of the 16384-frame windows against the partitioned path (tools/path_sweep.py: the hop shrinks to
     // 4096 frames at 12 289 taps): 1, 2, 3 and 5 channels stay fused to the window's limit (mono 12 289 taps: 64 / 34 G frames/s),
     // 4 channels up to ~9000 taps, 6 and 8 up to ~10 000, 7 up to ~11 800; layouts without a vector variant of the 16384-frame
     // kernels (9+ channels) take the partitioned path as soon as one 8192-frame window cannot hold the HRIR (12 ch, 8640 taps:
