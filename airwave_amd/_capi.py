@@ -41,12 +41,14 @@ SIGNATURES = {
     "aw_spatializer_process": (_I32, [_V, _V, _V, _I64]),
     "aw_spatializer_process_host": (_I32, [_V, c_float_p, c_float_p, _I64]),
     "aw_spatializer_process_planar": (_I32, [_V, c_float_p, c_float_p, c_float_p, c_float_p, _I32]),
+    "aw_spatializer_reserve": (_I32, [_V, _I64]),
     "aw_spatializer_reset": (_I32, [_V]),
     "aw_spatializer_stream_count": (_I32, [_V]),
     "aw_spatializer_channel_count": (_I32, [_V]),
     "aw_spatializer_info": (_I64, [_V, _I32]),
     "aw_spatializer_set_profiling": (_I32, [_V, _I32]),
     "aw_spatializer_kernel_time": (_I32, [_V, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_char_p)]),
+    "aw_spatializer_stage_time": (_I32, [_V, _I32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),
     "aw_spatializer_debug_stamps": (_I32, [_V, ctypes.POINTER(ctypes.c_uint64), _I64, ctypes.POINTER(ctypes.c_int64)]),
     "aw_engine_create": (_I32, [_V, c_float_p, _I32, _I32, c_void_pp]),
     "aw_engine_destroy": (None, [_V]),

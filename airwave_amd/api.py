@@ -342,6 +342,10 @@ class Spatializer:
         _check(self._lib.aw_spatializer_process_planar(self._h, _fp(l), None if r is None else _fp(r), _fp(ol), _fp(orr), l.size))
         return ol, orr
 
+    def reserve(self, max_frames: int) -> None:
+        """Size every internal device buffer for calls of up to max_frames frames: process never allocates afterwards."""
+        _check(self._lib.aw_spatializer_reserve(self._h, int(max_frames)))
+
     def reset(self) -> None:
         _check(self._lib.aw_spatializer_reset(self._h))
 
@@ -353,6 +357,17 @@ class Spatializer:
         name = ctypes.c_char_p()
         n = self._lib.aw_spatializer_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(name))
         return n, float(ms.value), (name.value or b"").decode()
+
+    def stage_times(self) -> List[Tuple[str, float, int]]:
+        """(kernel name, total ms, launches) of every separately timed launch since profiling was switched on."""
+        out = []
+        i = 0
+        while True:
+            name, ms, n = ctypes.c_char_p(), ctypes.c_double(), ctypes.c_int32()
+            if not self._lib.aw_spatializer_stage_time(self._h, i, ctypes.byref(name), ctypes.byref(ms), ctypes.byref(n)):
+                return out
+            out.append(((name.value or b"").decode(), float(ms.value), int(n.value)))
+            i += 1
 
 
 class ConvolutionEngine:

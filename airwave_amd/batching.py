@@ -43,7 +43,9 @@ class MixedRateBatch:
                  hrirMap: Optional[HRIRChannelMap] = None, ctx: Optional[Context] = None):
         self.ctx = ctx or default_context()
         tracks = np.ascontiguousarray(tracks, dtype=np.float32)
-        cmap = hrirMap or (HRIRChannelMap.hesuvi14Channel(layout) if tracks.shape[0] >= 14 else HRIRChannelMap.hesuvi7Channel(layout))
+        # the reference's chooser: 7-track files take the 7-channel map, everything else the 14-channel one
+        # (HRIRManager.swift:355-360; aw_preset_activate does the same) — an 8..13-track HRIR then fails the bounds check
+        cmap = hrirMap or (HRIRChannelMap.hesuvi7Channel(layout) if tracks.shape[0] == 7 else HRIRChannelMap.hesuvi14Channel(layout))
         lt, rt = cmap.resolve(layout, tracks.shape[0])
         self.left_track, self.right_track = lt, rt
         self.buckets: Dict[float, RateBucket] = {}

@@ -19,6 +19,7 @@ ARCH = "gfx950"
 
 SOURCES = [
     "device/kernels.hip",
+    "device/march_kernels.hip",
     "device/eq_kernels.hip",
     "runtime.cpp",
     "eq_runtime.cpp",
@@ -26,6 +27,8 @@ SOURCES = [
     "host/tables.cpp",
     "host/host_api.cpp",
 ]
+# per-source flags (see the header comment of the source)
+EXTRA_FLAGS = {"device/march_kernels.hip": [] if os.environ.get("AW_MARCH_SLP") else ["-fno-slp-vectorize"]}
 HEADERS = sorted(os.path.relpath(os.path.join(d, f), CSRC) for d, _, fs in os.walk(CSRC) for f in fs if f.endswith((".hpp", ".h"))) + [
     "../../include/airwave_hip.h",
 ]
@@ -45,7 +48,7 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, stamps: bool = False, defines=(), suffix: str = "") -> str:
+def build(force: bool = False, verbose: bool = False, stamps: bool = False, defines=(), suffix: str = "", only=()) -> str:
     """stamps=True builds the DIAGNOSTIC variant (phase time stamps, -DAW_STAMPS=1) as
     libairwave_hip_stamps.so; `defines` + `suffix` build tuning variants (libairwave_hip_<suffix>.so)
     for A/B runs.  Variants are never loaded unless AIRWAVE_HIP_LIBRARY points at them."""
@@ -54,10 +57,17 @@ def build(force: bool = False, verbose: bool = False, stamps: bool = False, defi
     if stamps:
         suffix = suffix or "stamps"
         defines.append("AW_STAMPS=1")
+    main_obj = OBJ
     if suffix:
         OUT = os.path.join(HERE, f"libairwave_hip_{suffix}.so")
         OBJ = os.path.join(HERE, f"_build_{suffix}")
     os.makedirs(OBJ, exist_ok=True)
+    if suffix and only:          # a variant whose defines touch only some sources: the other objects are the main build's
+        import shutil
+        for src in SOURCES:
+            o = src.replace("/", "_") + ".o"
+            if src not in only and os.path.exists(os.path.join(main_obj, o)):
+                shutil.copy2(os.path.join(main_obj, o), os.path.join(OBJ, o))
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     common = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"--offload-arch={ARCH}",
               "-Wall", "-Wno-unused-result", "-ffp-contract=fast"] + [f"-D{d}" for d in defines] + os.environ.get("AW_EXTRA_HIPCC_FLAGS", "").split()
@@ -66,8 +76,8 @@ def build(force: bool = False, verbose: bool = False, stamps: bool = False, defi
         spath = os.path.join(CSRC, src)
         opath = os.path.join(OBJ, src.replace("/", "_") + ".o")
         objs.append(opath)
-        if force or _stale(opath, [spath] + hdrs):
-            cmd = [hipcc()] + common + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", spath, "-o", opath]
+        if (force and (not only or src in only)) or (src in only) or _stale(opath, [spath] + hdrs):
+            cmd = [hipcc()] + common + EXTRA_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", spath, "-o", opath]
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
@@ -82,4 +92,5 @@ def build(force: bool = False, verbose: bool = False, stamps: bool = False, defi
 if __name__ == "__main__":
     defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
     sfx = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--suffix=")), "")
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, stamps="--stamps" in sys.argv, defines=defs, suffix=sfx))
+    only = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, stamps="--stamps" in sys.argv, defines=defs, suffix=sfx, only=only))

@@ -60,18 +60,41 @@ __global__ void __launch_bounds__(kThreads, 4) aw_fused_olsq_kernel(TileParams p
 
 // Windows [tile_lo, tile_hi) of every stream lie inside the call's input (INTERIOR), the others touch the
 // history or the zero page.  p.tile_lo/hi carry the window range here.
-template <int CS, bool INTERIOR>
-__global__ void __launch_bounds__(kThreads) aw_part_forward_kernel(TileParams p, long long nwg) {
+// MODE 1: windows [tile_lo, tile_hi) (interior); MODE 2: windows [head_lo, tile_lo) (head: history + input);
+// MODE 0: the rest, [0, head_lo) and [tile_hi, n_windows).  Persistent, XCD-aware like the fused kernels: each XCD group
+// walks a contiguous eighth of the window list, so windows that overlap by half meet in one L2.
+template <int CS, int MODE>
+__global__ void __launch_bounds__(kThreads) aw_part_forward_kernel(TileParams p, long long n_ids, int head_lo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
+    const int n_windows = p.n_blocks + p.partitions - 1;
+    const int per = MODE == 1 ? p.tile_hi - p.tile_lo : MODE == 2 ? p.tile_lo - head_lo : n_windows - (p.tile_hi - head_lo);
+    const int w0 = MODE == 1 ? p.tile_lo : head_lo, skip = p.tile_hi - head_lo;
+    const long long g = gridDim.x, b = blockIdx.x;
+    const long long xcd = b % 8, slot = b / 8;
+    const long long per_xcd_wg = (g - xcd + 7) / 8;
+    const long long q = n_ids / 8, r = n_ids % 8;
+    const long long lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const long long hi = lo + (xcd < r ? q + 1 : q);
+    tiles_part_forward<GpuCtx, CS, MODE>(ctx, p, lo + slot, per_xcd_wg, hi, per, w0, skip);
+}
+
+// One-pair form: workgroup id -> (stream, window, pair), pairs innermost; kInvLdsBytes of LDS, two workgroups per CU.
+template <int CS, int MODE>
+__global__ void __launch_bounds__(kThreads, 4) aw_part_forward1_kernel(TileParams p, long long nwg, int head_lo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
     const long long id = xcd_remap((long long)blockIdx.x, nwg);
+    const long long wid = id / p.n_pairs;
+    const int pair = (int)(id - wid * p.n_pairs);
     const int n_windows = p.n_blocks + p.partitions - 1;
-    const int per = INTERIOR ? p.tile_hi - p.tile_lo : n_windows - (p.tile_hi - p.tile_lo);
-    const long long stream = id / per;
-    int w = (int)(id - stream * per);
-    if (INTERIOR) w += p.tile_lo;
-    else if (w >= p.tile_lo) w += p.tile_hi - p.tile_lo;
-    tile_part_forward<GpuCtx, CS, INTERIOR>(ctx, p, stream, w);
+    const int per = MODE == 1 ? p.tile_hi - p.tile_lo : MODE == 2 ? p.tile_lo - head_lo : n_windows - (p.tile_hi - head_lo);
+    const long long stream = wid / per;
+    int w = (int)(wid - stream * per);
+    if (MODE == 1) w += p.tile_lo;
+    else if (MODE == 2) w += head_lo;
+    else if (w >= head_lo) w += p.tile_hi - head_lo;
+    tile_part_forward1<GpuCtx, CS, MODE>(ctx, p, stream, w, pair);
 }
 
 // grid = (N / kCmacThreads, block groups, streams): one thread per bin of kCmacBlocks consecutive blocks
@@ -136,6 +159,9 @@ hipError_t prepare_kernels() {
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             g_persistent_wgs = cus;
         if (const char *e2 = getenv("AW_PERSISTENT_WGS")) g_persistent_wgs = atoi(e2) > 0 ? atoi(e2) : g_persistent_wgs;
+        // the persistent kernels deal tiles to 8 XCD groups (blockIdx % 8): a grid below 8 workgroups with more tiles than
+        // workgroups would leave groups without a workgroup and their tiles uncomputed
+        if (g_persistent_wgs < 8) g_persistent_wgs = 8;
     }
 #define AW_SET_VEC(CS, NP)                                                                           \
     if (e == hipSuccess)                                                                             \
@@ -190,12 +216,27 @@ hipError_t prepare_kernels() {
 #undef AW_SET_GEN
 #define AW_SET_FWD(CS, NP)                                                                              \
     if (e == hipSuccess)                                                                                \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_forward_kernel<CS, true>),      \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_forward_kernel<CS, 1>),         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);                 \
+    if (e == hipSuccess)                                                                                \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_forward_kernel<CS, 2>),         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     AW_FOR_EACH_VEC(AW_SET_FWD)
 #undef AW_SET_FWD
+#define AW_SET_FWD1(CS, NP)                                                                             \
+    if (e == hipSuccess)                                                                                \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_forward1_kernel<CS, 1>),        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kInvLdsBytes);              \
+    if (e == hipSuccess)                                                                                \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_forward1_kernel<CS, 2>),        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kInvLdsBytes);
+    AW_FOR_EACH_VEC(AW_SET_FWD1)
+#undef AW_SET_FWD1
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_forward_kernel<0, false>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_forward1_kernel<0, 0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kInvLdsBytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_forward_kernel<0, 0>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_part_inverse_kernel),
@@ -445,49 +486,103 @@ hipError_t launch_fused_ols2(const TileParams &p_in, int n_streams, hipStream_t 
     return hipGetLastError();
 }
 
-hipError_t launch_part_forward(const TileParams &p_in, int n_streams, hipStream_t stream) {
+hipError_t launch_part_forward(const TileParams &p_in, int n_streams, hipStream_t stream, StageTimer *tm) {
     TileParams p = p_in;
     const int n_windows = p.n_blocks + p.partitions - 1;
     if ((long long)n_streams * n_windows <= 0) return hipSuccess;
     // window w covers frames [(w - P) B, (w - P) B + N): interior iff it starts at >= 0 and ends inside the input
-    // (one frame of slack for layouts whose frames are not whole float4s, see load_batch)
+    // (one frame of slack for layouts whose frames are not whole float4s, see load_batch); head iff it starts in the
+    // history (which reaches back P B frames: every window does) and still ends inside the input
     const long long usable = p.frames - ((p.n_channels % 4 != 0 && p.n_channels != 2) ? 1 : 0);
     long long lo = p.partitions;
-    long long hi = usable >= kN ? (usable - kN) / p.hop + p.partitions + 1 : lo;
+    long long hi = usable >= kN ? (usable - kN) / p.hop + p.partitions + 1 : lo;      // windows [0, hi) end inside the input
+    long long head_lo = 0;
     if (hi > n_windows) hi = n_windows;
     if (lo > n_windows) lo = n_windows;
-    if (hi < lo) hi = lo;
-    if (!has_vec_variant(p.n_channels)) hi = lo;
+    if (hi < lo) { lo = hi; }                   // short call: even some head windows run past the end
+    if (hi < 0) hi = 0;
+    if (lo < 0) lo = 0;
+    if (!has_vec_variant(p.n_channels)) { lo = 0; hi = 0; }
     p.tile_lo = (int)lo; p.tile_hi = (int)hi;
-    const long long n_int = (long long)n_streams * (hi - lo), n_bnd = (long long)n_streams * (n_windows - (hi - lo));
-    if (n_int > 0x7fffffffLL || n_bnd > 0x7fffffffLL) return hipErrorInvalidValue;
+    const long long n_int = (long long)n_streams * (hi - lo), n_head = (long long)n_streams * (lo - head_lo);
+    const long long n_bnd = (long long)n_streams * (n_windows - (hi - head_lo));
+    if (n_int > 0x7fffffffLL || n_bnd > 0x7fffffffLL || n_head > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (p.fwd_one_pair) {             // one channel pair per workgroup, two workgroups per CU (the default)
+        const long long np = p.n_pairs;
+        if (n_int * np > 0x7fffffffLL || n_bnd * np > 0x7fffffffLL || n_head * np > 0x7fffffffLL) return hipErrorInvalidValue;
+        if (n_int > 0) {
+            if (tm) tm->begin();
+            switch (p.n_channels) {
+#define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_part_forward1_kernel<CS, 1>), dim3((unsigned)(n_int * np)), dim3(kThreads), kInvLdsBytes, stream, p, n_int * np, (int)head_lo); break;
+                AW_FOR_EACH_VEC(AW_CASE)
+#undef AW_CASE
+                default: break;
+            }
+            if (tm) tm->end("aw_part_forward1_kernel<CS, interior>");
+        }
+        if (n_head > 0) {
+            if (tm) tm->begin();
+            switch (p.n_channels) {
+#define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_part_forward1_kernel<CS, 2>), dim3((unsigned)(n_head * np)), dim3(kThreads), kInvLdsBytes, stream, p, n_head * np, (int)head_lo); break;
+                AW_FOR_EACH_VEC(AW_CASE)
+#undef AW_CASE
+                default: break;
+            }
+            if (tm) tm->end("aw_part_forward1_kernel<CS, head>");
+        }
+        if (n_bnd > 0) {
+            if (tm) tm->begin();
+            hipLaunchKernelGGL((aw_part_forward1_kernel<0, 0>), dim3((unsigned)(n_bnd * np)), dim3(kThreads), kInvLdsBytes, stream, p, n_bnd * np, (int)head_lo);
+            if (tm) tm->end("aw_part_forward1_kernel<generic>");
+        }
+        return hipGetLastError();
+    }
     if (n_int > 0) {
+        if (tm) tm->begin();
         switch (p.n_channels) {
-#define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_part_forward_kernel<CS, true>), dim3((unsigned)n_int), dim3(kThreads), kLdsBytes, stream, p, n_int); break;
+#define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_part_forward_kernel<CS, 1>), persistent_grid(n_int), dim3(kThreads), kLdsBytes, stream, p, n_int, (int)head_lo); break;
             AW_FOR_EACH_VEC(AW_CASE)
 #undef AW_CASE
             default: break;
         }
+        if (tm) tm->end("aw_part_forward_kernel<CS, interior>");
     }
-    if (n_bnd > 0)
-        hipLaunchKernelGGL((aw_part_forward_kernel<0, false>), dim3((unsigned)n_bnd), dim3(kThreads), kLdsBytes, stream, p, n_bnd);
+    if (n_head > 0) {
+        if (tm) tm->begin();
+        switch (p.n_channels) {
+#define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_part_forward_kernel<CS, 2>), persistent_grid(n_head), dim3(kThreads), kLdsBytes, stream, p, n_head, (int)head_lo); break;
+            AW_FOR_EACH_VEC(AW_CASE)
+#undef AW_CASE
+            default: break;
+        }
+        if (tm) tm->end("aw_part_forward_kernel<CS, head>");
+    }
+    if (n_bnd > 0) {
+        if (tm) tm->begin();
+        hipLaunchKernelGGL((aw_part_forward_kernel<0, 0>), persistent_grid(n_bnd), dim3(kThreads), kLdsBytes, stream, p, n_bnd, (int)head_lo);
+        if (tm) tm->end("aw_part_forward_kernel<generic>");
+    }
     return hipGetLastError();
 }
 
-hipError_t launch_part_cmac(const TileParams &p, int n_streams, hipStream_t stream) {
+hipError_t launch_part_cmac(const TileParams &p, int n_streams, hipStream_t stream, StageTimer *tm) {
     const int groups = (p.n_blocks + kCmacBlocks - 1) / kCmacBlocks;
     if (n_streams <= 0 || groups <= 0) return hipSuccess;
     if (groups > 65535 || n_streams > 65535) return hipErrorInvalidValue;
+    if (tm) tm->begin();
     hipLaunchKernelGGL(aw_part_cmac_kernel, dim3(kN / kCmacThreads, (unsigned)groups, (unsigned)n_streams), dim3(kCmacThreads), 0,
                        stream, p);
+    if (tm) tm->end("aw_part_cmac_kernel");
     return hipGetLastError();
 }
 
-hipError_t launch_part_inverse(const TileParams &p, int n_streams, hipStream_t stream) {
+hipError_t launch_part_inverse(const TileParams &p, int n_streams, hipStream_t stream, StageTimer *tm) {
     const long long nwg = (long long)n_streams * p.n_blocks;
     if (nwg <= 0) return hipSuccess;
     if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (tm) tm->begin();
     hipLaunchKernelGGL(aw_part_inverse_kernel, dim3((unsigned)nwg), dim3(kThreads), kInvLdsBytes, stream, p, nwg);
+    if (tm) tm->end("aw_part_inverse_kernel");
     return hipGetLastError();
 }
 

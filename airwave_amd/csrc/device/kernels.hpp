@@ -6,8 +6,16 @@
 
 #include "tile_ols2.hpp"
 #include "tile_olsh.hpp"
+#include "tile_march.hpp"
 
 namespace awk {
+
+// Optional per-launch timing (profiling runs only): begin() right before a kernel launch, end(name) right after it.
+struct StageTimer {
+    virtual void begin() = 0;
+    virtual void end(const char *name) = 0;
+    virtual ~StageTimer() = default;
+};
 
 // Fused overlap-save spatializer: one workgroup per (stream, tile).  Returns hipSuccess or the
 // launch error.  `n_streams * p.tiles_per_stream` workgroups of kThreads.
@@ -29,9 +37,10 @@ const char *fused_ols2_kernel_name(int n_channels);
 
 // Partitioned (long-HRIR) path: window spectra -> scratch; per-bin CMAC over partitions for groups of
 // consecutive blocks -> W scratch; inverse transform of every block's W.
-hipError_t launch_part_forward(const TileParams &p, int n_streams, hipStream_t stream);
-hipError_t launch_part_cmac(const TileParams &p, int n_streams, hipStream_t stream);
-hipError_t launch_part_inverse(const TileParams &p, int n_streams, hipStream_t stream);
+hipError_t launch_part_forward(const TileParams &p, int n_streams, hipStream_t stream, StageTimer *tm = nullptr);
+hipError_t launch_part_cmac(const TileParams &p, int n_streams, hipStream_t stream, StageTimer *tm = nullptr);      // block-group kernel (A/B: AW_PART_CMAC=group)
+hipError_t launch_part_march(const TileParams &p, int n_streams, hipStream_t stream, StageTimer *tm = nullptr);     // marched kernel (tile_march.hpp), the default
+hipError_t launch_part_inverse(const TileParams &p, int n_streams, hipStream_t stream, StageTimer *tm = nullptr);
 
 // hist_new[s][i][c] <- frame (frames - hist_len + i) of (hist_old ++ in), for every stream.
 hipError_t launch_hist_update(const float *in, const float *hist_old, float *hist_new, long long frames,

@@ -90,6 +90,8 @@ struct TileParams {
     int partitions;         // P = ceil(taps / hop); tables are [partition][pair][N]
     int n_blocks;           // output blocks of `hop` frames per stream in this call
     int first_valid;        // first window position that is stored (N - hop)
+    int fwd_one_pair;       // forward kernel form: 1 = one channel pair per workgroup (two workgroups per CU), 0 = all pairs in one workgroup
+    int herm_last;          // odd channel count: the last pair's input is real, its spectrum Hermitian — rows 9..15 are neither stored nor read
     int stagger;            // tuning: waves 4-7 idle this many 64-cycle slots after each barrier (phase offset)
     unsigned long long *dbg; // diagnostic builds only (AW_STAMPS): [workgroup][16] s_memtime stamps of wave 0
     // sibling-workgroup kernels (tile_olsh.hpp) only:
@@ -264,6 +266,31 @@ AW_HD void load_batch(const TileParams &p, const float *in_s, const float *hist_
     } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j) load_frame<CS>(p, in_s, hist_s, f0 + t + 512 * j, raw[j], c0);
+    }
+}
+
+// HEAD windows of the partitioned path (the first P windows of a call: part history, part input, nothing past the
+// end): per frame a pointer select between the history buffer and the input, then the same whole-frame vector load as
+// the interior windows.  Layouts whose frames are not whole float4s read up to 3 floats past a frame: the history
+// allocation carries that slack (runtime.cpp), the launch keeps one input frame of slack.
+template <int CS>
+AW_HD void load_batch_head(const TileParams &p, const float *in_s, const float *hist_s, long long f0, int t, int c0,
+                           float (&raw)[16][kBatchCh]) {
+    static_assert(CS > 0, "vector layouts only");
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const long long f = f0 + t + 512 * j;
+        const float *src = (f < 0 ? hist_s + ((long long)p.hist_len + f) * CS : in_s + f * CS) + c0;
+        if constexpr (CS % 4 == 0) {
+            const f4 v = *reinterpret_cast<const f4 *>(src);
+            raw[j][0] = v.x; raw[j][1] = v.y; raw[j][2] = v.z; raw[j][3] = v.w;
+        } else if constexpr (CS == 2) {
+            const f2 v = *reinterpret_cast<const f2 *>(src);
+            raw[j][0] = v.x; raw[j][1] = v.y; raw[j][2] = 0.f; raw[j][3] = 0.f;
+        } else {
+            const f4u v = *reinterpret_cast<const f4u *>(src);
+            raw[j][0] = v.x; raw[j][1] = v.y; raw[j][2] = v.z; raw[j][3] = v.w;
+        }
     }
 }
 
@@ -493,62 +520,200 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
 // ---- partitioned path (taps too long for one window: Y[b] = sum_q X[b-q] . H_q, the same
 // frequency-domain delay line as ConvolutionEngine.swift:256-350 with B = N/2 = 4096) -----------
 // Kernel 1: spectra of one input window for every pair -> global scratch.
-// INTERIOR: the window lies inside the call's input (whole-frame vector loads off a uniform base).
-template <class Ctx, int CS, bool INTERIOR>
-AW_HD void tile_part_forward(Ctx &ctx, const TileParams &p, long long stream, int widx) {
-    const int t = ctx.tid();
-    const int lane = ctx.lane(), wave = ctx.wave();
+// MODE 1 (interior): the window lies inside the call's input (whole-frame vector loads off a uniform base);
+// MODE 2 (head): history + input, nothing past the end (vector loads behind a per-frame pointer select);
+// MODE 0: anything (scalar loads; history, input or the zero page per frame).
+// Persistent form: the workgroup walks window ids first, first + step, ... < end of its launch; id -> (stream, window)
+// through `per` windows per stream starting at window `w0` (MODE 0: the windows outside [w0, w0 + skip) — see the launcher).
+// The next window's first frame batch is issued right after the current window's last pass 1, so its latency hides under
+// the last sub-FFTs, and the spectrum stores of one window drain while the next one computes (a workgroup that ends
+// after its stores cannot overlap them with anything: measured 11.2 ms with, 7.9 ms without the stores).
+struct PartWin { long long stream; int w; };
+template <int MODE>
+AW_HD PartWin part_window_of(long long id, int per, int w0, int skip) {
+    PartWin r;
+    const unsigned q = (unsigned)id / (unsigned)per;          // ids fit 31 bits (checked at launch)
+    r.stream = q;
+    int w = (int)((unsigned)id - q * (unsigned)per);
+    if (MODE == 0) { if (w >= w0) w += skip; }
+    else w += w0;
+    r.w = w;
+    return r;
+}
+
+template <class Ctx, int CS, int MODE>
+AW_HD void tiles_part_forward(Ctx &ctx, const TileParams &p, long long first, long long step, long long end, int per, int w0, int skip) {
+    auto load = [&](const float *in_s, const float *hist_s, long long f0, int t, int c0, float (&raw)[16][kBatchCh]) {
+        if constexpr (MODE == 2) load_batch_head<CS>(p, in_s, hist_s, f0, t, c0, raw);
+        else load_batch<CS, MODE == 1>(p, in_s, hist_s, f0, t, c0, raw);
+        // Odd channel counts: the whole-frame vector loads put the next frame's first sample into the padding lane of
+        // the last pair.  Zero tables cancel it, but the Hermitian shortcut (herm_last) needs that pair's input REAL.
+        if constexpr (MODE != 0 && CS > 0 && (CS & 1)) {
+            if (c0 + kBatchCh > CS) {                              // uniform: the last batch
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+#pragma unroll
+                    for (int c = 0; c < kBatchCh; ++c)
+                        if (c0 + c >= CS) raw[j][c] = 0.f;
+            }
+        }
+    };
+    if (first >= end) return;
+    const int t0 = ctx.tid();
+    int t = t0, lane = ctx.lane();
+    const int wave = ctx.wave();
     cf *buf0 = ctx.lds();
     cf *buf1 = buf0 + kBufElems;
     cf *twa = buf1 + kBufElems;
+    cf *twb = twa + kTwaElems;
+    const int Cn = CS > 0 ? CS : p.n_channels;
+    const int n_windows = p.n_blocks + p.partitions - 1;
+    const cf w1 = p.tw1[t];
+    twa[t] = p.twa[t];
+    if (t < kTwbElems) twb[t] = p.twb[t];
+
+    float raw[16][kBatchCh];
+    {
+        const PartWin pw0 = part_window_of<MODE>(first, per, w0, skip);
+        load(p.in + pw0.stream * p.frames * Cn, p.hist + pw0.stream * (long long)p.hist_len * Cn,
+             ((long long)pw0.w - p.partitions) * p.hop, t, 0, raw);
+    }
+    for (long long id = first; id < end; id += step) {
+        t = ctx.opaque_i(t0);                       // keeps lane-dependent addresses from living across the window loop
+        lane = t & 63;
+        const PartWin cur = part_window_of<MODE>(id, per, w0, skip);
+        const float *in_s = p.in + cur.stream * p.frames * Cn;
+        const float *hist_s = p.hist + cur.stream * (long long)p.hist_len * Cn;
+        const long long f0 = ((long long)cur.w - p.partitions) * p.hop;      // window w covers blocks (w-P, w-P+1)
+        cf *spec_w = p.spec + ((cur.stream * n_windows + cur.w) * p.n_pairs) * (long long)kN;
+        for (int pair0 = 0; pair0 < p.n_pairs; pair0 += 2) {
+            const bool more = pair0 + 2 < p.n_pairs;
+            if (pair0 > 0 || id != first) ctx.barrier();          // every wave is done reading buf0/buf1
+            {
+                cf pw[16];
+                tw_powers(ctx.opaque(w1), pw);
+                cf x[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][0], raw[j][1]);
+                pair_pass1(x, pw, buf0, t);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][2], raw[j][3]);
+                pair_pass1(x, pw, buf1, t);
+            }
+            // the next batch's frames — of this window, or the first batch of the workgroup's next window — travel while
+            // this batch's sub-FFTs run (no accumulators or tables live here)
+            if (more) load(in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
+            else {
+                const PartWin nx = part_window_of<MODE>(id + step < end ? id + step : id, per, w0, skip);     // the last one re-reads its own batch
+                load(p.in + nx.stream * p.frames * Cn, p.hist + nx.stream * (long long)p.hist_len * Cn,
+                     ((long long)nx.w - p.partitions) * p.hop, t, 0, raw);
+            }
+            ctx.barrier();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (pair0 + h >= p.n_pairs) break;            // uniform
+                cf *buf = h == 0 ? buf0 : buf1;
+                cf *row0 = buf + wave_row(wave, 0) * kRowStride;
+                cf *row1 = buf + wave_row(wave, 1) * kRowStride;
+                cf z[2][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { z[0][j] = ctx.ld(row0 + lane + 64 * j); z[1][j] = ctx.ld(row1 + lane + 64 * j); }
+                ctx.wave_sync();
+                sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
+                cf *dst = spec_w + (long long)(pair0 + h) * kN;
+                // a real-only last pair (odd channel count): Z[N-k] = conj(Z[k]); rows 9..15 (slot 1 of waves 1..7) are not stored
+                const bool skip1 = p.herm_last && pair0 + h == p.n_pairs - 1 && wave != 0;      // uniform
+#ifdef AW_ABL_FWD_NOSTORE      // timing ablation only (wrong results): one store per wave instead of 16
+                if (z[0][0].x == 1.2345e-30f) dst[lane] = z[1][7];
+                continue;
+#endif
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (s == 1 && skip1) break;
+#pragma unroll
+                    for (int kc = 0; kc < 8; ++kc) dst[wave_row(wave, s) * kSub + lane + 64 * kc] = z[s][kc];
+                }
+            }
+        }
+    }
+}
+
+// one window (the CPU emulation harness and non-persistent launches)
+template <class Ctx, int CS, int MODE>
+AW_HD void tile_part_forward(Ctx &ctx, const TileParams &p, long long stream, int widx) {
+    const int n_windows = p.n_blocks + p.partitions - 1;
+    tiles_part_forward<Ctx, CS, MODE>(ctx, p, stream * n_windows + widx, 1, stream * n_windows + widx + 1, n_windows, MODE == 0 ? n_windows : 0, 0);
+}
+
+// Kernel 1, one-pair form: ONE channel pair of one input window per workgroup — one exchange buffer (78 KB of LDS) and
+// no register batch of four channels, so two workgroups share a CU like the inverse kernel's (which moves the same bytes
+// per transform and runs 4.4 us per transform against 6.2 here with one 152-KB workgroup per CU).  The four pair
+// workgroups of a window are neighbours in the launch order of one XCD: the lines they all read meet in its L2.
+struct __attribute__((packed, aligned(4))) f2u { float x, y; };    // 8 bytes at dword alignment
+
+template <class Ctx, int CS, int MODE>
+AW_HD void tile_part_forward1(Ctx &ctx, const TileParams &p, long long stream, int widx, int pair) {
+    const int t = ctx.tid();
+    const int lane = ctx.lane(), wave = ctx.wave();
+    cf *buf0 = ctx.lds();
+    cf *twa = buf0 + kBufElems;
     cf *twb = twa + kTwaElems;
     const int Cn = CS > 0 ? CS : p.n_channels;
     const float *in_s = p.in + stream * p.frames * Cn;
     const float *hist_s = p.hist + stream * (long long)p.hist_len * Cn;
     const long long f0 = ((long long)widx - p.partitions) * p.hop;      // window widx covers blocks (widx-P, widx-P+1)
     const int n_windows = p.n_blocks + p.partitions - 1;
-    cf *spec_w = p.spec + ((stream * n_windows + widx) * p.n_pairs) * (long long)kN;
-
-    float raw[16][kBatchCh];
-    load_batch<CS, INTERIOR>(p, in_s, hist_s, f0, t, 0, raw);
+    cf *dst = p.spec + ((stream * n_windows + widx) * p.n_pairs + pair) * (long long)kN;
+    const int c0 = 2 * pair;
+    const bool has_b = c0 + 1 < Cn;                 // uniform: an odd channel count's last pair has no second channel
+    cf x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const long long f = f0 + t + 512 * j;
+        if constexpr (MODE != 0 && CS > 0) {
+            const float *src = (MODE == 2 && f < 0 ? hist_s + ((long long)p.hist_len + f) * CS : in_s + f * CS) + c0;
+            if constexpr (CS % 2 == 0) {
+                const f2 v = *reinterpret_cast<const f2 *>(src);
+                x[j] = mk(v.x, v.y);
+            } else {
+                const f2u v = *reinterpret_cast<const f2u *>(src);      // the last pair's .y is the next frame's first sample: dropped below
+                x[j] = mk(v.x, v.y);
+            }
+        } else {
+            const bool before = f < 0, past = f >= p.frames;
+            const float *src = before ? hist_s + ((long long)p.hist_len + f) * Cn : (past ? p.zeros : in_s + f * Cn);
+            const float *qa = src + c0, *qb = has_b ? src + c0 + 1 : p.zeros;
+            x[j] = mk(*qa, *qb);
+        }
+    }
+    if constexpr (MODE != 0 && CS > 0 && (CS & 1)) {
+        if (!has_b) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) x[j].y = 0.f;
+        }
+    }
     const cf w1 = p.tw1[t];
     twa[t] = p.twa[t];
     if (t < kTwbElems) twb[t] = p.twb[t];
-
-    for (int pair0 = 0; pair0 < p.n_pairs; pair0 += 2) {
-        const bool more = pair0 + 2 < p.n_pairs;
-        if (pair0 > 0) ctx.barrier();
-        {
-            cf pw[16];
-            tw_powers(ctx.opaque(w1), pw);
-            cf x[16];
+    {
+        cf pw[16];
+        tw_powers(ctx.opaque(w1), pw);
+        pair_pass1(x, pw, buf0, t);
+    }
+    ctx.barrier();
+    cf *row0 = buf0 + wave_row(wave, 0) * kRowStride;
+    cf *row1 = buf0 + wave_row(wave, 1) * kRowStride;
+    cf z[2][8];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][0], raw[j][1]);
-            pair_pass1(x, pw, buf0, t);
+    for (int j = 0; j < 8; ++j) { z[0][j] = ctx.ld(row0 + lane + 64 * j); z[1][j] = ctx.ld(row1 + lane + 64 * j); }
+    ctx.wave_sync();
+    sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
+    const bool skip1 = p.herm_last && pair == p.n_pairs - 1 && wave != 0;      // uniform (see tile_part_forward)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][2], raw[j][3]);
-            pair_pass1(x, pw, buf1, t);
-        }
-        // the next batch's frames travel while this batch's sub-FFTs run (no accumulators or tables live here)
-        if (more) load_batch<CS, INTERIOR>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
-        ctx.barrier();
+    for (int s = 0; s < 2; ++s) {
+        if (s == 1 && skip1) break;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (pair0 + h >= p.n_pairs) break;            // uniform
-            cf *buf = h == 0 ? buf0 : buf1;
-            cf *row0 = buf + wave_row(wave, 0) * kRowStride;
-            cf *row1 = buf + wave_row(wave, 1) * kRowStride;
-            cf z[2][8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { z[0][j] = ctx.ld(row0 + lane + 64 * j); z[1][j] = ctx.ld(row1 + lane + 64 * j); }
-            ctx.wave_sync();
-            sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
-            cf *dst = spec_w + (long long)(pair0 + h) * kN;
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int kc = 0; kc < 8; ++kc) dst[wave_row(wave, s) * kSub + lane + 64 * kc] = z[s][kc];
-        }
+        for (int kc = 0; kc < 8; ++kc) dst[wave_row(wave, s) * kSub + lane + 64 * kc] = z[s][kc];
     }
 }
 

@@ -192,10 +192,11 @@ double aw_hrir_sample_rate(const aw_hrir *h) { return h ? h->sample_rate : 0.0; 
 
 /* ---- spatializer ---------------------------------------------------------------------------- */
 static aw_status sp_alloc_hist(aw_spatializer *sp) {
-    const size_t n = (size_t)sp->n_streams * sp->hist_len * sp->n_channels;
+    // + 4 floats: whole-frame vector loads of layouts whose frames are not float4s run up to 3 floats past a frame
+    const size_t n = (size_t)sp->n_streams * sp->hist_len * sp->n_channels + 4;
     for (int i = 0; i < 2; ++i) {
-        AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sp->d_hist[i]), std::max<size_t>(n, 1) * sizeof(float)));
-        AW_HIP_TRY(hipMemsetAsync(sp->d_hist[i], 0, std::max<size_t>(n, 1) * sizeof(float), sp->ctx->stream));
+        AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sp->d_hist[i]), n * sizeof(float)));
+        AW_HIP_TRY(hipMemsetAsync(sp->d_hist[i], 0, n * sizeof(float), sp->ctx->stream));
     }
     sp->hist_cur = 0;
     return AW_OK;
@@ -287,6 +288,12 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
         sp->hop = N / 2;
         sp->partitions = (hrir->taps + sp->hop - 1) / sp->hop;
         sp->hist_len = sp->partitions * sp->hop;
+        // every tuning knob of this path is read here, never on the process path
+        sp->cmac_group = sp->n_pairs > 8;                               // the marched kernel's lane groups hold up to 8 channel pairs
+        if (const char *e = getenv("AW_PART_CMAC")) sp->cmac_group = sp->cmac_group || std::strcmp(e, "group") == 0;
+        if (const char *e = getenv("AW_SPEC_SCRATCH_MB")) sp->scratch_budget = (size_t)atoll(e) << 20;
+        if (const char *e = getenv("AW_PART_FWD")) sp->fwd_one_pair = atoi(e) == 1;      // A/B: 1 = one channel pair per workgroup (two workgroups per CU)
+        if (const char *e = getenv("AW_PART_HERM")) sp->herm_ok = atoi(e) != 0;          // A/B: 0 stores the last pair's redundant half too
     }
     std::vector<awk::cf2> tab, all;
     if (sp->fused2) {
@@ -335,6 +342,7 @@ void aw_spatializer_destroy(aw_spatializer *sp) {
     if (sp->k0) (void)hipEventDestroy(sp->k0);
     if (sp->k1) (void)hipEventDestroy(sp->k1);
     for (auto &pr : sp->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto &r : sp->stage_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto ev : sp->event_pool) (void)hipEventDestroy(ev);
     delete sp;
 }
@@ -354,11 +362,15 @@ int64_t aw_spatializer_info(const aw_spatializer *sp, int32_t what) {
     }
 }
 
+static void sp_drain_stages(aw_spatializer *sp);
+
 aw_status aw_spatializer_set_profiling(aw_spatializer *sp, int32_t enabled) {
     if (!sp) return fail(AW_ERR_INVALID_ARGUMENT, "sp is NULL");
     sp->profiling = enabled != 0;
     sp->kernel_ms_sum = 0.0;
     sp->kernel_launches = 0;
+    sp_drain_stages(sp);
+    sp->stage_stats.clear();
     return AW_OK;
 }
 
@@ -371,6 +383,45 @@ static hipEvent_t sp_get_event(aw_spatializer *sp) {
     hipEvent_t e = nullptr;
     (void)hipEventCreate(&e);
     return e;
+}
+
+// HIP events around single launches on the context stream; drained into per-name sums by sp_drain_stages().
+struct SpStageTimer final : awk::StageTimer {
+    aw_spatializer *sp;
+    hipEvent_t cur = nullptr;
+    explicit SpStageTimer(aw_spatializer *s) : sp(s) {}
+    void begin() override { cur = sp_get_event(sp); (void)hipEventRecord(cur, sp->ctx->stream); }
+    void end(const char *name) override {
+        hipEvent_t e1 = sp_get_event(sp);
+        (void)hipEventRecord(e1, sp->ctx->stream);
+        sp->stage_pending.push_back({name, cur, e1});
+        cur = nullptr;
+    }
+};
+
+static void sp_drain_stages(aw_spatializer *sp) {
+    for (auto &r : sp->stage_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            auto it = std::find_if(sp->stage_stats.begin(), sp->stage_stats.end(), [&](const aw_spatializer::StageStat &s) { return std::strcmp(s.name, r.name) == 0; });
+            if (it == sp->stage_stats.end()) sp->stage_stats.push_back({r.name, ms, 1});
+            else { it->ms_sum += ms; it->launches += 1; }
+        }
+        sp->event_pool.push_back(r.e0);
+        sp->event_pool.push_back(r.e1);
+    }
+    sp->stage_pending.clear();
+}
+
+int32_t aw_spatializer_stage_time(aw_spatializer *sp, int32_t index, const char **name, double *total_ms, int32_t *launches) {
+    if (!sp || index < 0) return 0;
+    sp_drain_stages(sp);
+    if ((size_t)index >= sp->stage_stats.size()) return 0;
+    const auto &s = sp->stage_stats[(size_t)index];
+    if (name) *name = s.name;
+    if (total_ms) *total_ms = s.ms_sum;
+    if (launches) *launches = s.launches;
+    return 1;
 }
 
 int32_t aw_spatializer_kernel_time(aw_spatializer *sp, double *avg_ms, const char **kernel_name) {
@@ -386,7 +437,7 @@ int32_t aw_spatializer_kernel_time(aw_spatializer *sp, double *avg_ms, const cha
     }
     sp->pending.clear();
     if (avg_ms) *avg_ms = sp->kernel_launches ? sp->kernel_ms_sum / sp->kernel_launches : 0.0;
-    if (kernel_name) *kernel_name = sp->path == 0 ? (sp->fused2 ? awk::fused_ols2_kernel_name(sp->n_channels) : sp->fusedh ? awk::fused_olsh_kernel_name(sp->n_channels) : awk::fused_ols_kernel_name(sp->n_channels)) : "aw_part_forward_kernel + aw_part_cmac_kernel + aw_part_inverse_kernel";
+    if (kernel_name) *kernel_name = sp->path == 0 ? (sp->fused2 ? awk::fused_ols2_kernel_name(sp->n_channels) : sp->fusedh ? awk::fused_olsh_kernel_name(sp->n_channels) : awk::fused_ols_kernel_name(sp->n_channels)) : (sp->cmac_group ? "aw_part_forward_kernel + aw_part_cmac_kernel + aw_part_inverse_kernel" : "aw_part_forward_kernel + aw_part_march_kernel + aw_part_inverse_kernel");
     const int n = sp->kernel_launches;
     sp->kernel_ms_sum = 0.0;
     sp->kernel_launches = 0;
@@ -473,25 +524,53 @@ static aw_status sp_process_fused(aw_spatializer *sp, const float *in, float *ou
     return AW_OK;
 }
 
+// Scratch of the partitioned path for calls of `frames` frames: window spectra + accumulated W of one stream chunk.
+// Grow-only; aw_spatializer_reserve() sizes it ahead of time so that process never allocates.
+struct PartPlan { int n_blocks; long long n_windows; size_t per_stream, per_stream_w; long long chunk; size_t need; };
+
+static PartPlan part_plan(const aw_spatializer *sp, int64_t frames, size_t budget_bytes) {
+    PartPlan pl{};
+    const int N = awk::kN, B = sp->hop, P = sp->partitions;
+    pl.n_blocks = (int)((frames + B - 1) / B);
+    pl.n_windows = (long long)pl.n_blocks + P - 1;
+    pl.per_stream = (size_t)pl.n_windows * sp->n_pairs * N;          // complex elements of window spectra
+    pl.per_stream_w = (size_t)pl.n_blocks * N;                       // complex elements of accumulated W
+    pl.chunk = (long long)(budget_bytes / ((pl.per_stream + pl.per_stream_w) * sizeof(awk::cf)));
+    if (pl.chunk < 1) pl.chunk = 1;
+    if (pl.chunk > sp->n_streams) pl.chunk = sp->n_streams;
+    if (pl.chunk > 65535) pl.chunk = 65535;                          // grid.y / grid.z of the CMAC launches
+    pl.need = (pl.per_stream + pl.per_stream_w) * (size_t)pl.chunk;
+    return pl;
+}
+
+// Budget: AW_SPEC_SCRATCH_MB (read at create), else min(64 GiB, 40 % of the device memory free when first needed) —
+// sized for 288 GB of HBM: cfg 3 (1024 streams x 10 s, 4 pairs, 8 partitions) needs 40 GB and runs as one chunk.
+static size_t part_budget(aw_spatializer *sp) {
+    if (sp->scratch_budget == 0) {
+        size_t free_b = 0, total_b = 0;
+        size_t b = (size_t)6 << 30;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) b = std::min<size_t>((size_t)64 << 30, free_b / 5 * 2);
+        sp->scratch_budget = std::max<size_t>(b, (size_t)64 << 20);
+    }
+    return sp->scratch_budget;
+}
+
+static aw_status part_ensure_scratch(aw_spatializer *sp, size_t need) {
+    if (sp->spec_capacity >= need) return AW_OK;
+    if (sp->d_spec) AW_HIP_TRY(hipFree(sp->d_spec));
+    sp->d_spec = nullptr; sp->spec_capacity = 0;
+    AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sp->d_spec), need * sizeof(awk::cf)));
+    sp->spec_capacity = need;
+    return AW_OK;
+}
+
 static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, float *out, int64_t frames) {
     const int N = awk::kN, B = sp->hop, P = sp->partitions;
-    const int n_blocks = (int)((frames + B - 1) / B);
-    const long long n_windows = (long long)n_blocks + P - 1;
-    const size_t per_stream = (size_t)n_windows * sp->n_pairs * N;          // complex elements of window spectra
-    const size_t per_stream_w = (size_t)n_blocks * N;                       // complex elements of accumulated W
-    size_t budget_mb = 6144;
-    if (const char *e = getenv("AW_SPEC_SCRATCH_MB")) budget_mb = (size_t)atoll(e);
-    long long chunk = (long long)((budget_mb << 20) / ((per_stream + per_stream_w) * sizeof(awk::cf)));
-    if (chunk < 1) chunk = 1;
-    if (chunk > sp->n_streams) chunk = sp->n_streams;
-    if (chunk > 65535) chunk = 65535;                                       // grid.z of the CMAC launch
-    const size_t need = (per_stream + per_stream_w) * (size_t)chunk;
-    if (sp->spec_capacity < need) {
-        if (sp->d_spec) AW_HIP_TRY(hipFree(sp->d_spec));
-        sp->d_spec = nullptr; sp->spec_capacity = 0;
-        AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sp->d_spec), need * sizeof(awk::cf)));
-        sp->spec_capacity = need;
-    }
+    const PartPlan pl = part_plan(sp, frames, part_budget(sp));
+    const int n_blocks = pl.n_blocks;
+    const long long chunk = pl.chunk;
+    aw_status st = part_ensure_scratch(sp, pl.need);
+    if (st != AW_OK) return st;
     sp->dominant_frames = 0;
     for (long long s0 = 0; s0 < sp->n_streams; s0 += chunk) {
         const int ns = (int)std::min<long long>(chunk, sp->n_streams - s0);
@@ -502,24 +581,44 @@ static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, flo
         p.tab = sp->d_tab; p.tw1 = sp->ctx->d_tw1; p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb; p.zeros = sp->ctx->d_zeros;
         p.frames = frames; p.n_channels = sp->n_channels; p.n_pairs = sp->n_pairs;
         p.hop = B; p.hist_len = sp->hist_len; p.tiles_per_stream = n_blocks;
-        p.spec = sp->d_spec; p.wspec = sp->d_spec + per_stream * (size_t)chunk;
+        p.spec = sp->d_spec; p.wspec = sp->d_spec + pl.per_stream * (size_t)chunk;
         p.partitions = P; p.n_blocks = n_blocks; p.first_valid = N - B;
         p.stagger = 0; p.dbg = nullptr;
+        p.fwd_one_pair = sp->fwd_one_pair ? 1 : 0;
+        p.herm_last = (!sp->cmac_group && sp->herm_ok && (sp->n_channels & 1)) ? 1 : 0;
         // the timed unit of this path is the whole three-kernel pipeline of one stream chunk
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (sp->profiling) {
             e0 = sp_get_event(sp); e1 = sp_get_event(sp);
             AW_HIP_TRY(hipEventRecord(e0, sp->ctx->stream));
         }
-        AW_HIP_TRY(awk::launch_part_forward(p, ns, sp->ctx->stream));
-        AW_HIP_TRY(awk::launch_part_cmac(p, ns, sp->ctx->stream));
-        AW_HIP_TRY(awk::launch_part_inverse(p, ns, sp->ctx->stream));
+        SpStageTimer tm(sp);
+        awk::StageTimer *tmp = sp->profiling ? &tm : nullptr;
+        AW_HIP_TRY(awk::launch_part_forward(p, ns, sp->ctx->stream, tmp));
+        if (sp->cmac_group) AW_HIP_TRY(awk::launch_part_cmac(p, ns, sp->ctx->stream, tmp));
+        else AW_HIP_TRY(awk::launch_part_march(p, ns, sp->ctx->stream, tmp));
+        AW_HIP_TRY(awk::launch_part_inverse(p, ns, sp->ctx->stream, tmp));
         if (sp->profiling) {
             AW_HIP_TRY(hipEventRecord(e1, sp->ctx->stream));
             sp->pending.emplace_back(e0, e1);
         }
         sp->dominant_frames = (long long)ns * frames;
     }
+    return AW_OK;
+}
+
+// Sizes every grow-only device buffer for calls of up to max_frames frames, so that the process entries never
+// allocate afterwards ("process must not allocate"; creation may block).
+aw_status aw_spatializer_reserve(aw_spatializer *sp, int64_t max_frames) {
+    if (!sp) return fail(AW_ERR_INVALID_ARGUMENT, "sp is NULL");
+    if (max_frames <= 0) return fail(AW_ERR_INVALID_ARGUMENT, "max_frames must be positive");
+    AW_HIP_TRY(hipSetDevice(sp->ctx->device));
+    if (sp->path == 1) {
+        const PartPlan pl = part_plan(sp, max_frames, part_budget(sp));
+        aw_status st = part_ensure_scratch(sp, pl.need);
+        if (st != AW_OK) return st;
+    }
+    sp->reserved_frames = std::max<int64_t>(sp->reserved_frames, max_frames);
     return AW_OK;
 }
 
@@ -533,8 +632,11 @@ aw_status aw_spatializer_process(aw_spatializer *sp, const float *in, float *out
     if (st != AW_OK) return st;
     // carry the convolution tail: next call's history = last hist_len frames of (history ++ input)
     float *h_old = sp->d_hist[sp->hist_cur], *h_new = sp->d_hist[sp->hist_cur ^ 1];
+    SpStageTimer tm(sp);
+    if (sp->profiling) tm.begin();
     AW_HIP_TRY(awk::launch_hist_update(in, h_old, h_new, frames, sp->n_channels, sp->hist_len, sp->n_streams,
                                        sp->ctx->stream));
+    if (sp->profiling) tm.end("aw_hist_update_kernel");
     sp->hist_cur ^= 1;
     return AW_OK;
 }

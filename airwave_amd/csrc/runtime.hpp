@@ -55,6 +55,11 @@ struct aw_spatializer {
     // partitioned path scratch (grow-only): input-window spectra [stream][block][pair][N]
     awk::cf *d_spec = nullptr;
     size_t spec_capacity = 0;           // elements
+    size_t scratch_budget = 0;          // bytes per stream chunk (AW_SPEC_SCRATCH_MB at create; 0 = from free memory at first use)
+    bool cmac_group = false;            // partitioned path: block-group CMAC kernel instead of the marched one (> 8 pairs; AW_PART_CMAC=group)
+    bool fwd_one_pair = false;          // partitioned path: forward kernel with one channel pair per workgroup (opt-in AW_PART_FWD=1; measured 12.1 against 11.2 ms for the all-pairs kernel on cfg 3)
+    bool herm_ok = true;                // partitioned path, odd channel count: store/read only the non-redundant half of the last pair's spectrum
+    int64_t reserved_frames = 0;        // aw_spatializer_reserve(): buffers are sized for calls up to this many frames
     // host-entry staging (grow-only)
     float *d_stage_in = nullptr, *d_stage_out = nullptr;
     size_t stage_in_cap = 0, stage_out_cap = 0;   // floats
@@ -68,6 +73,11 @@ struct aw_spatializer {
     int kernel_launches = 0;
     long long dominant_frames = 0;         // output frames produced by the timed (dominant) launch of the last call
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // recorded, not yet read
+    // per-launch stage timing (profiling only): every kernel of the step, by name
+    struct StageRec { const char *name; hipEvent_t e0, e1; };
+    struct StageStat { const char *name; double ms_sum; int launches; };
+    std::vector<StageRec> stage_pending;
+    std::vector<StageStat> stage_stats;
     std::vector<hipEvent_t> event_pool;
 };
 

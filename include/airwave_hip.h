@@ -109,6 +109,10 @@ AW_API aw_status aw_spatializer_process_host(aw_spatializer *sp, const float *in
  * spatializer: planar HOST buffers, input_right may be NULL (mono duplication). Zero latency. */
 AW_API aw_status aw_spatializer_process_planar(aw_spatializer *sp, const float *input_left, const float *input_right,
                                                float *output_left, float *output_right, int32_t frame_count);
+/* Sizes every internal device buffer for calls of up to max_frames frames, so that the process entries never
+ * allocate afterwards (the reference allocates all engine state in ConvolutionEngine.init, ConvolutionEngine.swift:97-138,
+ * and nothing in process; creation may block, process must not).  Optional: without it buffers grow on first use. */
+AW_API aw_status aw_spatializer_reserve(aw_spatializer *sp, int64_t max_frames);
 /* ConvolutionEngine.reset() for every engine of every stream (ConvolutionEngine.swift:397-407). */
 AW_API aw_status aw_spatializer_reset(aw_spatializer *sp);
 AW_API int32_t aw_spatializer_stream_count(const aw_spatializer *sp);
@@ -121,6 +125,10 @@ AW_API int64_t aw_spatializer_info(const aw_spatializer *sp, int32_t what);
  * on the context stream); used for bench.py's roofline object.  Returns launches counted. */
 AW_API aw_status aw_spatializer_set_profiling(aw_spatializer *sp, int32_t enabled);
 AW_API int32_t aw_spatializer_kernel_time(aw_spatializer *sp, double *avg_ms, const char **kernel_name);
+/* While profiling is on every kernel launch of the partitioned path (and the history carry of every path) is bracketed by
+ * HIP events of its own; this iterates the per-kernel sums since profiling was switched on: index 0, 1, ... until it
+ * returns 0.  total_ms / launches are over all calls; names are static strings. */
+AW_API int32_t aw_spatializer_stage_time(aw_spatializer *sp, int32_t index, const char **name, double *total_ms, int32_t *launches);
 
 /* Diagnostic builds only (library compiled with -DAW_STAMPS=1, see tools/stamps.py): copies the
  * per-workgroup phase time stamps of the last fused-kernel launch to host_out as

@@ -90,6 +90,7 @@ class Spatializer {
     void process(const float *inputLeft, const float *inputRight, float *outputLeft, float *outputRight, int frameCount) {
         check(aw_spatializer_process_planar(h_, inputLeft, inputRight, outputLeft, outputRight, frameCount));
     }
+    void reserve(int64_t maxFrames) { check(aw_spatializer_reserve(h_, maxFrames)); }
     void reset() { check(aw_spatializer_reset(h_)); }
     aw_spatializer *get() const { return h_; }
   private:

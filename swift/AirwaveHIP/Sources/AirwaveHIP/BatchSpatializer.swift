@@ -35,6 +35,12 @@ public final class BatchSpatializer {
         guard st == AW_OK else { throw BatchSpatializer.error(st) }
     }
 
+    /// Sizes every internal device buffer for calls of up to `maxFrames` frames; `process` never allocates afterwards.
+    public func reserve(maxFrames: Int64) throws {
+        let st = aw_spatializer_reserve(handle, maxFrames)
+        guard st == AW_OK else { throw BatchSpatializer.error(st) }
+    }
+
     public func reset() { _ = aw_spatializer_reset(handle) }
 
     static func error(_ st: aw_status) -> NSError {

@@ -11,7 +11,7 @@ _DEFS = os.environ.get("AW_EMU_DEFINES", "").split()          # e.g. "-DAW_SUBFF
 _LIB = os.path.join(_HERE, "libemu.so" if not _DEFS else "libemu_variant.so")
 _SRCS = [os.path.join(_HERE, "emu_harness.cpp"), os.path.join(_ROOT, "airwave_amd/csrc/host/tables.cpp"),
          os.path.join(_ROOT, "airwave_amd/csrc/host/eq.cpp")]
-_DEPS = _SRCS + [os.path.join(_ROOT, "airwave_amd/csrc/device", f) for f in ("tile_ols.hpp", "tile_ols2.hpp", "tile_olsh.hpp", "cplx.hpp", "eq_cascade.hpp")] + [
+_DEPS = _SRCS + [os.path.join(_ROOT, "airwave_amd/csrc/device", f) for f in ("tile_ols.hpp", "tile_ols2.hpp", "tile_olsh.hpp", "tile_march.hpp", "cplx.hpp", "eq_cascade.hpp")] + [
     os.path.join(_ROOT, "airwave_amd/csrc/host/tables.hpp"), os.path.join(_ROOT, "airwave_amd/csrc/host/eq.hpp")]
 _lib = None
 
@@ -28,7 +28,7 @@ def lib():
         _lib.emu_fused_ols.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
                                        ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _lib.emu_partitioned.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
-                                         ctypes.c_longlong, ctypes.c_int]
+                                         ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
         _lib.emu_fft_small.argtypes = [fp, ctypes.c_int, ctypes.c_int]
         _lib.emu_eq_process.argtypes = [fp, fp, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_longlong, ctypes.c_double,
                                         ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int]
@@ -56,8 +56,9 @@ def fused_ols(x, tracks, left_track, right_track, hop=None, hist=None, variant=1
     return out
 
 
-def partitioned(x, tracks, left_track, right_track, hist=None):
-    """Long-HRIR path (hop 4096, P = ceil(taps/4096) partitions)."""
+def partitioned(x, tracks, left_track, right_track, hist=None, cmac="march"):
+    """Long-HRIR path (hop 4096, P = ceil(taps/4096) partitions); cmac = "march" (tile_march.hpp, the default
+    kernel) or "group" (the block-group kernel kept for more than 8 channel pairs)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     S, F, C = x.shape
     tr = np.ascontiguousarray(tracks, dtype=np.float32)
@@ -67,7 +68,7 @@ def partitioned(x, tracks, left_track, right_track, hist=None):
     h = None if hist is None else np.ascontiguousarray(hist, dtype=np.float32)
     rc = lib().emu_partitioned(x.ctypes.data_as(fp), out.ctypes.data_as(fp), None if h is None else h.ctypes.data_as(fp),
                                tr.ctypes.data_as(fp), tr.shape[0], tr.shape[1], C, lt.ctypes.data_as(ip),
-                               rt.ctypes.data_as(ip), F, S)
+                               rt.ctypes.data_as(ip), F, S, 1 if cmac == "group" else 0)
     assert rc == 0
     return out
 

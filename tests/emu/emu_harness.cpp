@@ -6,6 +6,7 @@
 // be checked on the CPU-only build container before spending GPU minutes.  It is NOT part of the
 // product library and nothing under airwave_amd/ links it.
 #include <barrier>
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +16,7 @@
 
 #include "../../airwave_amd/csrc/device/tile_ols.hpp"
 #include "../../airwave_amd/csrc/device/tile_olsh.hpp"
+#include "../../airwave_amd/csrc/device/tile_march.hpp"
 #include "../../airwave_amd/csrc/device/eq_cascade.hpp"
 #include "../../airwave_amd/csrc/host/eq.hpp"
 #include "../../airwave_amd/csrc/host/tables.hpp"
@@ -241,7 +243,7 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
 // Partitioned (long-HRIR) path: kernel 1 (window spectra) then kernel 2 (CMAC over partitions + inverse).
 int emu_partitioned(const float *in, float *out, const float *hist, const float *tracks, int n_tracks, int taps,
                     int n_channels, const int32_t *left_track, const int32_t *right_track, long long frames,
-                    int n_streams) {
+                    int n_streams, int cmac_variant) {
     using namespace awk;
     const int B = kN / 2, P = (taps + B - 1) / B;
     awh::Twiddles tw;
@@ -256,11 +258,13 @@ int emu_partitioned(const float *in, float *out, const float *hist, const float 
     p.frames = frames; p.n_channels = n_channels; p.n_pairs = (n_channels + 1) / 2;
     p.hop = B; p.hist_len = P * B; p.partitions = P; p.n_blocks = (int)((frames + B - 1) / B);
     p.tiles_per_stream = p.n_blocks; p.first_valid = kN - B;
+    p.herm_last = (cmac_variant != 1 && (n_channels & 1)) ? 1 : 0;      // as runtime.cpp sets it
     const int n_windows = p.n_blocks + P - 1;
-    std::vector<float> zero_hist;
-    if (!hist) { zero_hist.assign((size_t)n_streams * p.hist_len * n_channels, 0.f); hist = zero_hist.data(); }
-    p.hist = hist;
-    std::vector<cf> spec((size_t)n_streams * n_windows * p.n_pairs * kN);
+    // history with the 4 floats of slack the runtime allocates (whole-frame vector loads of 7-float frames)
+    std::vector<float> hist_pad((size_t)n_streams * p.hist_len * n_channels + 4, 0.f);
+    if (hist) std::memcpy(hist_pad.data(), hist, ((size_t)n_streams * p.hist_len * n_channels) * sizeof(float));
+    p.hist = hist_pad.data();
+    std::vector<cf> spec((size_t)n_streams * n_windows * p.n_pairs * kN, mk(NAN, NAN));      // a read of a bin that was never stored poisons the output
     p.spec = spec.data();
     EmuShared sh;
     auto run = [&](auto fn, int count) {
@@ -272,25 +276,59 @@ int emu_partitioned(const float *in, float *out, const float *hist, const float 
                 for (auto &x : th) x.join();
             }
     };
-    {   // interior / boundary split of awk::launch_part_forward (vector variants exist for 7 and 8 channels here)
+    {   // interior / head / generic split of awk::launch_part_forward (vector variants exist for 7 and 8 channels here)
         const long long usable = frames - ((n_channels % 4 != 0 && n_channels != 2) ? 1 : 0);
         long long lo = P, hi = usable >= kN ? (usable - kN) / B + P + 1 : lo;
         if (hi > n_windows) hi = n_windows;
         if (lo > n_windows) lo = n_windows;
-        if (hi < lo) hi = lo;
-        if (n_channels != 7 && n_channels != 8) hi = lo;
+        if (hi < lo) lo = hi;
+        if (hi < 0) hi = 0;
+        if (lo < 0) lo = 0;
+        if (n_channels != 7 && n_channels != 8) { lo = 0; hi = 0; }
+        if (cmac_variant == 1)             // with the block-group CMAC: the all-pairs-per-workgroup forward kernel
         run([&](EmuCtx &ctx, int s, int w) {
             if (w >= lo && w < hi) {
-                if (n_channels == 7) tile_part_forward<EmuCtx, 7, true>(ctx, p, s, w);
-                else tile_part_forward<EmuCtx, 8, true>(ctx, p, s, w);
-            } else tile_part_forward<EmuCtx, 0, false>(ctx, p, s, w);
+                if (n_channels == 7) tile_part_forward<EmuCtx, 7, 1>(ctx, p, s, w);
+                else tile_part_forward<EmuCtx, 8, 1>(ctx, p, s, w);
+            } else if (w < lo) {
+                if (n_channels == 7) tile_part_forward<EmuCtx, 7, 2>(ctx, p, s, w);
+                else tile_part_forward<EmuCtx, 8, 2>(ctx, p, s, w);
+            } else tile_part_forward<EmuCtx, 0, 0>(ctx, p, s, w);
+        }, n_windows);
+        else                               // default: one channel pair per workgroup
+        for (int pair = 0; pair < p.n_pairs; ++pair)
+        run([&](EmuCtx &ctx, int s, int w) {
+            if (w >= lo && w < hi) {
+                if (n_channels == 7) tile_part_forward1<EmuCtx, 7, 1>(ctx, p, s, w, pair);
+                else tile_part_forward1<EmuCtx, 8, 1>(ctx, p, s, w, pair);
+            } else if (w < lo) {
+                if (n_channels == 7) tile_part_forward1<EmuCtx, 7, 2>(ctx, p, s, w, pair);
+                else tile_part_forward1<EmuCtx, 8, 2>(ctx, p, s, w, pair);
+            } else tile_part_forward1<EmuCtx, 0, 0>(ctx, p, s, w, pair);
         }, n_windows);
     }
-    std::vector<cf> wspec((size_t)n_streams * p.n_blocks * kN);
+    std::vector<cf> wspec((size_t)n_streams * p.n_blocks * kN, mk(0.f, 0.f));
     p.wspec = wspec.data();
-    for (int s = 0; s < n_streams; ++s)                       // kernel 2: one "thread" per bin and block group
-        for (int b0 = 0; b0 < p.n_blocks; b0 += kCmacBlocks)
-            for (int i = 0; i < kN; ++i) part_cmac_bin(p, s, b0, i);
+    if (cmac_variant == 1) {
+        for (int s = 0; s < n_streams; ++s)                   // block-group kernel: one "thread" per bin and block group
+            for (int b0 = 0; b0 < p.n_blocks; b0 += kCmacBlocks)
+                for (int i = 0; i < kN; ++i) part_cmac_bin(p, s, b0, i);
+    } else {
+        // marched kernel: one "thread" per (bin-pair slot, channel pair); the lane-group sum is the += below.
+        // Passes of at most 8 partitions, PQ as awk::launch_part_march picks it.
+        for (int s = 0; s < n_streams; ++s)
+            for (int q0 = 0; q0 < P; q0 += 8)
+                for (int j = 0; j < kMarchSlots; ++j)
+                    for (int pl = 0; pl < p.n_pairs; ++pl) {
+                        auto emit = [&](long long st, int b, const MarchBins &mb, cf ai, cf ap) {
+                            cf *w = p.wspec + (st * p.n_blocks + b) * kN;
+                            w[mb.i] = w[mb.i] + ai;
+                            if (mb.pi != mb.i) w[mb.pi] = w[mb.pi] + ap;
+                        };
+                        if (P - q0 <= 4) march_thread<4>(p, s, s + 1, j, pl, q0, emit);
+                        else march_thread<8>(p, s, s + 1, j, pl, q0, emit);
+                    }
+    }
     run([&](EmuCtx &ctx, int s, int b) { tile_part_inverse<EmuCtx>(ctx, p, s, b); }, p.n_blocks);
     return 0;
 }

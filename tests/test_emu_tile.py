@@ -102,13 +102,40 @@ def test_emulated_sibling_workgroup_tiles(oracle, channels, taps, frames):
     assert oracle.peak_rel_error(y[0], oracle.spatialize_f64(x[0], h, lt, rt)) < TOL
 
 
-def test_emulated_partitioned_more_than_eight_partitions(oracle):
-    """P = 10 partitions: the per-bin CMAC kernel walks the partitions in chunks of 8, so this exercises a second,
-    partial chunk (and block groups that straddle it)."""
+@pytest.mark.parametrize("cmac", ["march", "group"])
+def test_emulated_partitioned_more_than_eight_partitions(oracle, cmac):
+    """P = 10 partitions: both CMAC kernels take the partitions 8 at a time, so this exercises a second, partial pass
+    (marched kernel: a PQ = 4 pass with two zero-table slots that accumulates into W; block-group kernel: groups that
+    straddle the chunk)."""
     h = oracle.synth_hrir(14, 40000, seed=8)
     lt = np.array([0, 3, 5], np.int32)
     rt = np.array([1, 4, 13], np.int32)
     x = oracle.synth_input(1, 50001, 3, seed=2)
-    y = emu.partitioned(x, h, lt, rt)
+    y = emu.partitioned(x, h, lt, rt, cmac=cmac)
     assert not np.isnan(y).any()
     assert oracle.peak_rel_error(y[0], oracle.spatialize_f64(x[0], h, lt, rt)) < TOL
+
+
+def test_marched_cmac_slots_cover_every_bin_once():
+    """tile_march.hpp: slot -> (bin, partner bin) must hit each of the 8192 storage indices exactly once, each slot's two
+    bins must be k and N - k, and the two self-paired bins (k = 0, N/2) get slots of their own."""
+    N = 8192
+    seen = np.zeros(N, int)
+    for j in range(N // 2 + 1):
+        if j < 7 * 512:
+            row, col = 1 + (j >> 9), j & 511
+            i, pi = row * 512 + col, (16 - row) * 512 + (511 - col)
+        elif j < 7 * 512 + 256:
+            col = j - 7 * 512
+            i, pi = col, (512 - col) & 511
+        elif j < 8 * 512:
+            col = j - (7 * 512 + 256)
+            i, pi = 8 * 512 + col, 8 * 512 + 511 - col
+        else:
+            i = pi = 256
+        k, kp = (i >> 9) + 16 * (i & 511), (pi >> 9) + 16 * (pi & 511)      # storage index = k1 * 512 + k2, k = k1 + 16 k2
+        assert (k + kp) % N == 0
+        seen[i] += 1
+        if pi != i:
+            seen[pi] += 1
+    assert (seen == 1).all()

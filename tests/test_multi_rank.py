@@ -61,3 +61,35 @@ def test_two_ranks_aggregate_like_bench():
     import airwave_oracle as orc
     whole = float(np.abs(orc.synth_input(6, 64, 2)).sum())
     assert abs(res[0][6] - whole) < 1e-6 * whole      # the two shards are exactly the single-process batch
+
+
+def _bench(*argv, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), env=e, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` (no launcher, WORLD_SIZE unset) must itself start two ranks — here in --dry-run mode
+    (no GPU in this container: rendezvous + shard + aggregate only, over gloo).  The line says it is no measurement."""
+    rc, line, err = _bench("--gpus", "2", "--dry-run", "--streams", "5")
+    assert rc == 0, err
+    assert line["dry_run"] is True and line["value"] == 0.0
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["self_launched"] is True
+    assert line["frames_all_ranks"] == 2 * 5 * 1000          # both shards were aggregated
+
+
+def test_bench_refuses_a_world_that_disagrees_with_gpus():
+    """Under a launcher the rank count must equal --gpus: never a line that claims N GPUs from a different world."""
+    rc, line, err = _bench("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc == 2 and line is None and "disagrees" in err
+    rc, line, err = _bench("--gpus", "1", "--dry-run")
+    assert rc == 0 and line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["self_launched"] is False
