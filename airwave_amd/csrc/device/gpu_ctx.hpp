@@ -98,6 +98,38 @@ struct GpuCtx {
         xswap32(a, b, bit);
         lo.y = __uint_as_float(a); hi.y = __uint_as_float(b);
     }
+    // Streaming (non-temporal) stores for data written once and read by a LATER kernel (spectra, W, the stereo output):
+    // they do not occupy the XCD's L2, which then keeps the input lines that overlapping windows and the second channel
+    // batch re-read (cfg 3 forward kernel: fabric-side reads 27.9 -> 15.7 GB per step, 10.7 -> 9.95 ms).  AW_NT_STORES=0: plain.
+#ifndef AW_NT_STORES
+#define AW_NT_STORES 1
+#endif
+    __device__ __forceinline__ void st_stream(cf *p, cf v) const {
+#if AW_NT_STORES
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f x = {v.x, v.y};
+        __builtin_nontemporal_store(x, reinterpret_cast<v2f *>(p));
+#else
+        *p = v;
+#endif
+    }
+    __device__ __forceinline__ void st_stream4(float *p, float a, float b, float c, float d) const {   // dword-aligned 16 bytes
+#if AW_NT_STORES
+        typedef float v4fu __attribute__((ext_vector_type(4), aligned(4)));
+        v4fu x = {a, b, c, d};
+        __builtin_nontemporal_store(x, reinterpret_cast<v4fu *>(p));
+#else
+        f4u v; v.x = a; v.y = b; v.z = c; v.w = d;
+        *reinterpret_cast<f4u *>(p) = v;
+#endif
+    }
+    // value of lane ^ 1 (DPP quad_perm [1,0,3,2]): pairs neighbouring bins for 16-byte stores
+    __device__ __forceinline__ cf xchg1(cf v) const {
+        cf r;
+        r.x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.x), 0xB1, 0xf, 0xf, true));
+        r.y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.y), 0xB1, 0xf, 0xf, true));
+        return r;
+    }
     // unconditional scheduling fence (bounds how far loads are hoisted)
     __device__ __forceinline__ void sched_fence_hard() const {
         asm volatile("" ::: "memory");

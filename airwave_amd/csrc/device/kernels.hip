@@ -60,6 +60,9 @@ __global__ void __launch_bounds__(kThreads, 4) aw_fused_olsq_kernel(TileParams p
 
 // Windows [tile_lo, tile_hi) of every stream lie inside the call's input (INTERIOR), the others touch the
 // history or the zero page.  p.tile_lo/hi carry the window range here.
+#ifndef AW_FWD_RUNS
+#define AW_FWD_RUNS 0
+#endif
 // MODE 1: windows [tile_lo, tile_hi) (interior); MODE 2: windows [head_lo, tile_lo) (head: history + input);
 // MODE 0: the rest, [0, head_lo) and [tile_hi, n_windows).  Persistent, XCD-aware like the fused kernels: each XCD group
 // walks a contiguous eighth of the window list, so windows that overlap by half meet in one L2.
@@ -76,7 +79,15 @@ __global__ void __launch_bounds__(kThreads) aw_part_forward_kernel(TileParams p,
     const long long q = n_ids / 8, r = n_ids % 8;
     const long long lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     const long long hi = lo + (xcd < r ? q + 1 : q);
+#if AW_FWD_RUNS
+    // each workgroup walks a contiguous run of windows: consecutive windows of a stream overlap by half, and the half a
+    // workgroup has just read is the likeliest to still be in its XCD's L2
+    const long long run = (hi - lo + per_xcd_wg - 1) / per_xcd_wg;
+    const long long first = lo + slot * run;
+    tiles_part_forward<GpuCtx, CS, MODE>(ctx, p, first, 1, first + run < hi ? first + run : hi, per, w0, skip);
+#else
     tiles_part_forward<GpuCtx, CS, MODE>(ctx, p, lo + slot, per_xcd_wg, hi, per, w0, skip);
+#endif
 }
 
 // One-pair form: workgroup id -> (stream, window, pair), pairs innermost; kInvLdsBytes of LDS, two workgroups per CU.

@@ -19,6 +19,12 @@ __device__ __forceinline__ float lane_group_sum(float v) {
     if constexpr (LG >= 8) v = dpp_add<0x141>(v);      // row_half_mirror: lane i <-> 7 - i of each 8
     return v;
 }
+__device__ __forceinline__ void march_st(cf *p, cf v) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f x = {v.x, v.y};
+    __builtin_nontemporal_store(x, reinterpret_cast<v2f *>(p));
+}
+
 #ifndef AW_MARCH_STREAMS
 #define AW_MARCH_STREAMS 4      // streams a workgroup walks with one table load (each stream re-reads 4 MB of tables otherwise)
 #endif
@@ -46,8 +52,9 @@ __global__ void __launch_bounds__(kMarchThreads, AW_MARCH_MIN_WAVES) aw_part_mar
         if (ai.x != 1.2345e-30f) return;
 #endif
         if constexpr (!ACC) {
-            if constexpr (LG == 1) { w[mb.i] = ai; w[mb.pi] = ap; }
-            else w[woff] = odd ? ap : ai;
+            // streaming stores: W is read by the inverse kernel only
+            if constexpr (LG == 1) { march_st(w + mb.i, ai); march_st(w + mb.pi, ap); }
+            else march_st(w + woff, odd ? ap : ai);
         } else {
             if (real && pl == 0) w[mb.i] = ai + w[mb.i];
             if (real && pl == (LG > 1 ? 1 : 0) && mb.pi != mb.i) w[mb.pi] = ap + w[mb.pi];

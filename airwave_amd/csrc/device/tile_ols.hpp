@@ -391,7 +391,7 @@ AW_HD void tile_inverse_final(Ctx &ctx, const TileParams &p, cf *buf0, cf w1, in
         const int m = t + 512 * j;
         const long long f = f0 + m;
         if (m >= first_valid && f < p.frames)
-            *reinterpret_cast<cf *>(p.out + ((long long)stream * p.frames + f) * 2) = y[j];
+            ctx.st_stream(reinterpret_cast<cf *>(p.out + ((long long)stream * p.frames + f) * 2), y[j]);
     }
     ctx.stamp(13);
     ctx.flush_stamps();
@@ -523,6 +523,32 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
 // MODE 1 (interior): the window lies inside the call's input (whole-frame vector loads off a uniform base);
 // MODE 2 (head): history + input, nothing past the end (vector loads behind a per-frame pointer select);
 // MODE 0: anything (scalar loads; history, input or the zero page per frame).
+// One 512-bin row of a spectrum from registers (lane holds bins lane + 64 kc) to memory as 16-byte stores: neighbouring
+// lanes trade one value per pair of chunks, so that even lanes store bins (lane, lane + 1) of chunk 2m and odd lanes bins
+// (lane - 1, lane) of chunk 2m + 1 — half the store instructions of 8-byte stores, every instruction still two whole
+// 512-byte runs (the spectrum stores are the forward kernel's issue-bound tail: 10.9 ms with them, 7.9 ms without).
+#ifndef AW_FWD_STORE16
+#define AW_FWD_STORE16 0     // measured cfg 3: 10.95 ms with 16-byte stores against 10.66 ms with 8-byte ones — the stores are not issue-bound
+#endif
+template <class Ctx>
+AW_HD void store_row16(Ctx &ctx, cf *row, const cf (&z)[8], int lane) {
+#if AW_FWD_STORE16
+    const bool odd = (lane & 1) != 0;
+    cf *base = row + (lane & ~1);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const cf na = ctx.xchg1(z[2 * m]), nb = ctx.xchg1(z[2 * m + 1]);
+        cf2 v;
+        v.a = odd ? nb : z[2 * m];
+        v.b = odd ? z[2 * m + 1] : na;
+        *reinterpret_cast<cf2 *>(base + 64 * (2 * m + (odd ? 1 : 0))) = v;
+    }
+#else
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) ctx.st_stream(row + lane + 64 * kc, z[kc]);
+#endif
+}
+
 // Persistent form: the workgroup walks window ids first, first + step, ... < end of its launch; id -> (stream, window)
 // through `per` windows per stream starting at window `w0` (MODE 0: the windows outside [w0, w0 + skip) — see the launcher).
 // The next window's first frame batch is issued right after the current window's last pass 1, so its latency hides under
@@ -630,8 +656,7 @@ AW_HD void tiles_part_forward(Ctx &ctx, const TileParams &p, long long first, lo
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     if (s == 1 && skip1) break;
-#pragma unroll
-                    for (int kc = 0; kc < 8; ++kc) dst[wave_row(wave, s) * kSub + lane + 64 * kc] = z[s][kc];
+                    store_row16(ctx, dst + wave_row(wave, s) * kSub, z[s], lane);
                 }
             }
         }
@@ -713,7 +738,7 @@ AW_HD void tile_part_forward1(Ctx &ctx, const TileParams &p, long long stream, i
     for (int s = 0; s < 2; ++s) {
         if (s == 1 && skip1) break;
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc) dst[wave_row(wave, s) * kSub + lane + 64 * kc] = z[s][kc];
+        for (int kc = 0; kc < 8; ++kc) ctx.st_stream(dst + wave_row(wave, s) * kSub + lane + 64 * kc, z[s][kc]);
     }
 }
 

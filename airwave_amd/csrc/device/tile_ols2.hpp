@@ -180,11 +180,9 @@ AW_HD void tile_inverse_final2(Ctx &ctx, const TileParams &p, cf *buf0, cf *buf1
         const long long f = f0 + n;
         if (n < first_valid) continue;                   // first_valid is even: both frames of the pair are new or neither
         if (INTERIOR || f + 1 < p.frames) {
-            f4u v;
-            v.x = ye[j].x; v.y = ye[j].y; v.z = yo[j].x; v.w = yo[j].y;
-            *reinterpret_cast<f4u *>(out_s + f * 2) = v;
+            ctx.st_stream4(out_s + f * 2, ye[j].x, ye[j].y, yo[j].x, yo[j].y);
         } else if (f < p.frames) {
-            *reinterpret_cast<cf *>(out_s + f * 2) = ye[j];
+            ctx.st_stream(reinterpret_cast<cf *>(out_s + f * 2), ye[j]);
         }
     }
 }

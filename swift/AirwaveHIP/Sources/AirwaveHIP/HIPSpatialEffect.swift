@@ -7,6 +7,7 @@
 //  (call it off the render thread, as the reference does) and reports `HRIRActivationResult`.
 
 import Foundation
+import os
 import CAirwaveHIP
 
 public enum HIPActivationResult: Equatable {
@@ -24,20 +25,41 @@ public final class HIPContext {
     deinit { aw_context_destroy(handle) }
 }
 
+/// One activated renderer network.  Immutable once published; the C handle is destroyed when the LAST reference goes
+/// away — the control thread's or the render thread's snapshot, whichever drops it later — exactly the lifetime rule of
+/// `HRIRManager.RendererState` (Airwave/HRIRManager.swift:118-131), which ARC keeps alive while `audioThreadState` holds it.
+final class SpatializerBox {
+    let handle: OpaquePointer
+    init(_ h: OpaquePointer) { handle = h }
+    deinit { aw_spatializer_destroy(handle) }
+}
+
 public final class HIPSpatialEffect /* : AudioSpatialEffect */ {
     private let context: HIPContext
-    private var spatializer: OpaquePointer?   // published like HRIRManager.rendererState: replaced, never mutated
+    // Writers publish immutable state under one lock; the render thread makes one non-blocking snapshot attempt per
+    // callback and otherwise keeps the state it already has (HRIRManager.swift:133-147, 539-548).
+    private let stateLock = OSAllocatedUnfairLock<SpatializerBox?>(initialState: nil)
+    nonisolated(unsafe) private var audioThreadState: SpatializerBox?      // touched by the render thread only
+    // Destroying a handle frees device memory and synchronises a HIP stream: never on the render thread.  A state the
+    // render thread lets go of is parked here (try-lock; kept one more callback under contention) and destroyed by the
+    // next control-side call — the retirement scheme of ParametricEqualizerProcessor (ParametricEqualizerProcessor.swift:380-406).
+    private let retiredLock = OSAllocatedUnfairLock<[SpatializerBox]>(initialState: [])
+    nonisolated(unsafe) private var awaitingRetirement: [SpatializerBox] = []   // render thread only; capacity reserved in init
 
-    public init(context: HIPContext) { self.context = context }
-    deinit { if let s = spatializer { aw_spatializer_destroy(s) } }
+    public init(context: HIPContext) {
+        self.context = context
+        awaitingRetirement.reserveCapacity(8)       // the render thread appends without allocating
+        retiredLock.withLock { $0.reserveCapacity(8) }
+    }
 
     /// AudioSpatialEffect.isReady
-    public var isReady: Bool { spatializer != nil }
+    public var isReady: Bool { stateLock.withLock { $0 != nil } }
 
     /// HRIRManager.activatePreset(_:targetSampleRate:inputLayout:)  — stereo layout, like the shipped product
-    /// (DeviceProfileRuntimeCoordinator.swift:104-108).
+    /// (DeviceProfileRuntimeCoordinator.swift:104-108).  Blocks (file I/O, table FFTs, device allocation): call it off
+    /// the render thread, as the reference does on its background queue.
     @discardableResult
-    public func activatePreset(fileURL: URL, targetSampleRate: Double, channelCount: Int32 = 2) -> HIPActivationResult {
+    public func activatePreset(fileURL: URL, targetSampleRate: Double, channelCount: Int32 = 2, maxFramesPerCallback: Int = 4096) -> HIPActivationResult {
         var layout: OpaquePointer?
         guard aw_layout_detect(channelCount, &layout) == AW_OK else { return .failure(lastError()) }
         defer { aw_layout_destroy(layout) }
@@ -48,15 +70,24 @@ public final class HIPSpatialEffect /* : AudioSpatialEffect */ {
         guard status == AW_OK, let sp = created else {
             return .failure("Failed to activate preset: \(lastError())")   // HRIRManager.swift:441
         }
-        let old = spatializer
-        spatializer = sp
-        if let o = old { aw_spatializer_destroy(o) }
+        _ = aw_spatializer_reserve(sp, Int64(maxFramesPerCallback))         // process never allocates afterwards
+        let fresh = SpatializerBox(sp)
+        // Publish.  The previous box is NOT destroyed here: the render thread may be inside `process` with it; it dies
+        // when the render thread's next successful snapshot replaces `audioThreadState` (deferred destruction by ARC).
+        stateLock.withLock { $0 = fresh }
+        drainRetiredStates()
         return .success
     }
 
     public func deactivatePreset() {
-        if let s = spatializer { aw_spatializer_destroy(s) }
-        spatializer = nil
+        stateLock.withLock { $0 = nil }
+        drainRetiredStates()
+    }
+
+    /// Control thread: destroys the states the render thread has let go of (their deinit runs here, not in `process`).
+    public func drainRetiredStates() {
+        let dead = retiredLock.withLock { list -> [SpatializerBox] in let d = list; list.removeAll(); return d }
+        _ = dead          // the boxes die at the end of this scope, on the calling (control) thread
     }
 
     /// StereoAudioProcessing.process(inputLeft:inputRight:outputLeft:outputRight:frameCount:)
@@ -68,17 +99,47 @@ public final class HIPSpatialEffect /* : AudioSpatialEffect */ {
         frameCount: Int
     ) {
         guard frameCount > 0 else { return }
-        guard let sp = spatializer else {
+        // A writer can never stall the render thread.  A failed attempt keeps the prior immutable state.
+        var state = audioThreadState
+        enum StateRead { case available(SpatializerBox?) }
+        if let read = stateLock.withLockIfAvailable({ StateRead.available($0) }) {
+            if case .available(let published) = read {
+                if let old = audioThreadState, old !== published { retire(old) }
+                state = published
+                audioThreadState = published
+            }
+        }
+        if !awaitingRetirement.isEmpty { flushAwaitingRetirement() }
+        guard let state else {
             // passthrough, HRIRManager.swift:550-559
             memcpy(outputLeft, inputLeft, frameCount * MemoryLayout<Float>.size)
             memcpy(outputRight, inputRight ?? inputLeft, frameCount * MemoryLayout<Float>.size)
             return
         }
-        _ = aw_spatializer_process_planar(sp, inputLeft, inputRight, outputLeft, outputRight, Int32(frameCount))
+        _ = aw_spatializer_process_planar(state.handle, inputLeft, inputRight, outputLeft, outputRight, Int32(frameCount))
     }
 
-    /// HRIRManager.resetConvolutionState()
-    public func resetConvolutionState() { if let s = spatializer { _ = aw_spatializer_reset(s) } }
+    /// Render thread: hand a state over for destruction without ever blocking or freeing here.
+    private func retire(_ box: SpatializerBox) {
+        awaitingRetirement.append(box)
+        flushAwaitingRetirement()
+    }
+
+    private func flushAwaitingRetirement() {
+        // try-lock only: under contention the states wait in the render thread's own list for a later callback
+        let moved: Bool? = retiredLock.withLockIfAvailable { list in
+            for b in awaitingRetirement { list.append(b) }
+            return true
+        }
+        if moved != nil { awaitingRetirement.removeAll(keepingCapacity: true) }
+    }
+
+    /// HRIRManager.resetConvolutionState(): the reference resets through the control side's reference to the state; the
+    /// engine handle is single-owner for `process`, so the host must call this with the render thread quiescent, as the
+    /// reference does (device stop / start, AudioPipeline.swift).
+    public func resetConvolutionState() {
+        if let s = stateLock.withLock({ $0 }) { _ = aw_spatializer_reset(s.handle) }
+    }
 
     private func lastError() -> String { String(cString: aw_last_error_message()) }
 }

@@ -60,6 +60,15 @@ struct EmuCtx {
         sh->wave[tid_ >> 6]->arrive_and_wait();
     }
     void wave_sync() const { sh->wave[tid_ >> 6]->arrive_and_wait(); }
+    void st_stream(awk::cf *q, awk::cf v) const { *q = v; }
+    void st_stream4(float *q, float a, float b, float c, float d) const { q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
+    awk::cf xchg1(awk::cf v) const {          // value of lane ^ 1
+        sh->xs[(size_t)tid_ * 2] = v;
+        sh->wave[tid_ >> 6]->arrive_and_wait();
+        const awk::cf r = sh->xs[(size_t)(tid_ ^ 1) * 2];
+        sh->wave[tid_ >> 6]->arrive_and_wait();
+        return r;
+    }
     // sibling flags: the emulation runs workgroups one after the other, the even-bin one first
     void flag_release(int *flag, int epoch) const { sh->wg.arrive_and_wait(); if (tid_ == 0) *flag = epoch; }
     awk::cf ld_out(const float *q) const { return *reinterpret_cast<const awk::cf *>(q); }
