@@ -23,7 +23,7 @@ __device__ __forceinline__ long long xcd_remap(long long bid, long long nwg) {
 
 // INTERIOR = true : tiles [tile_lo, tile_hi) of every stream (window inside the call's input)
 // INTERIOR = false: the remaining boundary tiles (history at the start, zero fill at the end)
-template <int CS, int NP, bool INTERIOR>
+template <int CS, int NP, bool INTERIOR, bool ACC = false>
 __global__ void __launch_bounds__(kThreads) aw_fused_ols_kernel(TileParams p, long long n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GpuCtx ctx{reinterpret_cast<cf *>(smem), p.dbg ? p.dbg + (long long)blockIdx.x * kStamps : nullptr};
@@ -38,10 +38,11 @@ __global__ void __launch_bounds__(kThreads) aw_fused_ols_kernel(TileParams p, lo
     const long long q = n_tiles / 8, r = n_tiles % 8;
     const long long lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     const long long hi = lo + (xcd < r ? q + 1 : q);
-    tiles_fused_ols<GpuCtx, CS, NP, INTERIOR>(ctx, p, lo + slot, per_xcd_wg, hi);
+    tiles_fused_ols<GpuCtx, CS, NP, INTERIOR, ACC>(ctx, p, lo + slot, per_xcd_wg, hi);
 }
 
 static int g_persistent_wgs = 256;      // one resident workgroup per CU (152 KB LDS each)
+static bool g_wide_two_pass = true;     // AW_WIDE_TWO_PASS=0 (read in prepare_kernels): the single run-time-loop kernel for 12/14/16 channels
 
 // Sibling form (tile_olsh.hpp): workgroups 2s and 2s + 1 of an XCD group take the even and the odd bins of the same
 // tiles.  blockIdx = 8 * slot + xcd, so the odd-bin sibling has the higher id and is dispatched after its partner.
@@ -159,6 +160,8 @@ static bool has_vec2_variant(int C) { return C >= 1 && C <= 8; }
 // batches of two pairs at run time: more than 8 channels, where full unrolling only spills).
 #define AW_FOR_EACH_VEC(X) X(2, 1) X(4, 2) X(6, 3) X(7, 4) X(8, 4) X(12, 0) X(14, 0) X(16, 0)
 #define AW_FOR_EACH_GEN(X) X(1) X(2) X(3) X(4) X(0)
+// wide layouts (interior tiles): (channels, pairs of the first pass, pairs of the accumulating second pass)
+#define AW_FOR_EACH_WIDE(X) X(10, 4, 1) X(12, 4, 2) X(14, 4, 3) X(16, 4, 4)
 // boundary tiles of the common layouts keep whole-frame vector loads (history / zero-page selects per frame)
 #define AW_FOR_EACH_BVEC(X) X(2, 1) X(4, 2) X(8, 4)
 
@@ -173,6 +176,7 @@ hipError_t prepare_kernels() {
         // the persistent kernels deal tiles to 8 XCD groups (blockIdx % 8): a grid below 8 workgroups with more tiles than
         // workgroups would leave groups without a workgroup and their tiles uncomputed
         if (g_persistent_wgs < 8) g_persistent_wgs = 8;
+        if (const char *e3 = getenv("AW_WIDE_TWO_PASS")) g_wide_two_pass = atoi(e3) != 0;
     }
 #define AW_SET_VEC(CS, NP)                                                                           \
     if (e == hipSuccess)                                                                             \
@@ -187,6 +191,21 @@ hipError_t prepare_kernels() {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<CS, NP, false>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     AW_FOR_EACH_VEC(AW_SET_VEC)
+#define AW_SET_WIDE(CS, NPA, NPB)                                                                              \
+    if (e == hipSuccess)                                                                                       \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<CS, NPA, true, false>),    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);                        \
+    if (e == hipSuccess)                                                                                       \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<CS, NPB, true, true>),     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    AW_FOR_EACH_WIDE(AW_SET_WIDE)
+#undef AW_SET_WIDE
+#define AW_SET_GENACC(NP)                                                                                      \
+    if (e == hipSuccess)                                                                                       \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<0, NP, false, true>),      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    AW_SET_GENACC(1) AW_SET_GENACC(2) AW_SET_GENACC(3) AW_SET_GENACC(4)
+#undef AW_SET_GENACC
     AW_FOR_EACH_GEN(AW_SET_GEN)
     AW_FOR_EACH_BVEC(AW_SET_BVEC)
 #define AW_SET_Q(CS, NP)                                                                                \
@@ -256,6 +275,7 @@ hipError_t prepare_kernels() {
 }
 
 static bool has_vec_variant(int C) { return C == 2 || C == 4 || C == 6 || C == 7 || C == 8 || C == 12 || C == 14 || C == 16; }
+static bool has_fused_vec_variant(int C) { return has_vec_variant(C) || C == 10; }       // 10 channels: two-pass kernels only
 
 const char *fused_ols_kernel_name(int C) {
     switch (C) {
@@ -264,9 +284,10 @@ const char *fused_ols_kernel_name(int C) {
         case 6: return "aw_fused_ols_kernel<6, 3, true>";
         case 7: return "aw_fused_ols_kernel<7, 4, true>";
         case 8: return "aw_fused_ols_kernel<8, 4, true>";
-        case 14: return "aw_fused_ols_kernel<14, 0, true>";
-        case 12: return "aw_fused_ols_kernel<12, 0, true>";
-        case 16: return "aw_fused_ols_kernel<16, 0, true>";
+        case 10: return "aw_fused_ols_kernel<10, 4, true> + <10, 1, true, accumulate>";
+        case 14: return "aw_fused_ols_kernel<14, 4, true> + <14, 3, true, accumulate>";
+        case 12: return "aw_fused_ols_kernel<12, 4, true> + <12, 2, true, accumulate>";
+        case 16: return "aw_fused_ols_kernel<16, 4, true> + <16, 4, true, accumulate>";
         default: return "aw_fused_ols_kernel<0, NP, false>";
     }
 }
@@ -277,6 +298,21 @@ static dim3 persistent_grid(long long n_tiles) {
 
 static void launch_vec(const TileParams &p, long long n_tiles, hipStream_t stream) {
     const dim3 grid = persistent_grid(n_tiles), block(kThreads);
+    if (g_wide_two_pass || p.n_channels == 10) {
+        // second pass: input and tables shifted by the first pass's 4 pairs (8 channels), result added to the output
+        TileParams q = p;
+        q.in = p.in + 8;
+        q.tab = p.tab + 4 * (long long)kN;
+        switch (p.n_channels) {
+#define AW_CASE(CS, NPA, NPB) case CS:                                                                                               \
+            hipLaunchKernelGGL((aw_fused_ols_kernel<CS, NPA, true, false>), grid, block, kLdsBytes, stream, p, n_tiles);           \
+            hipLaunchKernelGGL((aw_fused_ols_kernel<CS, NPB, true, true>), grid, block, kLdsBytes, stream, q, n_tiles);            \
+            return;
+            AW_FOR_EACH_WIDE(AW_CASE)
+#undef AW_CASE
+            default: break;
+        }
+    }
     switch (p.n_channels) {
 #define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_fused_ols_kernel<CS, NP, true>), grid, block, kLdsBytes, stream, p, n_tiles); break;
         AW_FOR_EACH_VEC(AW_CASE)
@@ -292,6 +328,20 @@ static void launch_gen(const TileParams &p, long long n_tiles, hipStream_t strea
         AW_FOR_EACH_BVEC(AW_CASE)
 #undef AW_CASE
         default: break;
+    }
+    if (p.n_pairs > 4 && p.n_pairs <= 8 && g_wide_two_pass) {
+        // 9-16 channels: compile-time 4-pair pass, then an accumulating compile-time pass over the remaining pairs
+        // (input, history and tables shifted by 8 channels; ch_base keeps the padding-channel test right)
+        TileParams q = p;
+        q.in = p.in + 8; q.hist = p.hist + 8; q.tab = p.tab + 4 * (long long)kN; q.ch_base = 8;
+        hipLaunchKernelGGL((aw_fused_ols_kernel<0, 4, false, false>), grid, block, kLdsBytes, stream, p, n_tiles);
+        switch (p.n_pairs - 4) {
+            case 1: hipLaunchKernelGGL((aw_fused_ols_kernel<0, 1, false, true>), grid, block, kLdsBytes, stream, q, n_tiles); break;
+            case 2: hipLaunchKernelGGL((aw_fused_ols_kernel<0, 2, false, true>), grid, block, kLdsBytes, stream, q, n_tiles); break;
+            case 3: hipLaunchKernelGGL((aw_fused_ols_kernel<0, 3, false, true>), grid, block, kLdsBytes, stream, q, n_tiles); break;
+            default: hipLaunchKernelGGL((aw_fused_ols_kernel<0, 4, false, true>), grid, block, kLdsBytes, stream, q, n_tiles); break;
+        }
+        return;
     }
     const int np = p.n_pairs <= 4 ? p.n_pairs : 0;
     switch (np) {
@@ -314,7 +364,7 @@ hipError_t launch_fused_ols(const TileParams &p_in, int n_streams, hipStream_t s
     if (hi > p.tiles_per_stream) hi = p.tiles_per_stream;
     if (hi < lo) hi = lo;
     if (lo > p.tiles_per_stream) { lo = p.tiles_per_stream; hi = lo; }
-    if (!has_vec_variant(p.n_channels)) { lo = 0; hi = 0; }        // everything through the generic kernels
+    if (!has_fused_vec_variant(p.n_channels)) { lo = 0; hi = 0; }  // everything through the generic kernels
     p.tile_lo = (int)lo; p.tile_hi = (int)hi;
     const long long n_int = (long long)n_streams * (hi - lo);
     const long long n_bnd = (long long)n_streams * (p.tiles_per_stream - (hi - lo));

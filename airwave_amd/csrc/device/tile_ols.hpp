@@ -62,6 +62,9 @@ constexpr bool kTabEarly1 = (AW_TAB_EARLY & 2) != 0;   // second pair: issued ri
 #define AW_SKIP_PHANTOM 1
 #endif
 constexpr bool kSkipPhantom = AW_SKIP_PHANTOM != 0;   // run-time batch loop: an odd pair count's last batch transforms one pair, not a phantom second one
+#ifndef AW_EVEN_F2_LOADS
+#define AW_EVEN_F2_LOADS 0
+#endif
 constexpr int kBatchCh = 4;       // input channels held in registers at once (two pairs)
 
 struct alignas(16) cf2 {          // one table entry: A[k], B[k]
@@ -90,6 +93,7 @@ struct TileParams {
     int partitions;         // P = ceil(taps / hop); tables are [partition][pair][N]
     int n_blocks;           // output blocks of `hop` frames per stream in this call
     int first_valid;        // first window position that is stored (N - hop)
+    int ch_base;            // second pass of a wide layout: `in`, `hist` and `tab` are shifted by this many channels (8); 0 otherwise
     int fwd_one_pair;       // forward kernel form: 1 = one channel pair per workgroup (two workgroups per CU), 0 = all pairs in one workgroup
     int herm_last;          // odd channel count: the last pair's input is real, its spectrum Hermitian — rows 9..15 are neither stored nor read
     int stagger;            // tuning: waves 4-7 idle this many 64-cycle slots after each barrier (phase offset)
@@ -229,7 +233,7 @@ AW_HD void load_frame(const TileParams &p, const float *in_s, const float *hist_
 #pragma unroll
         for (int c = 0; c < kBatchCh; ++c) {
             const int ch = c0 + c;
-            const float *q = ch < C ? src + ch : p.zeros;      // padding channels of the last batch read zeros
+            const float *q = ch + p.ch_base < C ? src + ch : p.zeros;      // padding channels of the last batch read zeros
             dst[c] = *q;
         }
     }
@@ -254,6 +258,12 @@ AW_HD void load_batch(const TileParams &p, const float *in_s, const float *hist_
             } else if constexpr (CS == 2) {
                 const f2 v = *reinterpret_cast<const f2 *>(src);
                 raw[j][0] = v.x; raw[j][1] = v.y; raw[j][2] = 0.f; raw[j][3] = 0.f;
+            } else if constexpr (CS % 2 == 0 && AW_EVEN_F2_LOADS) {
+                // 6, 10, 14 channels: frames are multiples of 8 bytes — two naturally aligned 8-byte loads instead of one
+                // dword-aligned 16-byte load (which the memory pipeline splits)
+                const f2 v0 = *reinterpret_cast<const f2 *>(src);
+                const f2 v1 = *reinterpret_cast<const f2 *>(src + 2);
+                raw[j][0] = v0.x; raw[j][1] = v0.y; raw[j][2] = v1.x; raw[j][3] = v1.y;
             } else {
                 // frames that are not whole float4s (6, 7, 14 channels): one dword-aligned 16-B load all the
                 // same.  The last batch of a frame runs up to 3 floats into the next frame; those lanes belong
@@ -372,8 +382,18 @@ AW_HD void tile_inverse_rows(Ctx &ctx, cf (&wacc)[2][8], cf *buf0, const cf *twa
 // frame f0 + m lies inside the call.
 template <class Ctx>
 AW_HD void tile_inverse_final(Ctx &ctx, const TileParams &p, cf *buf0, cf w1, int t, long long stream, long long f0,
-                              int first_valid) {
+                              int first_valid, bool accumulate = false) {
     ctx.stamp(11);
+    cf old[16];
+    if (accumulate) {          // uniform.  The first pass's output of this tile, issued before the barrier: it lands under the final pass
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int m = t + 512 * j;
+            const long long f = f0 + m;
+            old[j] = mk(0.f, 0.f);
+            if (m >= first_valid && f < p.frames) old[j] = *reinterpret_cast<const cf *>(p.out + ((long long)stream * p.frames + f) * 2);
+        }
+    }
     ctx.barrier();
     ctx.stamp(12);
     cf y[16];
@@ -390,8 +410,11 @@ AW_HD void tile_inverse_final(Ctx &ctx, const TileParams &p, cf *buf0, cf w1, in
     for (int j = 0; j < 16; ++j) {
         const int m = t + 512 * j;
         const long long f = f0 + m;
-        if (m >= first_valid && f < p.frames)
-            ctx.st_stream(reinterpret_cast<cf *>(p.out + ((long long)stream * p.frames + f) * 2), y[j]);
+        if (m >= first_valid && f < p.frames) {
+            cf *o = reinterpret_cast<cf *>(p.out + ((long long)stream * p.frames + f) * 2);
+            if (accumulate) y[j] = y[j] + old[j];      // second pass over a wide layout's remaining channels (uniform)
+            ctx.st_stream(o, y[j]);
+        }
     }
     ctx.stamp(13);
     ctx.flush_stamps();
@@ -419,7 +442,10 @@ AW_HD TileId tile_of(const TileParams &p, long long id) {
     return r;
 }
 
-template <class Ctx, int CS, int NP, bool INTERIOR>
+// ACC: the tile ADDS its result to the output (second pass of a wide layout, see launch_fused_ols: layouts of 9-16
+// channels run the compile-time 4-pair kernel on channels 0-7 and a second compile-time pass on the rest, because one
+// kernel over 5-8 pairs — unrolled or as a run-time batch loop — spills 56-87 VGPRs at the 256-register limit).
+template <class Ctx, int CS, int NP, bool INTERIOR, bool ACC = false>
 AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long long step, long long end) {
     const int t0 = ctx.tid();
     int t = t0, lane = ctx.lane();
@@ -512,7 +538,7 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
         load_batch<CS, INTERIOR>(p, p.in + nx.stream * p.frames * Cn, p.hist + nx.stream * (long long)p.hist_len * Cn,
                                  (long long)nx.tile * p.hop - p.hist_len, t, 0, raw);
     }
-    tile_inverse_final(ctx, p, buf0, w1, t, stream, f0, p.hist_len);
+    tile_inverse_final(ctx, p, buf0, w1, t, stream, f0, p.hist_len, ACC);
     ctx.barrier();                                       // the final exchange has been read before buf0 is rewritten
     }
 }

@@ -169,7 +169,7 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
     if (hi < lo) hi = lo;
     if (lo > p.tiles_per_stream) { lo = p.tiles_per_stream; hi = lo; }
     const bool vec = n_channels == 2 || n_channels == 4 || n_channels == 6 || n_channels == 7 || n_channels == 8 ||
-                     n_channels == 12 || n_channels == 14 || n_channels == 16;
+                     n_channels == 10 || n_channels == 12 || n_channels == 14 || n_channels == 16;
     if (!vec || (variant != 1 && variant != 4)) { lo = 0; hi = 0; }
     p.tile_lo = (int)lo; p.tile_hi = (int)hi;
     EmuShared sh;
@@ -221,15 +221,31 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
                     EmuCtx ctx{t, &sh};
                     // mirror of awk::launch_fused_ols' variant choice
                     if (interior) {
+                        // wide layouts: first pass over 4 pairs, then an accumulating pass over the rest (input and tables shifted)
+                        TileParams q = p;
+                        q.in = p.in + 8;
+                        q.tab = p.tab + 4 * (long long)kN;
                         switch (n_channels) {
                             case 2: tiles_fused_ols<EmuCtx, 2, 1, true>(ctx, p, g, G, n_tiles); break;
                             case 4: tiles_fused_ols<EmuCtx, 4, 2, true>(ctx, p, g, G, n_tiles); break;
                             case 6: tiles_fused_ols<EmuCtx, 6, 3, true>(ctx, p, g, G, n_tiles); break;
                             case 7: tiles_fused_ols<EmuCtx, 7, 4, true>(ctx, p, g, G, n_tiles); break;
                             case 8: tiles_fused_ols<EmuCtx, 8, 4, true>(ctx, p, g, G, n_tiles); break;
-                            case 14: tiles_fused_ols<EmuCtx, 14, 0, true>(ctx, p, g, G, n_tiles); break;
-                            case 12: tiles_fused_ols<EmuCtx, 12, 0, true>(ctx, p, g, G, n_tiles); break;
-                            default: tiles_fused_ols<EmuCtx, 16, 0, true>(ctx, p, g, G, n_tiles); break;
+                            case 10: tiles_fused_ols<EmuCtx, 10, 4, true>(ctx, p, g, G, n_tiles); ctx.barrier(); tiles_fused_ols<EmuCtx, 10, 1, true, true>(ctx, q, g, G, n_tiles); break;
+                            case 14: tiles_fused_ols<EmuCtx, 14, 4, true>(ctx, p, g, G, n_tiles); ctx.barrier(); tiles_fused_ols<EmuCtx, 14, 3, true, true>(ctx, q, g, G, n_tiles); break;
+                            case 12: tiles_fused_ols<EmuCtx, 12, 4, true>(ctx, p, g, G, n_tiles); ctx.barrier(); tiles_fused_ols<EmuCtx, 12, 2, true, true>(ctx, q, g, G, n_tiles); break;
+                            default: tiles_fused_ols<EmuCtx, 16, 4, true>(ctx, p, g, G, n_tiles); ctx.barrier(); tiles_fused_ols<EmuCtx, 16, 4, true, true>(ctx, q, g, G, n_tiles); break;
+                        }
+                    } else if (p.n_pairs > 4 && p.n_pairs <= 8 && variant == 1) {      // launch_gen's two passes for 9-16 channels
+                        TileParams q = p;
+                        q.in = p.in + 8; q.hist = p.hist + 8; q.tab = p.tab + 4 * (long long)kN; q.ch_base = 8;
+                        tiles_fused_ols<EmuCtx, 0, 4, false>(ctx, p, g, G, n_tiles);
+                        ctx.barrier();
+                        switch (p.n_pairs - 4) {
+                            case 1: tiles_fused_ols<EmuCtx, 0, 1, false, true>(ctx, q, g, G, n_tiles); break;
+                            case 2: tiles_fused_ols<EmuCtx, 0, 2, false, true>(ctx, q, g, G, n_tiles); break;
+                            case 3: tiles_fused_ols<EmuCtx, 0, 3, false, true>(ctx, q, g, G, n_tiles); break;
+                            default: tiles_fused_ols<EmuCtx, 0, 4, false, true>(ctx, q, g, G, n_tiles); break;
                         }
                     } else {
                         switch (p.n_pairs <= 4 && variant == 1 ? p.n_pairs : 0) {

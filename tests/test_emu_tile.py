@@ -23,10 +23,10 @@ def test_small_butterflies_match_numpy():
         assert np.abs(emu.fft_small(v, True) - iref).max() < 2e-6 * n
 
 
-@pytest.mark.parametrize("channels", [1, 2, 4, 5, 6, 7, 8, 12, 14])
+@pytest.mark.parametrize("channels", [1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
 def test_emulated_tile_matches_truth(oracle, golden_dir, channels):
     wav = oracle.wav_load(os.path.join(golden_dir, "hrtf", "RoomSH1.0.wav"))
-    spk = oracle.layout_detect(8)[:channels] if channels <= 8 else oracle.layout_detect(8) + ["FL", "FR", "BL", "BR", "SL", "SR"][: channels - 8]
+    spk = oracle.layout_detect(8)[:channels] if channels <= 8 else oracle.layout_detect(8) + ["FL", "FR", "BL", "BR", "SL", "SR", "FC", "LFE"][: channels - 8]
     cmap = oracle.map_hesuvi14(oracle.layout_detect(8))
     tracks = wav.audio_data
     lt = np.array([cmap[s][0] for s in spk], dtype=np.int32)

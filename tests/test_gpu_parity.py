@@ -75,10 +75,11 @@ def test_every_channel_count_matches_f32_oracle_and_truth(aw, oracle, golden_dir
         assert oracle.peak_rel_error(y[s], yo[s]) < TOL
 
 
-@pytest.mark.parametrize("channels", [2, 4, 6, 7, 8, 12, 14, 16])
+@pytest.mark.parametrize("channels", [2, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
 def test_interior_kernels_of_every_vector_layout(aw, oracle, golden_dir, channels):
     """Long enough for interior tiles (whole-frame vector loads; 6/7/14-channel frames are not whole float4s and
-    read into the next frame: zero tables must cancel the stray lanes), odd frame count, two calls."""
+    read into the next frame: zero tables must cancel the stray lanes; 10-16 channels run two passes, 4 pairs then the rest
+    accumulated into the output), odd frame count, two calls."""
     w = wav(oracle, golden_dir, "StageSH1.0.wav")
     tracks = np.asarray(w.audio_data)
     lt = (np.arange(channels) % 14).astype(np.int32)

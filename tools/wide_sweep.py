@@ -7,7 +7,7 @@ import airwave_amd as aw
 ctx = aw.Context(0, stream=torch.cuda.current_stream().cuda_stream)
 rng = np.random.default_rng(1)
 out = []
-for C in (9, 10, 11, 13, 14, 15, 16, 12):
+for C in (tuple(int(c) for c in os.environ["CHANNELS"].split(",")) if "CHANNELS" in os.environ else (9, 10, 11, 13, 14, 15, 16, 12)):
     S, F, taps = 128, 192000, 4320
     x = torch.empty((S, F, C), device="cuda"); y = torch.empty((S, F, 2), device="cuda")
     ctx.synth_fill(x.data_ptr(), S, F, C)
