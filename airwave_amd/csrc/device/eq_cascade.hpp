@@ -72,6 +72,8 @@ struct EqParams {
     EqTables t;
     long long frames;         // frames this launch processes per stream
     long long stride_frames;  // distance between streams, in frames
+    int cus;                  // compute units of the context's device (LaunchCfg); 0 = 256
+    int ear_split;            // LaunchCfg::eq_ear_split: -1 automatic, 0 / 1 forced
 };
 
 AW_HD double eq_flush(double v) { return (v < 0 ? -v : v) < 1e-30 ? 0.0 : v; }   // flushSubnormal :95-97

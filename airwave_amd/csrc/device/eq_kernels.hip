@@ -74,12 +74,7 @@ hipError_t launch_eq_cascade(const EqParams &p, int n_streams, hipStream_t strea
     // split the ears over two workgroups while one workgroup per stream leaves CUs idle (measured: 128 streams
     // 2.84 -> 2.25 ms; at 512 streams the unsplit kernel wins, 7.1 vs 9.8 ms: the split reads every line twice
     // and halves each thread's independent FMA chains)
-    static int cus = 0, force = -1;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        if (const char *e = getenv("AW_EQ_EAR_SPLIT")) force = atoi(e);
-    }
+    const int cus = p.cus > 0 ? p.cus : 256, force = p.ear_split;       // from the context (read once at its creation)
     const bool split = force >= 0 ? force != 0 : 2 * n_streams < 3 * cus;
     if (split)
         hipLaunchKernelGGL(aw_eq_cascade_kernel<1>, dim3((unsigned)n_streams * 2), dim3(kEqThreads), kEqLdsBytes, stream, p, p.t.tab, p.t.plane);

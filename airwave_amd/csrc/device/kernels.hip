@@ -41,8 +41,6 @@ __global__ void __launch_bounds__(kThreads) aw_fused_ols_kernel(TileParams p, lo
     tiles_fused_ols<GpuCtx, CS, NP, INTERIOR, ACC>(ctx, p, lo + slot, per_xcd_wg, hi);
 }
 
-static int g_persistent_wgs = 256;      // one resident workgroup per CU (152 KB LDS each)
-static bool g_wide_two_pass = true;     // AW_WIDE_TWO_PASS=0 (read in prepare_kernels): the single run-time-loop kernel for 12/14/16 channels
 
 // Sibling form (tile_olsh.hpp): workgroups 2s and 2s + 1 of an XCD group take the even and the odd bins of the same
 // tiles.  blockIdx = 8 * slot + xcd, so the odd-bin sibling has the higher id and is dispatched after its partner.
@@ -165,18 +163,25 @@ static bool has_vec2_variant(int C) { return C >= 1 && C <= 8; }
 // boundary tiles of the common layouts keep whole-frame vector loads (history / zero-page selects per frame)
 #define AW_FOR_EACH_BVEC(X) X(2, 1) X(4, 2) X(8, 4)
 
-hipError_t prepare_kernels() {
+hipError_t prepare_kernels(LaunchCfg *cfg) {
     hipError_t e = hipSuccess;
-    {
+    if (cfg) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-            g_persistent_wgs = cus;
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
+            cfg->cus = cus;
+            cfg->persistent_wgs = cus;            // one resident workgroup per CU (152 KB LDS each)
+        }
+        int &g_persistent_wgs = cfg->persistent_wgs;
         if (const char *e2 = getenv("AW_PERSISTENT_WGS")) g_persistent_wgs = atoi(e2) > 0 ? atoi(e2) : g_persistent_wgs;
         // the persistent kernels deal tiles to 8 XCD groups (blockIdx % 8): a grid below 8 workgroups with more tiles than
         // workgroups would leave groups without a workgroup and their tiles uncomputed
         if (g_persistent_wgs < 8) g_persistent_wgs = 8;
-        if (const char *e3 = getenv("AW_WIDE_TWO_PASS")) g_wide_two_pass = atoi(e3) != 0;
+        if (const char *e3 = getenv("AW_WIDE_TWO_PASS")) cfg->wide_two_pass = atoi(e3) != 0;
+        if (const char *e4 = getenv("AW_OLSH_WGS_PER_CU")) cfg->olsh_wgs_per_cu = atoi(e4) > 0 ? atoi(e4) : 2;
+        cfg->debug_occupancy = getenv("AW_DEBUG_OCCUPANCY") != nullptr;
+        if (const char *e5 = getenv("AW_STAMP_THREAD")) cfg->stamp_thread = atoi(e5);
+        if (const char *e6 = getenv("AW_EQ_EAR_SPLIT")) cfg->eq_ear_split = atoi(e6);
     }
 #define AW_SET_VEC(CS, NP)                                                                           \
     if (e == hipSuccess)                                                                             \
@@ -292,13 +297,14 @@ const char *fused_ols_kernel_name(int C) {
     }
 }
 
-static dim3 persistent_grid(long long n_tiles) {
-    return dim3((unsigned)(n_tiles < g_persistent_wgs ? n_tiles : g_persistent_wgs));
+static dim3 persistent_grid(long long n_tiles, const TileParams &p) {
+    const long long wgs = p.persistent_wgs >= 8 ? p.persistent_wgs : 256;
+    return dim3((unsigned)(n_tiles < wgs ? n_tiles : wgs));
 }
 
 static void launch_vec(const TileParams &p, long long n_tiles, hipStream_t stream) {
-    const dim3 grid = persistent_grid(n_tiles), block(kThreads);
-    if (g_wide_two_pass || p.n_channels == 10) {
+    const dim3 grid = persistent_grid(n_tiles, p), block(kThreads);
+    if (p.wide_two_pass || p.n_channels == 10) {
         // second pass: input and tables shifted by the first pass's 4 pairs (8 channels), result added to the output
         TileParams q = p;
         q.in = p.in + 8;
@@ -322,14 +328,14 @@ static void launch_vec(const TileParams &p, long long n_tiles, hipStream_t strea
 }
 
 static void launch_gen(const TileParams &p, long long n_tiles, hipStream_t stream) {
-    const dim3 grid = persistent_grid(n_tiles), block(kThreads);
+    const dim3 grid = persistent_grid(n_tiles, p), block(kThreads);
     switch (p.n_channels) {
 #define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_fused_ols_kernel<CS, NP, false>), grid, block, kLdsBytes, stream, p, n_tiles); return;
         AW_FOR_EACH_BVEC(AW_CASE)
 #undef AW_CASE
         default: break;
     }
-    if (p.n_pairs > 4 && p.n_pairs <= 8 && g_wide_two_pass) {
+    if (p.n_pairs > 4 && p.n_pairs <= 8 && p.wide_two_pass) {
         // 9-16 channels: compile-time 4-pair pass, then an accumulating compile-time pass over the remaining pairs
         // (input, history and tables shifted by 8 channels; ch_base keeps the padding-channel test right)
         TileParams q = p;
@@ -395,9 +401,9 @@ __global__ void __launch_bounds__(kThreads, 4) aw_xcc_probe_kernel(int *out) {
     }
 }
 
-hipError_t probe_sibling_placement(hipStream_t stream, bool *ok) {
+hipError_t probe_sibling_placement(hipStream_t stream, int persistent_wgs, bool *ok) {
     *ok = false;
-    const int grid = 2 * g_persistent_wgs / 16 * 16;
+    const int grid = 2 * (persistent_wgs >= 8 ? persistent_wgs : 256) / 16 * 16;
     if (grid < 16) return hipSuccess;
     int *d = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&d), grid * sizeof(int));
@@ -432,7 +438,6 @@ const char *fused_olsh_kernel_name(int C) {
     }
 }
 
-static int g_olsh_wgs_per_cu = 2;
 
 hipError_t launch_fused_olsh(const TileParams &p_in, int n_streams, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
                              long long *dominant_tiles) {
@@ -448,15 +453,14 @@ hipError_t launch_fused_olsh(const TileParams &p_in, int n_streams, hipStream_t 
     const long long n_int = (long long)n_streams * (hi - lo);
     const long long n_bnd = (long long)n_streams * (p.tiles_per_stream - (hi - lo));
     if (n_int > 0x7fffffffLL || n_bnd > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (const char *e = getenv("AW_OLSH_WGS_PER_CU")) g_olsh_wgs_per_cu = atoi(e) > 0 ? atoi(e) : 2;
-    if (getenv("AW_DEBUG_OCCUPANCY")) {
+    if (p.debug_occupancy) {
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&aw_fused_olsq_kernel<8, 4, true>), kThreads, kHLdsBytes);
         hipFuncAttributes fa{};
         (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&aw_fused_olsq_kernel<8, 4, true>));
         fprintf(stderr, "[aw] olsq<8,4,true>: %d workgroups per CU (regs %d, static LDS %zu, scratch %zu)\n", nb, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes);
     }
-    const long long max_wgs = (long long)g_persistent_wgs * g_olsh_wgs_per_cu;
+    const long long max_wgs = (long long)(p.persistent_wgs >= 8 ? p.persistent_wgs : 256) * (p.olsh_wgs_per_cu > 0 ? p.olsh_wgs_per_cu : 2);
     const dim3 block(kThreads);
     const bool dom_int = n_int > 0;
     if (dominant_tiles) *dominant_tiles = dom_int ? n_int : n_bnd;
@@ -522,7 +526,7 @@ hipError_t launch_fused_ols2(const TileParams &p_in, int n_streams, hipStream_t 
     const bool dom_int = n_int > 0;
     if (dominant_tiles) *dominant_tiles = dom_int ? n_int : n_bnd;
     if (n_int > 0) {
-        const dim3 grid = persistent_grid(n_int), block(kThreads);
+        const dim3 grid = persistent_grid(n_int, p), block(kThreads);
         if (ev0) (void)hipEventRecord(ev0, stream);
         switch (p.n_channels) {
 #define AW_CASE(CS, NB) case CS: hipLaunchKernelGGL((aw_fused_ols2_kernel<CS, NB, true>), grid, block, kLdsBytes, stream, p, n_int); break;
@@ -535,7 +539,7 @@ hipError_t launch_fused_ols2(const TileParams &p_in, int n_streams, hipStream_t 
     if (n_bnd > 0) {
         p.dbg = nullptr;                 // diagnostic stamps describe the interior launch only
         if (ev0 && !dom_int) (void)hipEventRecord(ev0, stream);
-        const dim3 grid = persistent_grid(n_bnd), block(kThreads);
+        const dim3 grid = persistent_grid(n_bnd, p), block(kThreads);
         switch (p.n_channels) {      // compile-time channel and batch counts also for the boundary tiles (scalar loads)
 #define AW_CASE(CS, NB) case CS: hipLaunchKernelGGL((aw_fused_ols2_kernel<CS, NB, false>), grid, block, kLdsBytes, stream, p, n_bnd); break;
             AW_FOR_EACH_VEC2(AW_CASE)
@@ -601,7 +605,7 @@ hipError_t launch_part_forward(const TileParams &p_in, int n_streams, hipStream_
     if (n_int > 0) {
         if (tm) tm->begin();
         switch (p.n_channels) {
-#define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_part_forward_kernel<CS, 1>), persistent_grid(n_int), dim3(kThreads), kLdsBytes, stream, p, n_int, (int)head_lo); break;
+#define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_part_forward_kernel<CS, 1>), persistent_grid(n_int, p), dim3(kThreads), kLdsBytes, stream, p, n_int, (int)head_lo); break;
             AW_FOR_EACH_VEC(AW_CASE)
 #undef AW_CASE
             default: break;
@@ -611,7 +615,7 @@ hipError_t launch_part_forward(const TileParams &p_in, int n_streams, hipStream_
     if (n_head > 0) {
         if (tm) tm->begin();
         switch (p.n_channels) {
-#define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_part_forward_kernel<CS, 2>), persistent_grid(n_head), dim3(kThreads), kLdsBytes, stream, p, n_head, (int)head_lo); break;
+#define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_part_forward_kernel<CS, 2>), persistent_grid(n_head, p), dim3(kThreads), kLdsBytes, stream, p, n_head, (int)head_lo); break;
             AW_FOR_EACH_VEC(AW_CASE)
 #undef AW_CASE
             default: break;
@@ -620,7 +624,7 @@ hipError_t launch_part_forward(const TileParams &p_in, int n_streams, hipStream_
     }
     if (n_bnd > 0) {
         if (tm) tm->begin();
-        hipLaunchKernelGGL((aw_part_forward_kernel<0, 0>), persistent_grid(n_bnd), dim3(kThreads), kLdsBytes, stream, p, n_bnd, (int)head_lo);
+        hipLaunchKernelGGL((aw_part_forward_kernel<0, 0>), persistent_grid(n_bnd, p), dim3(kThreads), kLdsBytes, stream, p, n_bnd, (int)head_lo);
         if (tm) tm->end("aw_part_forward_kernel<generic>");
     }
     return hipGetLastError();

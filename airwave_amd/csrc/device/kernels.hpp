@@ -29,7 +29,7 @@ hipError_t launch_fused_olsh(const TileParams &p, int n_streams, hipStream_t str
                              hipEvent_t ev1 = nullptr, long long *dominant_tiles = nullptr);
 const char *fused_olsh_kernel_name(int n_channels);
 // measures whether workgroups b and b + 8 of the sibling kernels' launch shape share an XCD (two probe launches, synchronous)
-hipError_t probe_sibling_placement(hipStream_t stream, bool *ok);
+hipError_t probe_sibling_placement(hipStream_t stream, int persistent_wgs, bool *ok);
 // 16384-frame windows (tile_ols2.hpp); p.hop / p.hist_len in real frames, p.tab = cf4 tables, p.n_pairs = pseudo-pairs.
 hipError_t launch_fused_ols2(const TileParams &p, int n_streams, hipStream_t stream, hipEvent_t ev0 = nullptr,
                              hipEvent_t ev1 = nullptr, long long *dominant_tiles = nullptr);
@@ -54,6 +54,17 @@ hipError_t launch_synth_fill(float *dst, int n_streams, long long per_stream, un
 hipError_t launch_interleave2(const float *left, const float *right, float *dst, int frames, hipStream_t stream);
 hipError_t launch_deinterleave2(const float *src, float *left, float *right, int frames, hipStream_t stream);
 
-hipError_t prepare_kernels();   // sets the dynamic-LDS attribute on every tile kernel (once)
+// Launch configuration of one context: device properties and tuning knobs, read ONCE at aw_context_create (never on a
+// process path, never process-global: contexts on different devices keep their own).
+struct LaunchCfg {
+    int cus = 256;                // compute units of the context's device
+    int persistent_wgs = 256;     // grid of the persistent tile kernels (AW_PERSISTENT_WGS; >= 8: the kernels deal tiles to 8 XCD groups)
+    int wide_two_pass = 1;        // 9-16 channels as two compile-time passes (AW_WIDE_TWO_PASS=0: the run-time-loop kernels)
+    int olsh_wgs_per_cu = 2;      // sibling-workgroup kernels (AW_OLSH_WGS_PER_CU)
+    int debug_occupancy = 0;      // AW_DEBUG_OCCUPANCY
+    int stamp_thread = 0;         // AW_STAMP_THREAD (diagnostic builds)
+    int eq_ear_split = -1;        // AW_EQ_EAR_SPLIT: -1 automatic, 0 / 1 forced
+};
+hipError_t prepare_kernels(LaunchCfg *cfg);   // fills cfg from the current device + environment; sets the dynamic-LDS attribute on every tile kernel
 
 }  // namespace awk

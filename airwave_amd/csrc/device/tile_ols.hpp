@@ -93,6 +93,10 @@ struct TileParams {
     int partitions;         // P = ceil(taps / hop); tables are [partition][pair][N]
     int n_blocks;           // output blocks of `hop` frames per stream in this call
     int first_valid;        // first window position that is stored (N - hop)
+    int persistent_wgs;     // grid of the persistent kernels (LaunchCfg, from the context); 0 = 256
+    int wide_two_pass;      // LaunchCfg::wide_two_pass
+    int olsh_wgs_per_cu;    // LaunchCfg::olsh_wgs_per_cu
+    int debug_occupancy;    // LaunchCfg::debug_occupancy
     int ch_base;            // second pass of a wide layout: `in`, `hist` and `tab` are shifted by this many channels (8); 0 otherwise
     int fwd_one_pair;       // forward kernel form: 1 = one channel pair per workgroup (two workgroups per CU), 0 = all pairs in one workgroup
     int herm_last;          // odd channel count: the last pair's input is real, its spectrum Hermitian — rows 9..15 are neither stored nor read

@@ -104,6 +104,7 @@ aw_status state_process(EqState &s, const float *in, long long in_stride, float 
     }
     awk::EqParams p{};
     p.z = s.d_z; p.t = s.t; p.stride_frames = out_stride;
+    p.cus = s.ctx->cfg.cus; p.ear_split = s.ctx->cfg.eq_ear_split;
     const long long body = frames - frames % awk::kEqChunk;
     if (body > 0) {
         p.in = in; p.out = out; p.frames = body;
@@ -265,8 +266,12 @@ aw_status aw_eq_create(aw_context *ctx, double sample_rate, int32_t n_streams, i
     eq->active = eq->unity;
     eq->transition_length = std::max<long long>(1, (long long)std::round(sample_rate * 0.020));   // :155 (.rounded(): half away from zero)
     const size_t n = (size_t)n_streams * eq->transition_length * 2;
-    AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&eq->d_old), n * sizeof(float)));
-    AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&eq->d_new), n * sizeof(float)));
+    hipError_t he = hipMalloc(reinterpret_cast<void **>(&eq->d_old), n * sizeof(float));
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&eq->d_new), n * sizeof(float));
+    if (he != hipSuccess) {                      // a failed second allocation must not leak the first: destroy frees whatever exists
+        aw_eq_destroy(eq.release());
+        return awr::hip_fail(he, "crossfade scratch");
+    }
     *out = eq.release();
     return AW_OK;
 }

@@ -85,7 +85,7 @@ static aw_status context_create_impl(int32_t device, void *ext_stream, bool use_
     }
     hipError_t e = hipEventCreate(&c->t0);
     if (e == hipSuccess) e = hipEventCreate(&c->t1);
-    if (e == hipSuccess) e = awk::prepare_kernels();
+    if (e == hipSuccess) e = awk::prepare_kernels(&c->cfg);
     awh::Twiddles tw;
     awh::build_twiddles(tw);
     auto upload = [&](const std::vector<awk::cf> &v, awk::cf **d) -> hipError_t {
@@ -278,7 +278,7 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
         if (const char *e = getenv("AW_KERNEL_H")) sp->fusedh = atoi(e) == 2 ? 2 : 0;     // experimental sibling-workgroup kernels (tile_olsh.hpp)
         if (sp->fusedh) {           // ... only where the dispatcher is measured to co-locate siblings (their flag protocol needs one L2)
             bool ok = false;
-            if (awk::probe_sibling_placement(ctx->stream, &ok) != hipSuccess || !ok) sp->fusedh = 0;
+            if (awk::probe_sibling_placement(ctx->stream, ctx->cfg.persistent_wgs, &ok) != hipSuccess || !ok) sp->fusedh = 0;
         }
         sp->hop = align_hop(N - (hrir->taps - 1));
         sp->hist_len = N - sp->hop;
@@ -358,6 +358,7 @@ int64_t aw_spatializer_info(const aw_spatializer *sp, int32_t what) {
         case 3: return sp->path;
         case 4: return sp->hist_len;
         case 5: return sp->dominant_frames;   // output frames covered by the launch aw_spatializer_kernel_time() times (last call)
+        case 6: return (int64_t)(sp->spec_capacity * sizeof(awk::cf) + (sp->stage_in_cap + sp->stage_out_cap) * sizeof(float));   // grow-only device buffers, bytes
         default: return -1;
     }
 }
@@ -462,6 +463,12 @@ aw_status aw_spatializer_debug_stamps(aw_spatializer *sp, uint64_t *host_out, in
 #endif
 }
 
+static void sp_fill_cfg(const aw_spatializer *sp, awk::TileParams &p) {
+    const awk::LaunchCfg &c = sp->ctx->cfg;
+    p.persistent_wgs = c.persistent_wgs; p.wide_two_pass = c.wide_two_pass; p.olsh_wgs_per_cu = c.olsh_wgs_per_cu;
+    p.debug_occupancy = c.debug_occupancy;
+}
+
 static aw_status sp_process_fused(aw_spatializer *sp, const float *in, float *out, int64_t frames) {
     awk::TileParams p{};
     p.in = in; p.out = out; p.hist = sp->d_hist[sp->hist_cur];
@@ -470,10 +477,8 @@ static aw_status sp_process_fused(aw_spatializer *sp, const float *in, float *ou
     p.hop = sp->hop; p.hist_len = sp->hist_len;
     p.tiles_per_stream = (int)((frames + sp->hop - 1) / sp->hop);
     p.dbg = nullptr;
-    {
-        const char *e = getenv("AW_STAMP_THREAD");      // tuning knob, default from the measured sweep
-        p.stagger = e ? atoi(e) : 0;
-    }
+    p.stagger = sp->ctx->cfg.stamp_thread;
+    sp_fill_cfg(sp, p);
 #if defined(AW_STAMPS) && AW_STAMPS
     {
         const long long nwg = (long long)sp->n_streams * p.tiles_per_stream;
@@ -584,6 +589,7 @@ static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, flo
         p.spec = sp->d_spec; p.wspec = sp->d_spec + pl.per_stream * (size_t)chunk;
         p.partitions = P; p.n_blocks = n_blocks; p.first_valid = N - B;
         p.stagger = 0; p.dbg = nullptr;
+        sp_fill_cfg(sp, p);
         p.fwd_one_pair = sp->fwd_one_pair ? 1 : 0;
         p.herm_last = (!sp->cmac_group && sp->herm_ok && (sp->n_channels & 1)) ? 1 : 0;
         // the timed unit of this path is the whole three-kernel pipeline of one stream chunk
@@ -607,6 +613,8 @@ static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, flo
     return AW_OK;
 }
 
+static aw_status sp_grow(float **buf, size_t *cap, size_t need);
+
 // Sizes every grow-only device buffer for calls of up to max_frames frames, so that the process entries never
 // allocate afterwards ("process must not allocate"; creation may block).
 aw_status aw_spatializer_reserve(aw_spatializer *sp, int64_t max_frames) {
@@ -616,6 +624,12 @@ aw_status aw_spatializer_reserve(aw_spatializer *sp, int64_t max_frames) {
     if (sp->path == 1) {
         const PartPlan pl = part_plan(sp, max_frames, part_budget(sp));
         aw_status st = part_ensure_scratch(sp, pl.need);
+        if (st != AW_OK) return st;
+    }
+    if (sp->n_streams == 1) {       // plug-in shaped use (host / planar entries): their staging buffers too
+        const size_t n = (size_t)max_frames * std::max(sp->n_channels, 4);
+        aw_status st = sp_grow(&sp->d_stage_in, &sp->stage_in_cap, n);
+        if (st == AW_OK) st = sp_grow(&sp->d_stage_out, &sp->stage_out_cap, (size_t)max_frames * 4);
         if (st != AW_OK) return st;
     }
     sp->reserved_frames = std::max<int64_t>(sp->reserved_frames, max_frames);

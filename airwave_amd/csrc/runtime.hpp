@@ -30,6 +30,7 @@ struct aw_context {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     awk::cf *d_tw1 = nullptr, *d_twa = nullptr, *d_twb = nullptr;   // twiddle rows (FFTSetupManager analogue)
     float *d_zeros = nullptr;                                       // page of zeros (frames past the end of a call)
+    awk::LaunchCfg cfg;                                             // device properties + tuning knobs, read once at creation
 };
 
 struct aw_hrir {

@@ -1,0 +1,93 @@
+""""creation may block, process must not allocate" — and no environment lookups on a process path.
+Source-level part (CPU): the bodies of the process entries contain no getenv.  GPU part: after reserve(), process calls of
+up to that size leave the device's free memory unchanged (no hipMalloc / hipFree), on the partitioned and the fused path."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _body(src: str, name: str) -> str:
+    m = re.search(r"^[\w\s\*]*\b" + re.escape(name) + r"\(", src, re.M)
+    assert m, name
+    j = src.index("{", m.end())
+    depth, k = 0, j
+    while True:
+        depth += {"{": 1, "}": -1}.get(src[k], 0)
+        if depth == 0:
+            return src[j:k + 1]
+        k += 1
+
+
+def test_no_environment_lookups_on_process_paths():
+    rt = open(os.path.join(ROOT, "airwave_amd", "csrc", "runtime.cpp")).read()
+    for fn in ("sp_process_fused", "sp_process_partitioned", "aw_spatializer_process", "aw_spatializer_process_host",
+               "aw_spatializer_process_planar", "aw_realtime_process", "aw_engine_process", "part_plan", "part_ensure_scratch"):
+        assert "getenv" not in _body(rt, fn), fn
+    eq = open(os.path.join(ROOT, "airwave_amd", "csrc", "eq_runtime.cpp")).read()
+    assert "getenv" not in eq
+    for f in ("kernels.hip", "march_kernels.hip", "eq_kernels.hip"):
+        src = open(os.path.join(ROOT, "airwave_amd", "csrc", "device", f)).read()
+        for m in re.finditer(r"getenv", src):       # only inside prepare_kernels (context creation)
+            start = src.rfind("\nhipError_t ", 0, m.start())
+            assert src[start:start + 60].lstrip().startswith("hipError_t prepare_kernels("), (f, src[start:start + 60])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("taps,channels", [(20000, 7), (40000, 14), (4320, 8)])
+def test_process_does_not_allocate_after_reserve(oracle, taps, channels):
+    """reserve(max_frames) sizes every grow-only internal buffer; afterwards calls of any size up to it leave them alone
+    (info()["scratch_bytes"] constant) and, once the HIP runtime has loaded each kernel, the device's free memory too."""
+    import torch
+    import airwave_amd as aw
+    ctx = aw.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    h = oracle.synth_hrir(14, taps, seed=7)
+    lt = (np.arange(channels) % 14).astype(np.int32)
+    rt = ((np.arange(channels) + 7) % 14).astype(np.int32)
+    S, F = 3, 50000
+    x = torch.empty((S, F, channels), dtype=torch.float32, device="cuda")
+    ctx.synth_fill(x.data_ptr(), S, F, channels)
+    y = torch.empty((S, F, 2), dtype=torch.float32, device="cuda")
+    sizes = (1000, F, 4097, F)
+    sp = aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=S, ctx=ctx)
+    partitioned = sp.info()["path"] == 1
+    sp.reserve(F)
+    cap0 = sp.info()["scratch_bytes"]
+    assert (cap0 > 0) == partitioned
+    for n in sizes:
+        sp.process_device(x.data_ptr(), y.data_ptr(), n)
+        assert sp.info()["scratch_bytes"] == cap0, n
+    torch.cuda.synchronize()
+    flat = x.view(-1, channels)                     # a call of n frames reads streams packed with stride n: stream 1 = rows [n, 2n)
+    ref = oracle.spatialize_f64(np.concatenate([flat[n:2 * n].cpu().numpy() for n in sizes]), h, lt, rt)
+    assert oracle.peak_rel_error(y[1].cpu().numpy(), ref[-F:]) < 1e-5          # and the calls still continue one stream exactly
+    # second round, every kernel already loaded by the runtime: the device's free memory does not move at all
+    free0 = torch.cuda.mem_get_info()[0]
+    for n in sizes:
+        sp.process_device(x.data_ptr(), y.data_ptr(), n)
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free0, n
+    if partitioned:          # without reserve the same buffers grow with the calls (what reserve() is for)
+        sp2 = aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=S, ctx=ctx)
+        sp2.process_device(x.data_ptr(), y.data_ptr(), 1000)
+        small = sp2.info()["scratch_bytes"]
+        sp2.process_device(x.data_ptr(), y.data_ptr(), F)
+        assert small < sp2.info()["scratch_bytes"] <= cap0
+
+
+@pytest.mark.gpu
+def test_mixed_rate_batch_uses_the_reference_map_chooser(oracle):
+    """HRIRManager.swift:355-360: 7 tracks -> hesuvi7, anything else -> hesuvi14 (an 8-track HRIR then fails the bounds
+    check of the 14-channel map instead of silently taking the 7-channel one)."""
+    import airwave_amd as aw
+    layout = aw.InputLayout.detect(8)
+    h8 = oracle.synth_hrir(8, 300, seed=1)
+    with pytest.raises(Exception) as ei:
+        aw.MixedRateBatch(h8, 48000.0, layout, [48000.0])
+    assert "out of range" in str(ei.value) or "Invalid channel mapping" in str(ei.value)
+    h7 = oracle.synth_hrir(7, 300, seed=1)
+    b = aw.MixedRateBatch(h7, 48000.0, aw.InputLayout.detect(2), [48000.0])
+    assert list(b.left_track) == [0, 1] and list(b.right_track) == [1, 0]          # hesuvi7: FL(0,1) FR(1,0)
