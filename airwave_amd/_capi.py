@@ -85,6 +85,8 @@ SIGNATURES = {
     "aw_map_resolve": (_I32, [_V, _V, _I32, c_int32_p, c_int32_p]),
     "aw_resample_output_count": (_I32, [_I32, _D, _D]),
     "aw_resample": (_I32, [c_float_p, _I32, _D, _D, c_float_p, _I32, c_int32_p]),
+    "aw_resample_vgenp": (_I32, [c_float_p, _I32, _D, _D, c_float_p, _I32, c_int32_p]),
+    "aw_context_set_resampler": (_I32, [_V, _I32]),
     "aw_preset_activate": (_I32, [_V, _S, _D, _V, _V, _I32, c_void_pp, c_void_pp]),
     "aw_synth_fill": (_I32, [_V, _V, _I32, _I64, _I32, _U64, _U64]),
     # parametric EQ row

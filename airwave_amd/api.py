@@ -84,6 +84,11 @@ class Context:
     def __del__(self):
         self.close()
 
+    def set_resampler(self, literal_vgenp: bool = False) -> None:
+        """Which resampler activatePreset uses for this context: the intended interpolation (default) or the literal
+        vDSP_vgenp call of the shipped reference."""
+        _check(self._lib.aw_context_set_resampler(self._h, int(literal_vgenp)))
+
     def synchronize(self):
         _check(self._lib.aw_context_synchronize(self._h))
 
@@ -260,13 +265,16 @@ class Resampler:
     """Resampler (Resampler.swift:12-69)."""
 
     @staticmethod
-    def resampleHighQuality(input, fromRate: float, toRate: float) -> np.ndarray:
+    def resampleHighQuality(input, fromRate: float, toRate: float, literal_vgenp: bool = False) -> np.ndarray:
+        """The intended interpolation out[i] = lerp(input, i * fromRate / toRate) by default; literal_vgenp=True is the
+        call the reference actually makes (vDSP_vramp + vDSP_vgenp, Resampler.swift:56-65) as Apple documents vgenp."""
         lib = _capi.load()
         x = _f32(input)
         n = max(lib.aw_resample_output_count(x.size, fromRate, toRate), 0)
         out = np.zeros(max(n, 1), dtype=np.float32)
         cnt = ctypes.c_int32()
-        _check(lib.aw_resample(_fp(x), x.size, fromRate, toRate, _fp(out), out.size, ctypes.byref(cnt)))
+        fn = lib.aw_resample_vgenp if literal_vgenp else lib.aw_resample
+        _check(fn(_fp(x), x.size, fromRate, toRate, _fp(out), out.size, ctypes.byref(cnt)))
         return out[: cnt.value]
 
     resample = resampleHighQuality

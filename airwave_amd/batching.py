@@ -29,18 +29,18 @@ def bucket_by_rate(stream_rates: Sequence[float]) -> Dict[float, List[int]]:
     return buckets
 
 
-def resample_tracks(tracks: np.ndarray, from_rate: float, to_rate: float) -> np.ndarray:
+def resample_tracks(tracks: np.ndarray, from_rate: float, to_rate: float, literal_vgenp: bool = False) -> np.ndarray:
     """Every HRIR track through Resampler.resampleHighQuality (identity when the rates agree, :33-35)."""
     if from_rate == to_rate:
         return np.ascontiguousarray(tracks, dtype=np.float32)
-    return np.stack([Resampler.resampleHighQuality(t, from_rate, to_rate) for t in tracks])
+    return np.stack([Resampler.resampleHighQuality(t, from_rate, to_rate, literal_vgenp=literal_vgenp) for t in tracks])
 
 
 class MixedRateBatch:
     """One preset, streams at several sample rates: `buckets[rate].spatializer` convolves that rate's streams."""
 
     def __init__(self, tracks, hrir_rate: float, layout: InputLayout, stream_rates: Sequence[float],
-                 hrirMap: Optional[HRIRChannelMap] = None, ctx: Optional[Context] = None):
+                 hrirMap: Optional[HRIRChannelMap] = None, ctx: Optional[Context] = None, literal_vgenp: bool = False):
         self.ctx = ctx or default_context()
         tracks = np.ascontiguousarray(tracks, dtype=np.float32)
         # the reference's chooser: 7-track files take the 7-channel map, everything else the 14-channel one
@@ -50,7 +50,7 @@ class MixedRateBatch:
         self.left_track, self.right_track = lt, rt
         self.buckets: Dict[float, RateBucket] = {}
         for rate, ids in bucket_by_rate(stream_rates).items():
-            tr = resample_tracks(tracks, hrir_rate, rate)
+            tr = resample_tracks(tracks, hrir_rate, rate, literal_vgenp=literal_vgenp)     # literal_vgenp: what the shipped reference computes
             sp = Spatializer(HRIR(tr, rate, ctx=self.ctx), lt, rt, n_streams=len(ids), ctx=self.ctx)
             self.buckets[rate] = RateBucket(rate, ids, int(tr.shape[1]), sp)
 

@@ -355,6 +355,32 @@ aw_status aw_resample(const float *input, int32_t count, double from_rate, doubl
     return AW_OK;
 }
 
+// vDSP_vgenp as documented, on the control ramp of Resampler.swift:53-56 (float32, C[m] = m * step).  The ramp the
+// reference allocates has only outputCount entries while vgenp is told M = input.count knots; every evaluation point
+// n < outputCount is bracketed by knots below outputCount when stride > 1, so the entries past the array are never needed.
+aw_status aw_resample_vgenp(const float *input, int32_t count, double from_rate, double to_rate, float *output,
+                            int32_t capacity, int32_t *output_count) {
+    if (!input || !output || !output_count || count < 0) return fail(AW_ERR_INVALID_ARGUMENT, "bad argument");
+    const int n_out = aw_resample_output_count(count, from_rate, to_rate);
+    *output_count = n_out > 0 ? n_out : 0;
+    if (n_out <= 0) return AW_OK;
+    if (capacity < n_out) return fail(AW_ERR_INVALID_ARGUMENT, "output capacity too small");
+    if (std::fabs(from_rate - to_rate) < 0.01) { std::memcpy(output, input, sizeof(float) * (size_t)count); return AW_OK; }
+    const float step = (float)(from_rate / to_rate);
+    auto knot = [&](long long m) { return (float)m * step; };          // B[m]
+    const long long M = count;
+    long long m = 0;                                                    // invariant: B[m] < n (for n >= 1)
+    for (int n = 0; n < n_out; ++n) {
+        const float x = (float)n;
+        if (x <= knot(0)) { output[n] = input[0]; continue; }
+        if (x > knot(M - 1)) { output[n] = input[M - 1]; continue; }
+        while (m + 1 < M - 1 && knot(m + 1) < x) ++m;                   // B[m] < n <= B[m+1]
+        const float b0 = knot(m), b1 = knot(m + 1);
+        output[n] = input[m] + (input[m + 1] - input[m]) * ((x - b0) / (b1 - b0));
+    }
+    return AW_OK;
+}
+
 /* ---- HRIRManager.activatePreset (HRIRManager.swift:347-446) ------------------------------------------ */
 aw_status aw_preset_activate(aw_context *ctx, const char *wav_path, double target_rate, const aw_layout *layout,
                              const aw_channel_map *custom_map, int32_t n_streams, aw_spatializer **sp_out,
@@ -386,8 +412,8 @@ aw_status aw_preset_activate(aw_context *ctx, const char *wav_path, double targe
         tracks.resize((size_t)wav->channels * taps);
         for (int c = 0; c < wav->channels; ++c) {
             int n = 0;
-            st = aw_resample(aw_wav_channel(wav, c), wav->frames, wav->sample_rate, target_rate,
-                             tracks.data() + (size_t)c * taps, taps, &n);
+            st = (awr::context_literal_resampler(ctx) ? aw_resample_vgenp : aw_resample)(aw_wav_channel(wav, c), wav->frames, wav->sample_rate, target_rate,
+                                                                                            tracks.data() + (size_t)c * taps, taps, &n);
             if (st != AW_OK) { aw_wav_destroy(wav); return st; }
         }
     } else {

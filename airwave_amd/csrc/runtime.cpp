@@ -30,6 +30,8 @@ aw_status hip_fail(hipError_t e, const char *what) {
     return e == hipErrorOutOfMemory ? AW_ERR_OUT_OF_MEMORY : AW_ERR_HIP;
 }
 
+bool context_literal_resampler(const aw_context *ctx) { return ctx && ctx->literal_resampler; }
+
 }  // namespace awr
 
 using awr::fail;
@@ -127,6 +129,12 @@ void aw_context_destroy(aw_context *c) {
 aw_status aw_context_synchronize(aw_context *c) {
     if (!c) return fail(AW_ERR_INVALID_ARGUMENT, "ctx is NULL");
     AW_HIP_TRY(hipStreamSynchronize(c->stream));
+    return AW_OK;
+}
+
+aw_status aw_context_set_resampler(aw_context *c, int32_t literal_vgenp) {
+    if (!c) return fail(AW_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    c->literal_resampler = literal_vgenp != 0;
     return AW_OK;
 }
 

@@ -14,6 +14,7 @@ namespace awr {
 void set_error(const std::string &msg);
 aw_status fail(aw_status code, const std::string &msg);
 aw_status hip_fail(hipError_t e, const char *what);
+bool context_literal_resampler(const aw_context *ctx);
 
 #define AW_HIP_TRY(expr)                                          \
     do {                                                          \
@@ -30,6 +31,7 @@ struct aw_context {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     awk::cf *d_tw1 = nullptr, *d_twa = nullptr, *d_twb = nullptr;   // twiddle rows (FFTSetupManager analogue)
     float *d_zeros = nullptr;                                       // page of zeros (frames past the end of a call)
+    bool literal_resampler = false;                                 // aw_context_set_resampler: aw_preset_activate resamples HRIRs with the literal vgenp call
     awk::LaunchCfg cfg;                                             // device properties + tuning knobs, read once at creation
 };
 

@@ -207,6 +207,16 @@ AW_API aw_status aw_map_resolve(const aw_channel_map *m, const aw_layout *layout
 AW_API int32_t aw_resample_output_count(int32_t count, double from_rate, double to_rate);
 AW_API aw_status aw_resample(const float *input, int32_t count, double from_rate, double to_rate, float *output,
                              int32_t output_capacity, int32_t *output_count);
+/* The LITERAL call the reference makes (Resampler.swift:56-65): vDSP_vramp(0, stride) into a control vector, then
+ * vDSP_vgenp(A = input, B = control, C = output, N = outputCount, M = input.count), as Apple documents vgenp: the knots
+ * (B[m], A[m]) define a piecewise-linear function that is evaluated at the INTEGERS n = 0..N-1 (C[n] = A[0] for n <= B[0],
+ * A[M-1] past the last knot).  With B[m] = m * stride that is lerp(input, n / stride) — the inverse of the intended ratio:
+ * 48 -> 96 kHz yields input[2n] then holds the last sample, 48 -> 44.1 kHz stretches the response instead of compressing it.
+ * Same output length as aw_resample.  Optional; nothing selects it unless asked (aw_context_set_resampler). */
+AW_API aw_status aw_resample_vgenp(const float *input, int32_t count, double from_rate, double to_rate, float *output,
+                                   int32_t output_capacity, int32_t *output_count);
+/* Which of the two aw_preset_activate uses when it resamples an HRIR: 0 = intended interpolation (default), 1 = literal vgenp. */
+AW_API aw_status aw_context_set_resampler(aw_context *ctx, int32_t literal_vgenp);
 
 /* HRIRManager.activatePreset body (HRIRManager.swift:347-446): load WAV -> choose map (7 tracks:
  * hesuvi7, else hesuvi14; or `custom_map`) -> resolve -> resample HRIR to target rate when it

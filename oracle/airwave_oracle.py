@@ -446,6 +446,38 @@ def resample_intended(x, from_rate: float, to_rate: float) -> np.ndarray:
     return (x[i0c] + frac * (x[i1c] - x[i0c])).astype(np.float32)
 
 
+def resample_vgenp_literal(x, from_rate: float, to_rate: float) -> np.ndarray:
+    """The call Resampler.swift:56-65 literally makes: control = vDSP_vramp(0, Float(stride)) (outputCount entries), then
+    vDSP_vgenp(A=input, B=control, C=output, N=outputCount, M=input.count).  vgenp as Apple documents it: the knots
+    (B[m], A[m]) define a piecewise-linear function evaluated at the integers n = 0..N-1; C[n] = A[0] for n <= B[0] and
+    A[M-1] for n > B[M-1].  Written as the knot search, not as a closed form.  (For stride > 1 the evaluation points never
+    need a knot index >= outputCount, so the entries vgenp would read past the control array do not matter.)
+    Unpinned by the reference's tests and by Apple's closed implementation; kept to show what the shipped code computes."""
+    x = _f32(x)
+    if abs(from_rate - to_rate) < 0.01:
+        return x.copy()
+    n_out = resample_output_count(x.size, from_rate, to_rate)
+    if n_out <= 0:
+        return np.zeros(0, dtype=np.float32)
+    step = np.float32(from_rate / to_rate)
+    M = x.size
+    knots = (np.arange(M, dtype=np.float32) * step).astype(np.float32)          # B[m] (the reference allocates only n_out of them)
+    out = np.empty(n_out, dtype=np.float32)
+    m = 0
+    for n in range(n_out):
+        xn = np.float32(n)
+        if xn <= knots[0]:
+            out[n] = x[0]
+        elif xn > knots[M - 1]:
+            out[n] = x[M - 1]
+        else:
+            while m + 1 < M - 1 and knots[m + 1] < xn:
+                m += 1
+            b0, b1 = knots[m], knots[m + 1]
+            out[n] = np.float32(x[m] + (x[m + 1] - x[m]) * np.float32((xn - b0) / (b1 - b0)))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # Renderer assembly (HRIRManager.activatePreset, Airwave/HRIRManager.swift:347-446)
 # ------------------------------------------------------------------------------------------------

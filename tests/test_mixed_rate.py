@@ -47,3 +47,42 @@ def test_mixed_rate_batch_matches_truth_per_bucket(oracle, golden_dir):
     batch.reset()
     again = batch.process(xs, rates)
     assert all(np.array_equal(a, b) for a, b in zip(again, ys))
+
+
+@pytest.mark.parametrize("to_rate", [44100.0, 96000.0, 88200.0, 32000.0])
+def test_literal_vgenp_resampler_matches_oracle_and_differs_from_intended(oracle, golden_dir, to_rate):
+    """SURVEY 8f-2's optional variant: the call the reference literally makes (vDSP_vramp + vDSP_vgenp as documented).
+    Product == oracle restatement; and it is NOT the intended interpolation: it evaluates at n / stride instead of n * stride."""
+    w = oracle.wav_load(os.path.join(golden_dir, "hrtf", "StageSH1.0.wav"))
+    x = np.asarray(w.audio_data)[3]
+    lit = aw.Resampler.resampleHighQuality(x, 48000.0, to_rate, literal_vgenp=True)
+    exp = oracle.resample_vgenp_literal(x, 48000.0, to_rate)
+    intended = aw.Resampler.resampleHighQuality(x, 48000.0, to_rate)
+    assert lit.shape == exp.shape == intended.shape
+    assert np.max(np.abs(lit - exp)) <= 1e-7 * np.max(np.abs(x))
+    assert np.max(np.abs(lit - intended)) > 0.05 * np.max(np.abs(x))           # the two are different filters
+    stride = 48000.0 / to_rate
+    if to_rate == 96000.0:
+        # up by 2: every second INPUT sample, then the last sample held (a 2x time-COMPRESSED response with a flat tail)
+        assert np.max(np.abs(lit[:x.size // 2] - x[0:2 * (x.size // 2):2])) <= 1e-7 * np.max(np.abs(x))     # a + (b - a) * 1 rounds
+        assert np.all(lit[(x.size + 1) // 2:] == x[-1])
+    else:
+        # in general: lerp(input, n / stride) (intended: n * stride)
+        pos = np.arange(lit.size) / stride
+        ok = pos <= x.size - 1
+        ref = np.interp(pos[ok], np.arange(x.size), x.astype(np.float64))
+        assert np.max(np.abs(lit[ok] - ref)) <= 2e-4 * np.max(np.abs(x))
+
+
+@pytest.mark.gpu
+def test_preset_activation_with_the_literal_resampler(oracle, golden_dir):
+    """aw_context_set_resampler(ctx, 1): activatePreset at 96 kHz builds the renderer network on the literally resampled HRIR."""
+    ctx = aw.Context(0)
+    ctx.set_resampler(literal_vgenp=True)
+    layout = aw.InputLayout(["FL", "FR", "FC", "BL", "BR", "SL", "SR"], "7 speakers")
+    sp = aw.HRIRManager(ctx=ctx).activatePreset(os.path.join(golden_dir, "hrtf", "StageSH1.0.wav"), 96000.0, layout)
+    w = oracle.wav_load(os.path.join(golden_dir, "hrtf", "StageSH1.0.wav"))
+    tracks = np.stack([oracle.resample_vgenp_literal(t, 48000.0, 96000.0) for t in np.asarray(w.audio_data)])
+    _, lt, rt = oracle.assemble_tracks(w, ["FL", "FR", "FC", "BL", "BR", "SL", "SR"])
+    x = oracle.synth_input(1, 12000, 7, seed=3)
+    assert oracle.peak_rel_error(sp.process(x)[0], oracle.spatialize_f64(x[0], tracks, lt, rt)) < 1e-5
