@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(kMarchThreads, AW_MARCH_MIN_WAVES) aw_part_mar
     // has one unpredicated store and no branch.  Accumulating passes keep one loader/storer per bin.
     const bool odd = (pl & 1) != 0;
     const int woff = (LG > 1 && odd) ? march_bins(j).pi : march_bins(j).i;
-    march_thread<PQ>(p, s0, s1, j, pl, q0, [&](long long stream, int b, const MarchBins &mb, cf ai, cf ap) {
+    march_thread<PQ, (LG < 8)>(p, s0, s1, j, pl, q0, [&](long long stream, int b, const MarchBins &mb, cf ai, cf ap) {
         ai.x = lane_group_sum<LG>(ai.x); ai.y = lane_group_sum<LG>(ai.y);
         ap.x = lane_group_sum<LG>(ap.x); ap.y = lane_group_sum<LG>(ap.y);
         cf *w = p.wspec + (stream * p.n_blocks + b) * (long long)kN;

@@ -81,7 +81,9 @@ template <int PQ> struct MarchState {
 #ifndef AW_MARCH_NT
 #define AW_MARCH_NT 1
 #endif
+template <bool NT>
 AW_HD cf march_ld(const cf *p) {
+    if constexpr (!NT) return *p;
 #if defined(__HIP_DEVICE_COMPILE__) && AW_MARCH_NT
     typedef float v2f __attribute__((ext_vector_type(2)));
     const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p));
@@ -96,7 +98,10 @@ AW_HD cf march_ld(const cf *p) {
 // The thread walks streams [stream0, stream1) one after the other with the same tables.
 // p.herm_last: the last channel pair has a real input only (odd channel count), so its spectrum is Hermitian and the
 // forward kernel stored rows 0..8 only: slots whose partner bin lies in rows 9..15 take conj(Z[i]) instead of a load.
-template <int PQ, class Emit>
+// NT: non-temporal spectrum loads.  Right when a wave consumes whole 128-byte lines (lane groups of up to 4: 16 slots x 8 B
+// per plane); with lane groups of 8 a wave takes HALF of each line and its sibling wave the other half — then the line must
+// stay cached for the sibling (measured with NT on the 14-channel reading of cfg 3: 108 GB read for 55 GB of spectra).
+template <int PQ, bool NT = true, class Emit>
 AW_HD void march_thread(const TileParams &p, long long stream0, long long stream1, int j, int pl, int q0, Emit &&emit) {
     constexpr int D = AW_MARCH_DEPTH < PQ ? AW_MARCH_DEPTH : PQ;
     static_assert(PQ % D == 0, "the prefetch ring is indexed by step mod D inside a loop unrolled by PQ");
@@ -133,8 +138,8 @@ AW_HD void march_thread(const TileParams &p, long long stream0, long long stream
             u = 0;
 #endif
             const cf *w = spec_s + (long long)u * wstride;
-            z = march_ld(w + mb.i);
-            zp = march_ld(w + ipart);
+            z = march_ld<NT>(w + mb.i);
+            zp = march_ld<NT>(w + ipart);
         };
         auto push = [&](int slot, cf z, cf zp) {
             s.fz[slot] = z;

@@ -300,7 +300,11 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
         sp->cmac_group = sp->n_pairs > 8;                               // the marched kernel's lane groups hold up to 8 channel pairs
         if (const char *e = getenv("AW_PART_CMAC")) sp->cmac_group = sp->cmac_group || std::strcmp(e, "group") == 0;
         if (const char *e = getenv("AW_SPEC_SCRATCH_MB")) sp->scratch_budget = (size_t)atoll(e) << 20;
-        if (const char *e = getenv("AW_PART_FWD")) sp->fwd_one_pair = atoi(e) == 1;      // A/B: 1 = one channel pair per workgroup (two workgroups per CU)
+        // forward kernel form: all pairs of a window in one workgroup up to 4 pairs (cfg 3: 11.2 against 12.1 ms); with more pairs
+        // the four-channel batches of 56-byte-or-wider frames each re-read every line (14 channels: fabric reads 4.3x the input),
+        // and one pair per workgroup — the pairs of a window side by side on one XCD — wins (27.0 -> 22.7 ms).  AW_PART_FWD=1|2 forces.
+        sp->fwd_one_pair = sp->n_pairs > 4;
+        if (const char *e = getenv("AW_PART_FWD")) sp->fwd_one_pair = atoi(e) == 1;
         if (const char *e = getenv("AW_PART_HERM")) sp->herm_ok = atoi(e) != 0;          // A/B: 0 stores the last pair's redundant half too
     }
     std::vector<awk::cf2> tab, all;

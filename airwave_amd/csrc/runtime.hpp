@@ -60,7 +60,7 @@ struct aw_spatializer {
     size_t spec_capacity = 0;           // elements
     size_t scratch_budget = 0;          // bytes per stream chunk (AW_SPEC_SCRATCH_MB at create; 0 = from free memory at first use)
     bool cmac_group = false;            // partitioned path: block-group CMAC kernel instead of the marched one (> 8 pairs; AW_PART_CMAC=group)
-    bool fwd_one_pair = false;          // partitioned path: forward kernel with one channel pair per workgroup (opt-in AW_PART_FWD=1; measured 12.1 against 11.2 ms for the all-pairs kernel on cfg 3)
+    bool fwd_one_pair = false;          // partitioned path: forward kernel with one channel pair per workgroup (default for more than 4 pairs; AW_PART_FWD=1|2 forces either form)
     bool herm_ok = true;                // partitioned path, odd channel count: store/read only the non-redundant half of the last pair's spectrum
     int64_t reserved_frames = 0;        // aw_spatializer_reserve(): buffers are sized for calls up to this many frames
     // host-entry staging (grow-only)

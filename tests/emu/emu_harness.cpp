@@ -350,8 +350,8 @@ int emu_partitioned(const float *in, float *out, const float *hist, const float 
                             w[mb.i] = w[mb.i] + ai;
                             if (mb.pi != mb.i) w[mb.pi] = w[mb.pi] + ap;
                         };
-                        if (P - q0 <= 4) march_thread<4>(p, s, s + 1, j, pl, q0, emit);
-                        else march_thread<8>(p, s, s + 1, j, pl, q0, emit);
+                        if (P - q0 <= 4) march_thread<4, true>(p, s, s + 1, j, pl, q0, emit);
+                        else march_thread<8, true>(p, s, s + 1, j, pl, q0, emit);
                     }
     }
     run([&](EmuCtx &ctx, int s, int b) { tile_part_inverse<EmuCtx>(ctx, p, s, b); }, p.n_blocks);

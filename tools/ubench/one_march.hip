@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(kMarchThreads) one_march(TileParams p, int q0)
     const long long stream = blockIdx.y * 4;
     const bool odd = (pl & 1) != 0;
     const int woff = (LG > 1 && odd) ? march_bins(j).pi : march_bins(j).i;
-    march_thread<ONE_PQ>(p, stream, stream + 4, j, pl, q0, [&](long long st, int b, const MarchBins &mb, cf ai, cf ap) {
+    march_thread<ONE_PQ, (ONE_LG < 8)>(p, stream, stream + 4, j, pl, q0, [&](long long st, int b, const MarchBins &mb, cf ai, cf ap) {
         ai.x = lane_group_sum<LG>(ai.x); ai.y = lane_group_sum<LG>(ai.y);
         ap.x = lane_group_sum<LG>(ap.x); ap.y = lane_group_sum<LG>(ap.y);
         cf *w = p.wspec + (st * p.n_blocks + b) * (long long)kN;
