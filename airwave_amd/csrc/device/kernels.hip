@@ -560,7 +560,10 @@ hipError_t launch_part_forward(const TileParams &p_in, int n_streams, hipStream_
     // history (which reaches back P B frames: every window does) and still ends inside the input
     const long long usable = p.frames - ((p.n_channels % 4 != 0 && p.n_channels != 2) ? 1 : 0);
     long long lo = p.partitions;
-    long long hi = usable >= kN ? (usable - kN) / p.hop + p.partitions + 1 : lo;      // windows [0, hi) end inside the input
+    // windows [0, hi) end inside the input: (w - P) B + N <= usable  <=>  w <= floor((usable - N) / B) + P   (floor, not truncation:
+    // a call shorter than one window leaves only windows that lie entirely in the history)
+    const long long d = usable - kN;
+    long long hi = (d >= 0 ? d / p.hop : -((-d + p.hop - 1) / p.hop)) + p.partitions + 1;
     long long head_lo = 0;
     if (hi > n_windows) hi = n_windows;
     if (lo > n_windows) lo = n_windows;

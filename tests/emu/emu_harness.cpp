@@ -303,7 +303,8 @@ int emu_partitioned(const float *in, float *out, const float *hist, const float 
     };
     {   // interior / head / generic split of awk::launch_part_forward (vector variants exist for 7 and 8 channels here)
         const long long usable = frames - ((n_channels % 4 != 0 && n_channels != 2) ? 1 : 0);
-        long long lo = P, hi = usable >= kN ? (usable - kN) / B + P + 1 : lo;
+        const long long d = usable - kN;
+        long long lo = P, hi = (d >= 0 ? d / B : -((-d + B - 1) / B)) + P + 1;       // floor((usable - N) / B) + P + 1, as awk::launch_part_forward
         if (hi > n_windows) hi = n_windows;
         if (lo > n_windows) lo = n_windows;
         if (hi < lo) lo = hi;

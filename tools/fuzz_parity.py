@@ -14,18 +14,27 @@ TOL = 1e-5
 fails, n = [], 0
 t_end = time.time() + budget
 while time.time() < t_end:
-    C = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 14, 16]))
+    C = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]))
     taps = int(rng.choice([1, 2, 3, 17, 255, 256, 1000, 2799, 2800, 4096, 4320, 5399, 5400, 5900, 6145, 6146, 8640, 12289, 12290, 16000]))
     if rng.random() < 0.3:
         taps = int(rng.integers(1, 14000))
+    if rng.random() < 0.2:                       # long HRIRs: the partitioned path (marched CMAC; several passes above 8 partitions)
+        taps = int(rng.choice([12290, 16384, 16385, 20000, 32768, 40000, 70000, int(rng.integers(12290, 80000))]))
     S = int(rng.choice([1, 2, 3, 5]))
     total = int(rng.integers(1, 60000)) if rng.random() < 0.8 else int(rng.choice([1, 2, 3839, 3840, 3841, 8191, 8192, 8193, 16384]))
     env = {}
     r = rng.random()
     if r < 0.25: env["AW_WINDOW"] = "8192"
     elif r < 0.5: env["AW_WINDOW"] = "16384"
+    elif r < 0.6: env["AW_WINDOW"] = "4096"     # the partitioned path whatever the HRIR length
     if rng.random() < 0.25: env["AW_KERNEL_H"] = "2"
-    for k in ("AW_WINDOW", "AW_KERNEL_H"):
+    r2 = rng.random()
+    if r2 < 0.15: env["AW_PART_FWD"] = "1"
+    elif r2 < 0.3: env["AW_PART_FWD"] = "2"
+    if rng.random() < 0.1: env["AW_PART_CMAC"] = "group"
+    if rng.random() < 0.1: env["AW_PART_HERM"] = "0"
+    if rng.random() < 0.15: env["AW_SPEC_SCRATCH_MB"] = str(int(rng.choice([1, 3, 16])))      # several stream chunks
+    for k in ("AW_WINDOW", "AW_KERNEL_H", "AW_PART_FWD", "AW_PART_CMAC", "AW_PART_HERM", "AW_SPEC_SCRATCH_MB"):
         os.environ.pop(k, None)
     os.environ.update(env)
     n_tracks = int(rng.choice([2, 7, 14]))
@@ -38,6 +47,8 @@ while time.time() < t_end:
     x = orc.synth_input(S, total, C, seed=int(rng.integers(1 << 30)))
     cuts = sorted(set(int(c) for c in rng.integers(0, total + 1, size=int(rng.integers(0, 4))))) if total > 1 else []
     bounds = [0] + [c for c in cuts if 0 < c < total] + [total]
+    if os.environ.get("AW_FUZZ_TRACE"):
+        print("CASE", C, taps, S, total, bounds, env, n_tracks, flush=True)
     try:
         sp = aw.Spatializer(aw.HRIR(h), lt, rt, n_streams=S)
         info = sp.info()
