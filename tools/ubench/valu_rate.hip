@@ -94,7 +94,7 @@ int main() {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const double clk = prop.clockRate * 1e3;   // Hz
     printf("device %s, CUs %d, clock %.0f MHz\n", prop.name, prop.multiProcessorCount, clk / 1e6);
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
         for (int wps : {1, 2, 4}) {            // waves per SIMD
             const int threads = 64 * 4 * wps;  // one workgroup per CU, 4 SIMDs
             auto launch = [&]() {
