@@ -174,8 +174,7 @@ AW_HD void sub_fft512x2(Ctx &ctx, cf (&a)[2][8], cf *scr0, cf *scr1, const cf *t
 #pragma unroll
     for (int ka = 0; ka < 8; ++ka) { scr0[ka * 72 + lane] = a[0][ka]; scr1[ka * 72 + lane] = a[1][ka]; }
     ctx.wave_sync();
-#pragma unroll
-    for (int l1 = 0; l1 < 8; ++l1) { a[0][l1] = ctx.ld(scr0 + kap * 72 + l0 + 8 * l1); a[1][l1] = ctx.ld(scr1 + kap * 72 + l0 + 8 * l1); }
+    ctx.template ld8x2<8>(a[0], scr0 + kap * 72 + l0, a[1], scr1 + kap * 72 + l0);
     ctx.wave_sync();
 #endif
     ctx.stamp(SB + 2);
@@ -195,8 +194,7 @@ AW_HD void sub_fft512x2(Ctx &ctx, cf (&a)[2][8], cf *scr0, cf *scr1, const cf *t
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) { scr0[(kb * 8 + kap) * 9 + l0] = a[0][kb]; scr1[(kb * 8 + kap) * 9 + l0] = a[1][kb]; }
     ctx.wave_sync();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { a[0][i] = ctx.ld(scr0 + lane * 9 + i); a[1][i] = ctx.ld(scr1 + lane * 9 + i); }   // chunk kb''*8 + ka'' == lane
+    ctx.template ld8x2<1>(a[0], scr0 + lane * 9, a[1], scr1 + lane * 9);   // chunk kb''*8 + ka'' == lane
     ctx.wave_sync();
     ctx.stamp(SB + 4);
     // pass C: radix-8 over l0 -> kc.  Now a[s][kc] = X_s[ka'' + 8 kb'' + 64 kc] = X_s[lane + 64 kc]
@@ -341,8 +339,7 @@ AW_HD void pair_subfft_cmac(Ctx &ctx, const TileParams &p, int pair, cf *buf, co
     cf *row0 = buf + wave_row(wave, 0) * kRowStride;
     cf *row1 = buf + wave_row(wave, 1) * kRowStride;
     cf z[2][8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { z[0][j] = ctx.ld(row0 + lane + 64 * j); z[1][j] = ctx.ld(row1 + lane + 64 * j); }
+    ctx.template ld8x2<64>(z[0], row0 + lane, z[1], row1 + lane);
     ctx.wave_sync();
     sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
     if (!tab_loaded) load_tab(p, pair, wave, lane, tab);
@@ -672,8 +669,7 @@ AW_HD void tiles_part_forward(Ctx &ctx, const TileParams &p, long long first, lo
                 cf *row0 = buf + wave_row(wave, 0) * kRowStride;
                 cf *row1 = buf + wave_row(wave, 1) * kRowStride;
                 cf z[2][8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { z[0][j] = ctx.ld(row0 + lane + 64 * j); z[1][j] = ctx.ld(row1 + lane + 64 * j); }
+                ctx.template ld8x2<64>(z[0], row0 + lane, z[1], row1 + lane);
                 ctx.wave_sync();
                 sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
                 cf *dst = spec_w + (long long)(pair0 + h) * kN;
@@ -759,8 +755,7 @@ AW_HD void tile_part_forward1(Ctx &ctx, const TileParams &p, long long stream, i
     cf *row0 = buf0 + wave_row(wave, 0) * kRowStride;
     cf *row1 = buf0 + wave_row(wave, 1) * kRowStride;
     cf z[2][8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { z[0][j] = ctx.ld(row0 + lane + 64 * j); z[1][j] = ctx.ld(row1 + lane + 64 * j); }
+    ctx.template ld8x2<64>(z[0], row0 + lane, z[1], row1 + lane);
     ctx.wave_sync();
     sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
     const bool skip1 = p.herm_last && pair == p.n_pairs - 1 && wave != 0;      // uniform (see tile_part_forward)

@@ -60,6 +60,9 @@ struct EmuCtx {
         sh->wave[tid_ >> 6]->arrive_and_wait();
     }
     void wave_sync() const { sh->wave[tid_ >> 6]->arrive_and_wait(); }
+    template <int STRIDE> void ld8x2(awk::cf (&a)[8], const awk::cf *p0, awk::cf (&b)[8], const awk::cf *p1) const {
+        for (int i = 0; i < 8; ++i) { a[i] = p0[i * STRIDE]; b[i] = p1[i * STRIDE]; }
+    }
     void st_stream(awk::cf *q, awk::cf v) const { *q = v; }
     void st_stream4(float *q, float a, float b, float c, float d) const { q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
     awk::cf xchg1(awk::cf v) const {          // value of lane ^ 1

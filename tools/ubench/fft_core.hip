@@ -43,8 +43,7 @@ __global__ void __launch_bounds__(kThreads) k_core(const cf *tw1, const cf *twa_
             cf *row0 = buf + wave_row(wave, 0) * kRowStride;
             cf *row1 = buf + wave_row(wave, 1) * kRowStride;
             cf z[2][8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { z[0][j] = ctx.ld(row0 + lane + 64 * j); z[1][j] = ctx.ld(row1 + lane + 64 * j); }
+            ctx.template ld8x2<64>(z[0], row0 + lane, z[1], row1 + lane);
             ctx.wave_sync();
             sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
 #pragma unroll
