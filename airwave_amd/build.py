@@ -20,6 +20,7 @@ ARCH = "gfx950"
 SOURCES = [
     "device/kernels.hip",
     "device/march_kernels.hip",
+    "device/ols2_even_kernels.hip",
     "device/eq_kernels.hip",
     "runtime.cpp",
     "eq_runtime.cpp",

@@ -5,6 +5,7 @@
 // utility kernels (history carry, synthetic fill, planar<->interleaved).
 #include "kernels.hpp"
 #include "gpu_ctx.hpp"
+#include "ols2_kernel.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -119,22 +120,8 @@ __global__ void __launch_bounds__(kThreads) aw_part_inverse_kernel(TileParams p,
     tile_part_inverse<GpuCtx>(ctx, p, id / p.n_blocks, (int)(id % p.n_blocks));
 }
 
-// The 16384-frame window path (tile_ols2.hpp).  CS = real channels, NB = batches of four pseudo-channels.
-template <int CS, int NB, bool INTERIOR>
-__global__ void __launch_bounds__(kThreads) aw_fused_ols2_kernel(TileParams p, long long n_tiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    GpuCtx ctx{reinterpret_cast<cf *>(smem), p.dbg ? p.dbg + (long long)blockIdx.x * kStamps : nullptr};
-    ctx.stamp_thread_ = p.stagger;
-    const long long g = gridDim.x, b = blockIdx.x;
-    const long long xcd = b % 8, slot = b / 8;
-    const long long per_xcd_wg = (g - xcd + 7) / 8;
-    const long long q = n_tiles / 8, r = n_tiles % 8;
-    const long long lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    const long long hi = lo + (xcd < r ? q + 1 : q);
-    tiles_fused_ols2<GpuCtx, CS, NB, INTERIOR>(ctx, p, lo + slot, per_xcd_wg, hi);
-}
 // (real channels, batches): 2C pseudo-channels in batches of four
-#define AW_FOR_EACH_VEC2(X) X(1, 1) X(2, 1) X(3, 2) X(4, 2) X(5, 3) X(6, 3) X(7, 4) X(8, 4)
+#define AW_FOR_EACH_VEC2(X) X(1, 1) X(2, 1) X(3, 2) X(5, 3) X(7, 4)      // 4, 6 and 8 channels live in ols2_even_kernels.hip (SLP on)
 
 const char *fused_ols2_kernel_name(int C) {
     switch (C) {
@@ -150,6 +137,7 @@ const char *fused_ols2_kernel_name(int C) {
     }
 }
 static bool has_vec2_variant(int C) { return C >= 1 && C <= 8; }
+static bool ols2_slp_layout(int C) { return C == 4 || C == 6 || C == 8; }      // built in ols2_even_kernels.hip
 
 // Kernel variants.  Vectorised interior kernels <CS, NP, true> exist for the channel counts whose
 // frames are whole float4s/float2s (2, 4, 8, 12, 16 channels: stereo ... 7.1.4 + 4); every other
@@ -246,6 +234,7 @@ hipError_t prepare_kernels(LaunchCfg *cfg) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols2_kernel<0, 0, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e == hipSuccess) e = prepare_ols2_even();
 #undef AW_SET_BVEC
 #undef AW_SET_VEC
 #undef AW_SET_GEN
@@ -528,7 +517,8 @@ hipError_t launch_fused_ols2(const TileParams &p_in, int n_streams, hipStream_t 
     if (n_int > 0) {
         const dim3 grid = persistent_grid(n_int, p), block(kThreads);
         if (ev0) (void)hipEventRecord(ev0, stream);
-        switch (p.n_channels) {
+        if (ols2_slp_layout(p.n_channels)) launch_ols2_even(p, true, n_int, grid, stream);
+        else switch (p.n_channels) {
 #define AW_CASE(CS, NB) case CS: hipLaunchKernelGGL((aw_fused_ols2_kernel<CS, NB, true>), grid, block, kLdsBytes, stream, p, n_int); break;
             AW_FOR_EACH_VEC2(AW_CASE)
 #undef AW_CASE
@@ -540,7 +530,8 @@ hipError_t launch_fused_ols2(const TileParams &p_in, int n_streams, hipStream_t 
         p.dbg = nullptr;                 // diagnostic stamps describe the interior launch only
         if (ev0 && !dom_int) (void)hipEventRecord(ev0, stream);
         const dim3 grid = persistent_grid(n_bnd, p), block(kThreads);
-        switch (p.n_channels) {      // compile-time channel and batch counts also for the boundary tiles (scalar loads)
+        if (ols2_slp_layout(p.n_channels)) launch_ols2_even(p, false, n_bnd, grid, stream);
+        else switch (p.n_channels) {      // compile-time channel and batch counts also for the boundary tiles (scalar loads)
 #define AW_CASE(CS, NB) case CS: hipLaunchKernelGGL((aw_fused_ols2_kernel<CS, NB, false>), grid, block, kLdsBytes, stream, p, n_bnd); break;
             AW_FOR_EACH_VEC2(AW_CASE)
 #undef AW_CASE

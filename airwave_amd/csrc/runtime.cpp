@@ -249,31 +249,36 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
     if (const char *e = getenv("AW_WINDOW")) window = atoi(e);
     const int hist2 = awh::poly_history_frames(hrir->taps);          // 16384-frame windows (tile_ols2.hpp)
     const bool fits1 = hrir->taps - 1 <= N - 2048, fits2 = hist2 <= awk::kN2 - 4096;
-    // Long end of the 16384-frame windows against the partitioned path (tools/path_sweep.py: the hop shrinks to
-    // 4096 frames at 12 289 taps): 1, 2, 3 and 5 channels stay fused to the window's limit (mono 12 289 taps: 64 / 34 G frames/s),
-    // 4 channels up to ~9000 taps, 6 and 8 up to ~10 000, 7 up to ~11 800; layouts without a vector variant of the 16384-frame
-    // kernels (9+ channels) take the partitioned path as soon as one 8192-frame window cannot hold the HRIR (12 ch, 8640 taps:
-    // 3.0 on the generic kernel against 10.2 G frames/s).
-    const int upto = (n_in <= 3 || n_in == 5) ? 12289 : n_in == 4 ? 9000 : (n_in == 6 || n_in == 8) ? 10000 : n_in == 7 ? 11800 : 0;
+    // Path / window policy.  Every threshold below is a measured crossover (G stereo frames/s, 128 streams x 4 s unless stated) and
+    // is regenerated in one command: `bash tools/regen_policy.sh` (round 2, after the marched partitioned path, the two-pass
+    // wide kernels and the per-layout SLP choice moved most of them).
+    // (1) Long end of the 16384-frame windows against the partitioned path (the hop shrinks to 4096 frames at 12 289 taps):
+    //     1, 3 and 5 channels stay fused to the window's limit (mono 12 289 taps: 79 / 49), stereo too (12 289: 53 / 51);
+    //     7 channels up to ~11 800 (11 000: 19.7 / 18.8; 12 289: 16.7 / 18.3); the even layouts leave early, their 16384-frame
+    //     kernels carry ~100 spilled VGPRs: 4 channels up to ~7000 (6146: 36.8 / 35.1; 8000: 30.7 / 35.4), 6 up to ~8500
+    //     (8000: 23.5 / 21.8; 9000: 20.2 / 21.1), 8 up to ~7800 (6146: 20.6 / 17.6; 8000: 18.2 / 18.2).  9+ channels have no
+    //     16384-frame vector kernels: partitioned as soon as one 8192-frame window cannot hold the HRIR.
+    const int upto = (n_in <= 3 || n_in == 5) ? 12289 : n_in == 4 ? 7000 : n_in == 6 ? 8500 : n_in == 8 ? 7800 : n_in == 7 ? 11800 : 0;
     const bool fused2_ok = fits2 && hrir->taps <= upto;
     if (window == 0) {
-        // measured crossover of the two fused kernels (tools/window_sweep.py, 128 streams x 4 s, G frames/s 8192 / 16384):
-        // mono always (4320 taps 76 / 172), stereo from ~2800 taps (84 / 110), 3 channels from ~1000 (4320 taps 50 / 80),
-        // 5 from ~2700 (34 / 43), 7 from ~4800, 4 and 6 from ~5400, 8 from ~5900.  Odd counts cross early: the
-        // 8192-frame kernels pad them to whole pairs, the polyphase view has 2C pseudo-channels — always whole pairs.
-        // Everything else (9+ channels: no vector variant) only when one 8192-frame window cannot hold the HRIR.
+        // (2) 8192- against 16384-frame windows where both can hold the HRIR (8192 / 16384): mono always 16384 (4320 taps 93 / 202),
+        //     stereo from ~2000 taps (2048: 157 / 160; 4320: 105 / 143), 3 channels from ~1000 (4320: 61 / 98), 5 from ~2000
+        //     (2048: 61 / 63; 4320: 40 / 55), 7 from ~4400 (4320: 35.9 / 35.6; 5000: 29.7 / 33.2); 4, 6 and 8 channels only at the very
+        //     end of the 8192-frame window's range (6 and 8 from ~6100: 26.4 / 27.5 and 21.1 / 21.2 at 6145; 4 never: 38.2 / 36.9).
+        //     Odd counts cross early: the 8192-frame kernels pad them to whole pairs, the polyphase view has 2C pseudo-channels.
         const int c = n_in;
-        const int from = c == 1 ? 0 : c == 2 ? 2800 : c == 3 ? 1000 : c == 5 ? 2700 : c == 7 ? 4800 : (c == 4 || c == 6) ? 5400 : c == 8 ? 5900 : (1 << 30);
+        const int from = c == 1 ? 0 : c == 2 ? 2000 : c == 3 ? 1000 : c == 5 ? 2000 : c == 7 ? 4400 : (c == 6 || c == 8) ? 6100 : (1 << 30);
         window = (hrir->taps >= from && fused2_ok) ? awk::kN2 : AW_DEFAULT_WINDOW;
-        // small batches cannot fill 256 CUs with 16384-frame tiles (a 10 s stream is 40 of them): the 8192-frame kernels
-        // give three times the tiles.  Measured crossover in streams (tools/small_batch_sweep.py, 4320 taps, 10 s per
-        // stream): mono 8 (1 stream 13 -> 25 G frames/s on 8192), stereo 20, 3 channels 16, 5 channels 24; 16 elsewhere
-        const int min_streams = c == 1 ? 8 : c == 2 ? 20 : c == 5 ? 24 : 16;
+        // (3) small batches cannot fill 256 CUs with 16384-frame tiles (a 10 s stream is 40 of them): the 8192-frame kernels give
+        //     three times the tiles.  Crossover in streams (tools/small_batch_sweep.py, 4320 taps, 10 s per stream): mono 8
+        //     (4 streams 67 / 55, 8: 79 / 81), stereo 24 (16: 88 / 86, 24: 92 / 107), 3 channels 12, 5 channels 24; 16 elsewhere
+        const int min_streams = c == 1 ? 8 : c == 2 ? 24 : c == 3 ? 12 : c == 5 ? 24 : 16;
         if (window == awk::kN2 && n_streams < min_streams && fits1) window = awk::kN;
     }
-    // 9+ channels near the end of the 8192-frame window's range (hop down to 2048 frames): the partitioned path is faster from
-    // ~5300 taps (9-11 channels) / ~5800 (12-16) — 9 channels, 6145 taps: 8.7 -> 11.8 G frames/s (tools/path_sweep.py)
-    const bool prefer_partitioned = getenv("AW_WINDOW") == nullptr && n_in >= 9 && hrir->taps >= (n_in <= 11 ? 5300 : 5800);
+    // (4) 9+ channels near the end of the 8192-frame window's range (hop down to ~2000 frames) against the partitioned path
+    //     (8192 / partitioned): 9 channels from ~5600 taps (5300: 15.4 / 13.6; 5800: 13.4 / 13.7), the others only at the very end
+    //     (12 channels 6145 taps: 12.1 / 11.8; 14: 10.3 / 10.3; 16: 9.2 / 9.5)
+    const bool prefer_partitioned = getenv("AW_WINDOW") == nullptr && n_in >= 9 && hrir->taps >= (n_in == 9 ? 5600 : 6100);
     const bool force_partitioned = window == 4096 || prefer_partitioned;       // AW_WINDOW=4096: the partitioned path (A/B)
     if (!force_partitioned && ((window == awk::kN2 && fits2) || (!fits1 && fused2_ok))) {
         sp->path = 0; sp->fused2 = true;
