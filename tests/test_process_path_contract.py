@@ -91,3 +91,23 @@ def test_mixed_rate_batch_uses_the_reference_map_chooser(oracle):
     h7 = oracle.synth_hrir(7, 300, seed=1)
     b = aw.MixedRateBatch(h7, 48000.0, aw.InputLayout.detect(2), [48000.0])
     assert list(b.left_track) == [0, 1] and list(b.right_track) == [1, 0]          # hesuvi7: FL(0,1) FR(1,0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wgs", ["3", "12"])
+def test_tiny_persistent_grids_still_compute_every_tile(oracle, wgs, monkeypatch):
+    """AW_PERSISTENT_WGS below 8 (a documented knob, or a device with fewer than 8 CUs): the persistent kernels deal tiles to 8 XCD
+    groups by blockIdx % 8, so the grid is clamped to >= 8 workgroups — otherwise whole groups of tiles would never be computed.
+    The knob is read when the CONTEXT is created."""
+    import airwave_amd as aw
+    monkeypatch.setenv("AW_PERSISTENT_WGS", wgs)
+    ctx = aw.Context(0)
+    monkeypatch.delenv("AW_PERSISTENT_WGS")
+    for taps, channels in ((4320, 8), (4320, 7), (20000, 4), (900, 14)):
+        h = oracle.synth_hrir(14, taps, seed=5)
+        lt = (np.arange(channels) % 14).astype(np.int32)
+        rt = ((np.arange(channels) + 7) % 14).astype(np.int32)
+        x = oracle.synth_input(2, 60000, channels, seed=taps)
+        y = aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=2, ctx=ctx).process(x)
+        assert np.isfinite(y).all()
+        assert oracle.peak_rel_error(y[1], oracle.spatialize_f64(x[1], h, lt, rt)) < 1e-5, (taps, channels)
