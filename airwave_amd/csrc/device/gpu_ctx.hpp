@@ -50,7 +50,11 @@ struct GpuCtx {
     // wave id as a provably wave-uniform (SGPR) value: row bases become scalar
     __device__ __forceinline__ int wave() const { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
     __device__ __forceinline__ cf *lds() const { return lds_; }
+#ifdef AW_ABL_NOBARRIER       // timing ablation only (racy)
+    __device__ __forceinline__ void barrier() const { __builtin_amdgcn_wave_barrier(); }
+#else
     __device__ __forceinline__ void barrier() const { __syncthreads(); }
+#endif
     // Phase offset between the two waves of each SIMD (waves w and w+4): the younger half idles a
     // little after a barrier so that its LDS-exchange phases fall into the older half's butterfly
     // phases instead of colliding with them (MI355X_MICROARCH "Two waves per SIMD", item 9).

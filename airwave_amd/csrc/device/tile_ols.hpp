@@ -248,6 +248,13 @@ AW_HD void load_frame(const TileParams &p, const float *in_s, const float *hist_
 template <int CS, bool INTERIOR>
 AW_HD void load_batch(const TileParams &p, const float *in_s, const float *hist_s, long long f0, int t, int c0,
                       float (&raw)[16][kBatchCh]) {
+#ifdef AW_ABL_NOLOAD           // timing ablation only: no global loads of frames
+    {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { raw[j][0] = 0.001f * t; raw[j][1] = 0.002f * j; raw[j][2] = 0.003f * c0; raw[j][3] = 1.0f; }
+        return;
+    }
+#endif
     if constexpr (INTERIOR && CS > 0) {
         const float *lane_base = in_s + f0 * CS + c0;          // uniform
         const int lane_off = t * CS;                            // per lane, 32-bit
@@ -342,6 +349,13 @@ AW_HD void pair_subfft_cmac(Ctx &ctx, const TileParams &p, int pair, cf *buf, co
     ctx.template ld8x2<64>(z[0], row0 + lane, z[1], row1 + lane);
     ctx.wave_sync();
     sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
+#ifdef AW_ABL_NOCMAC          // timing ablation only (wrong results): no tables, no partner exchange, no multiply-accumulate
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) wacc[s][kc] = wacc[s][kc] + z[s][kc];
+    return;
+#endif
     if (!tab_loaded) load_tab(p, pair, wave, lane, tab);
     ctx.stamp(22);
     // publish Z rows inside the wave, then CMAC against the partner bins
@@ -414,6 +428,9 @@ AW_HD void tile_inverse_final(Ctx &ctx, const TileParams &p, cf *buf0, cf w1, in
         if (m >= first_valid && f < p.frames) {
             cf *o = reinterpret_cast<cf *>(p.out + ((long long)stream * p.frames + f) * 2);
             if (accumulate) y[j] = y[j] + old[j];      // second pass over a wide layout's remaining channels (uniform)
+#ifdef AW_ABL_NOSTORE         // timing ablation only
+            if (y[j].x == 1.2345e-30f)
+#endif
             ctx.st_stream(o, y[j]);
         }
     }

@@ -1,0 +1,67 @@
+// tile_bench.hip — the fused 8192-frame tile kernel <8, 4, interior> alone, on cfg-2-shaped synthetic data, built in seconds:
+// a fast A/B loop for -D variants of the tile code (timing only: tables and input are random).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -fno-slp-vectorize -Iairwave_amd/csrc -Iinclude tools/ubench/tile_bench.hip -o tools/ubench/tile_bench
+#include "device/tile_ols.hpp"
+#include "device/gpu_ctx.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#ifndef TB_CS
+#define TB_CS 8
+#define TB_NP 4
+#endif
+namespace awk {
+__global__ void __launch_bounds__(kThreads) k_tile(TileParams p, long long n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
+    const long long g = gridDim.x, b = blockIdx.x;
+    const long long xcd = b % 8, slot = b / 8;
+    const long long per_xcd_wg = (g - xcd + 7) / 8;
+    const long long q = n_tiles / 8, r = n_tiles % 8;
+    const long long lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const long long hi = lo + (xcd < r ? q + 1 : q);
+    tiles_fused_ols<GpuCtx, TB_CS, TB_NP, true>(ctx, p, lo + slot, per_xcd_wg, hi);
+}
+}
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+int main() {
+    using namespace awk;
+    const int S = 128, C = TB_CS, taps = 4320; const long long F = 480000;
+    const int hop = (kN - (taps - 1)) / 64 * 64, hist = kN - hop;
+    std::vector<float> h_in((size_t)4 << 20);
+    for (size_t i = 0; i < h_in.size(); ++i) h_in[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
+    float *d_in, *d_out; cf2 *d_tab; cf *d1, *da, *db;
+    const size_t n_in = (size_t)S * F * C, n_out = (size_t)S * F * 2;
+    CK(hipMalloc((void **)&d_in, (n_in + 64) * 4)); CK(hipMalloc((void **)&d_out, n_out * 4));
+    for (size_t off = 0; off < n_in; off += h_in.size()) CK(hipMemcpy(d_in + off, h_in.data(), std::min(h_in.size(), n_in - off) * 4, hipMemcpyHostToDevice));
+    const size_t n_tab = (size_t)(TB_NP + 1) * kN;
+    std::vector<cf2> tab(n_tab);
+    for (size_t i = 0; i < n_tab; ++i) { tab[i].a = mk(1e-4f * (i % 97), -1e-4f * (i % 89)); tab[i].b = mk(2e-5f * (i % 83), 1e-5f * (i % 79)); }
+    CK(hipMalloc((void **)&d_tab, n_tab * sizeof(cf2))); CK(hipMemcpy(d_tab, tab.data(), n_tab * sizeof(cf2), hipMemcpyHostToDevice));
+    std::vector<cf> tw1(512), twa(512), twb(64);
+    for (int t = 0; t < 512; ++t) tw1[t] = mk(cosf(-2 * 3.14159265f * t / 8192), sinf(-2 * 3.14159265f * t / 8192));
+    for (int ka = 0; ka < 8; ++ka) for (int l = 0; l < 64; ++l) twa[ka * 64 + l] = mk(cosf(-2 * 3.14159265f * l * ka / 512), sinf(-2 * 3.14159265f * l * ka / 512));
+    for (int kb = 0; kb < 8; ++kb) for (int l = 0; l < 8; ++l) twb[kb * 8 + l] = mk(cosf(-2 * 3.14159265f * l * kb / 64), sinf(-2 * 3.14159265f * l * kb / 64));
+    CK(hipMalloc((void **)&d1, 512 * 8)); CK(hipMalloc((void **)&da, 512 * 8)); CK(hipMalloc((void **)&db, 64 * 8));
+    CK(hipMemcpy(d1, tw1.data(), 512 * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(da, twa.data(), 512 * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(db, twb.data(), 64 * 8, hipMemcpyHostToDevice));
+    TileParams p{};
+    p.in = d_in; p.out = d_out; p.hist = d_in; p.tab = d_tab; p.tw1 = d1; p.twa = da; p.twb = db; p.zeros = d_in;
+    p.frames = F; p.n_channels = C; p.n_pairs = TB_NP; p.hop = hop; p.hist_len = hist;
+    p.tiles_per_stream = (int)((F + hop - 1) / hop);
+    long long lo = (hist + hop - 1) / hop, hi = (F - kN + hist) / hop + 1;
+    p.tile_lo = (int)lo; p.tile_hi = (int)hi;
+    const long long n_tiles = (long long)S * (hi - lo);
+    CK(hipFuncSetAttribute((const void *)k_tile, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9f;
+    for (int it = 0; it < 8; ++it) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_tile, dim3(256), dim3(kThreads), kLdsBytes, 0, p, n_tiles);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (it >= 2 && ms < best) best = ms;
+    }
+    printf("tile kernel <%d,%d>: %.3f ms for %lld tiles -> %.2f us per tile per CU, %.2f G frames/s\n", TB_CS, TB_NP, best, n_tiles, best * 1e3 / (n_tiles / 256.0), n_tiles * (double)hop / best / 1e6);
+    return 0;
+}
