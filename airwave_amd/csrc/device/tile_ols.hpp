@@ -288,6 +288,35 @@ AW_HD void load_batch(const TileParams &p, const float *in_s, const float *hist_
     }
 }
 
+// Both four-channel batches of the thread's 16 frames in one go (interior tiles, 5-8 channels): the two 16-byte loads of a
+// frame are issued back to back, so the second one hits the line the first has just brought into L1 — the batches no longer
+// pull every line through the L2 -> L1 path twice, half a tile apart (tools/ubench/tile_bench.hip: frame loads are 20 % of a
+// cfg-2 tile, a throughput cost of that path).  Same registers as issuing batch 1 during batch 0's processing.
+#ifndef AW_WHOLE_FRAMES
+#define AW_WHOLE_FRAMES 1
+#endif
+template <int CS>
+AW_HD void load_batch2(const float *in_s, long long f0, int t, float (&ra)[16][kBatchCh], float (&rb)[16][kBatchCh]) {
+    static_assert(CS >= 5 && CS <= 8, "two batches of four channels");
+    const float *lane_base = in_s + f0 * CS;            // uniform
+    const int lane_off = t * CS;                         // per lane, 32-bit
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float *src = lane_base + (long long)j * 512 * CS + lane_off;
+        if constexpr (CS % 4 == 0) {
+            const f4 a = *reinterpret_cast<const f4 *>(src);
+            const f4 b = *reinterpret_cast<const f4 *>(src + 4);
+            ra[j][0] = a.x; ra[j][1] = a.y; ra[j][2] = a.z; ra[j][3] = a.w;
+            rb[j][0] = b.x; rb[j][1] = b.y; rb[j][2] = b.z; rb[j][3] = b.w;
+        } else {
+            const f4u a = *reinterpret_cast<const f4u *>(src);
+            const f4u b = *reinterpret_cast<const f4u *>(src + 4);      // runs up to 3 floats into the next frame: zero tables (see load_batch)
+            ra[j][0] = a.x; ra[j][1] = a.y; ra[j][2] = a.z; ra[j][3] = a.w;
+            rb[j][0] = b.x; rb[j][1] = b.y; rb[j][2] = b.z; rb[j][3] = b.w;
+        }
+    }
+}
+
 // HEAD windows of the partitioned path (the first P windows of a call: part history, part input, nothing past the
 // end): per frame a pointer select between the history buffer and the input, then the same whole-frame vector load as
 // the interior windows.  Layouts whose frames are not whole float4s read up to 3 floats past a frame: the history
@@ -478,11 +507,15 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
     twa[t] = p.twa[t];                                   // 512 entries, one per thread
     if (t < kTwbElems) twb[t] = p.twb[t];                // visible after the first barrier below
 
+    // whole-frame mode: both batches of a tile are loaded together (load_batch2), batch 1 waits in raw_b
+    constexpr bool kWhole = AW_WHOLE_FRAMES != 0 && INTERIOR && CS >= 5 && CS <= 8 && (NP == 3 || NP == 4);
     float raw[16][kBatchCh];
+    float raw_b[kWhole ? 16 : 1][kBatchCh];
     {
         const TileId id0 = tile_of<INTERIOR>(p, first);
-        load_batch<CS, INTERIOR>(p, p.in + id0.stream * p.frames * Cn, p.hist + id0.stream * (long long)p.hist_len * Cn,
-                                 (long long)id0.tile * p.hop - p.hist_len, t, 0, raw);
+        if constexpr (kWhole) load_batch2<CS>(p.in + id0.stream * p.frames * Cn, (long long)id0.tile * p.hop - p.hist_len, t, raw, raw_b);
+        else load_batch<CS, INTERIOR>(p, p.in + id0.stream * p.frames * Cn, p.hist + id0.stream * (long long)p.hist_len * Cn,
+                                      (long long)id0.tile * p.hop - p.hist_len, t, 0, raw);
     }
     for (long long id = first; id < end; id += step) {
     // Per-iteration opaque thread index: keeps lane-dependent addresses from being hoisted out of
@@ -514,6 +547,25 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
             cf pw[16];
             tw_powers(ctx.opaque(w1), pw);       // opaque: keep the 15 powers out of long-lived registers
             cf x[16];
+            if constexpr (kWhole) {
+                if (pair0 > 0) {                 // compile-time after unrolling: the second batch waits in raw_b
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) x[j] = mk(raw_b[j][0], raw_b[j][1]);
+                    pair_pass1(x, pw, buf0, t);
+                    if (two) {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) x[j] = mk(raw_b[j][2], raw_b[j][3]);
+                        pair_pass1(x, pw, buf1, t);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][0], raw[j][1]);
+                    pair_pass1(x, pw, buf0, t);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][2], raw[j][3]);
+                    pair_pass1(x, pw, buf1, t);
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][0], raw[j][1]);
             pair_pass1(x, pw, buf0, t);
@@ -521,6 +573,7 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
 #pragma unroll
                 for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][2], raw[j][3]);
                 pair_pass1(x, pw, buf1, t);
+            }
             }
         }
         cf2 tab[2][8];
@@ -533,9 +586,9 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
         ctx.stamp(pair0 > 0 ? 9 : 4);
         const int pair1 = pair0 + 1;     // a phantom second pair (odd pair count, runtime loop) lands on the zero pair after the last one
         if (two && kTabEarly1) load_tab(p, pair1, wave, lane, tab);
-        if (kPrefetchRawEarly && more) load_batch<CS, INTERIOR>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
+        if (!kWhole && kPrefetchRawEarly && more) load_batch<CS, INTERIOR>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
         if (two) pair_subfft_cmac(ctx, p, pair1, buf1, twa, twb, tab, lane, wave, wacc, kTabEarly1);
-        if (!kPrefetchRawEarly && more) load_batch<CS, INTERIOR>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
+        if (!kWhole && !kPrefetchRawEarly && more) load_batch<CS, INTERIOR>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
         ctx.stamp(pair0 > 0 ? 10 : 5);
     };
     if constexpr (NP > 0) {
@@ -553,8 +606,9 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
     {   // prefetch the next tile's first batch here, where few registers are live (unconditional:
         // the last iteration re-reads its own batch; a branch would put phis on 64 registers)
         const TileId nx = tile_of<INTERIOR>(p, id + step < end ? id + step : id);
-        load_batch<CS, INTERIOR>(p, p.in + nx.stream * p.frames * Cn, p.hist + nx.stream * (long long)p.hist_len * Cn,
-                                 (long long)nx.tile * p.hop - p.hist_len, t, 0, raw);
+        if constexpr (kWhole) load_batch2<CS>(p.in + nx.stream * p.frames * Cn, (long long)nx.tile * p.hop - p.hist_len, t, raw, raw_b);
+        else load_batch<CS, INTERIOR>(p, p.in + nx.stream * p.frames * Cn, p.hist + nx.stream * (long long)p.hist_len * Cn,
+                                      (long long)nx.tile * p.hop - p.hist_len, t, 0, raw);
     }
     tile_inverse_final(ctx, p, buf0, w1, t, stream, f0, p.hist_len, ACC);
     ctx.barrier();                                       // the final exchange has been read before buf0 is rewritten
