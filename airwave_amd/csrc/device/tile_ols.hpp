@@ -387,6 +387,16 @@ AW_HD void pair_subfft_cmac(Ctx &ctx, const TileParams &p, int pair, cf *buf, co
 #endif
     if (!tab_loaded) load_tab(p, pair, wave, lane, tab);
     ctx.stamp(22);
+#ifdef AW_ABL_NOPARTNER       // timing ablation only (wrong results): no partner exchange through LDS
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            wacc[s][kc] = cfma(z[s][kc], tab[s][kc].a, wacc[s][kc]);
+            wacc[s][kc] = cfmac(z[1 - s][7 - kc], tab[s][kc].b, wacc[s][kc]);
+        }
+    return;
+#endif
     // publish Z rows inside the wave, then CMAC against the partner bins
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc) { row0[lane + 64 * kc] = z[0][kc]; row1[lane + 64 * kc] = z[1][kc]; }
@@ -696,12 +706,28 @@ AW_HD void tiles_part_forward(Ctx &ctx, const TileParams &p, long long first, lo
     twa[t] = p.twa[t];
     if (t < kTwbElems) twb[t] = p.twb[t];
 
+    // whole-frame mode (interior windows of 5-8 channel layouts): both four-channel batches of a window are loaded together
+    // (load_batch2: every line crosses the L2 -> L1 path once), the second batch waits in raw_b
+    constexpr bool kWhole = AW_WHOLE_FRAMES != 0 && MODE == 1 && CS >= 5 && CS <= 8;
     float raw[16][kBatchCh];
-    {
-        const PartWin pw0 = part_window_of<MODE>(first, per, w0, skip);
-        load(p.in + pw0.stream * p.frames * Cn, p.hist + pw0.stream * (long long)p.hist_len * Cn,
-             ((long long)pw0.w - p.partitions) * p.hop, t, 0, raw);
-    }
+    float raw_b[kWhole ? 16 : 1][kBatchCh];
+    auto load_window = [&](const PartWin &w) {
+        const float *in_w = p.in + w.stream * p.frames * Cn;
+        const long long fw = ((long long)w.w - p.partitions) * p.hop;
+        if constexpr (kWhole) {
+            load_batch2<CS>(in_w, fw, t, raw, raw_b);
+            if constexpr ((CS & 1) != 0) {                  // the padding lane of an odd layout's last pair must be a real zero (herm_last)
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+#pragma unroll
+                    for (int c = 0; c < kBatchCh; ++c)
+                        if (4 + c >= CS) raw_b[j][c] = 0.f;
+            }
+        } else {
+            load(in_w, p.hist + w.stream * (long long)p.hist_len * Cn, fw, t, 0, raw);
+        }
+    };
+    load_window(part_window_of<MODE>(first, per, w0, skip));
     for (long long id = first; id < end; id += step) {
         t = ctx.opaque_i(t0);                       // keeps lane-dependent addresses from living across the window loop
         lane = t & 63;
@@ -717,21 +743,26 @@ AW_HD void tiles_part_forward(Ctx &ctx, const TileParams &p, long long first, lo
                 cf pw[16];
                 tw_powers(ctx.opaque(w1), pw);
                 cf x[16];
+                if (kWhole && pair0 > 0) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][0], raw[j][1]);
-                pair_pass1(x, pw, buf0, t);
+                    for (int j = 0; j < 16; ++j) x[j] = mk(raw_b[kWhole ? j : 0][0], raw_b[kWhole ? j : 0][1]);
+                    pair_pass1(x, pw, buf0, t);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][2], raw[j][3]);
-                pair_pass1(x, pw, buf1, t);
+                    for (int j = 0; j < 16; ++j) x[j] = mk(raw_b[kWhole ? j : 0][2], raw_b[kWhole ? j : 0][3]);
+                    pair_pass1(x, pw, buf1, t);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][0], raw[j][1]);
+                    pair_pass1(x, pw, buf0, t);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) x[j] = mk(raw[j][2], raw[j][3]);
+                    pair_pass1(x, pw, buf1, t);
+                }
             }
             // the next batch's frames — of this window, or the first batch of the workgroup's next window — travel while
             // this batch's sub-FFTs run (no accumulators or tables live here)
-            if (more) load(in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
-            else {
-                const PartWin nx = part_window_of<MODE>(id + step < end ? id + step : id, per, w0, skip);     // the last one re-reads its own batch
-                load(p.in + nx.stream * p.frames * Cn, p.hist + nx.stream * (long long)p.hist_len * Cn,
-                     ((long long)nx.w - p.partitions) * p.hop, t, 0, raw);
-            }
+            if (more) { if (!kWhole) load(in_s, hist_s, f0, t, 2 * (pair0 + 2), raw); }
+            else load_window(part_window_of<MODE>(id + step < end ? id + step : id, per, w0, skip));     // the last one re-reads its own frames
             ctx.barrier();
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
