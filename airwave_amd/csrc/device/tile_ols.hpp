@@ -297,7 +297,7 @@ AW_HD void load_batch(const TileParams &p, const float *in_s, const float *hist_
 #endif
 template <int CS>
 AW_HD void load_batch2(const float *in_s, long long f0, int t, float (&ra)[16][kBatchCh], float (&rb)[16][kBatchCh]) {
-    static_assert(CS >= 5 && CS <= 8, "two batches of four channels");
+    static_assert(CS >= 5, "two batches of four channels (the first eight channels from the base pointer; wide layouts shift the base)");
     const float *lane_base = in_s + f0 * CS;            // uniform
     const int lane_off = t * CS;                         // per lane, 32-bit
 #pragma unroll
@@ -518,7 +518,7 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
     if (t < kTwbElems) twb[t] = p.twb[t];                // visible after the first barrier below
 
     // whole-frame mode: both batches of a tile are loaded together (load_batch2), batch 1 waits in raw_b
-    constexpr bool kWhole = AW_WHOLE_FRAMES != 0 && INTERIOR && CS >= 5 && CS <= 8 && (NP == 3 || NP == 4);
+    constexpr bool kWhole = AW_WHOLE_FRAMES != 0 && INTERIOR && CS >= 5 && (NP == 3 || NP == 4);    // also both passes of the wide layouts
     float raw[16][kBatchCh];
     float raw_b[kWhole ? 16 : 1][kBatchCh];
     {
