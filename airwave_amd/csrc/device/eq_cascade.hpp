@@ -10,9 +10,10 @@
 //     filter, (1) runs the biquad from a ZERO state over its chunk (zero-state response) and keeps
 //     the end state e[c]; (2) the true state entering chunk c obeys s[c+1] = P s[c] + e[c] with
 //     P = M^kEqChunk (M = the filter's zero-input state matrix [[-a1, 1], [-a2, 0]]), a linear
-//     recurrence over chunks that is solved with a two-level scan: Hillis-Steele inside each wave
-//     with the precomputed powers P^(2^j) (wave-private LDS slots, no workgroup barrier), then the
-//     four wave totals are chained with P^64 and applied per lane with P^lane (one barrier);
+//     recurrence over chunks that is solved with a two-level scan: inside each wave in registers
+//     (DPP moves: rows of 16 lanes with the precomputed powers P^1..P^8, then the row totals with the
+//     per-lane powers P^(m+1); no LDS, no branches), then the four wave totals are chained with P^64
+//     through LDS and applied per lane with P^(lane+1) (one barrier);
 //     (3) the zero-input response of s[c] is added to the chunk: y[j] += (M^j s[c])_1;
 //   * the state after the last chunk is carried to the next span / the next call.
 //
@@ -34,22 +35,22 @@ namespace awk {
 
 constexpr int kEqThreads = 256;
 #ifndef AW_EQ_CHUNK
-#define AW_EQ_CHUNK 16
+#define AW_EQ_CHUNK 32
 #endif
 constexpr int kEqChunk = AW_EQ_CHUNK;            // frames per thread and span (power of two)
-constexpr int kEqSpan = kEqThreads * kEqChunk;   // 4096 frames
+constexpr int kEqSpan = kEqThreads * kEqChunk;   // 8192 frames
+#ifndef AW_EQ_PREFETCH
+#define AW_EQ_PREFETCH 0                         // 1: the next span's loads are issued before the filter loop (kEqChunk x E more VGPRs; no faster at 16, spills at 32)
+#endif
 constexpr int kEqMaxFilters = 64;                // ParametricEqualizerState.maximumFilterCount :17
 constexpr int kEqScanSteps = 7;                  // P^(2^s), s = 0 .. 6 (6 = one whole wave of chunks)
 // LDS map (bytes)
-#ifndef AW_EQ_STAGE_EARS
-#define AW_EQ_STAGE_EARS 2       // 1: stage sized for the per-ear workgroups only (tuning builds with bigger chunks)
-#endif
-constexpr int kEqStageBytes = ((kEqThreads * (kEqChunk * AW_EQ_STAGE_EARS + (AW_EQ_STAGE_EARS == 2 ? 4 : 1)) * 4 + 15) / 16) * 16;   // 36,864: [chunk][32 + 4] floats (both ears)
-constexpr int kEqScanBytes = 4 * kEqThreads * 8;                          // [4][thread] double (component-major: conflict-free 8-B accesses)
+constexpr int eq_stage_bytes(int ears) { return ((kEqThreads * (kEqChunk * ears + (ears == 2 ? 4 : 1)) * 4 + 15) / 16) * 16; }   // [chunk][64 + 4] floats (both ears: 69,632) or [chunk][32 + 1] (one: 33,792)
 constexpr int kEqTotalsBytes = 2 * (kEqThreads / 64) * 4 * 8;             // ping-pong [wave][4]
 constexpr int kEqCarryBytes = 2 * kEqMaxFilters * 4 * 8;                  // ping-pong [filter][4]
-constexpr int kEqLdsBytes = kEqStageBytes + kEqScanBytes + kEqTotalsBytes + kEqCarryBytes;   // 49,408
-constexpr int kEqTabDoubles = 5 + kEqChunk * 2 + kEqScanSteps * 4;        // 65 per filter
+constexpr int eq_lds_bytes(int ears) { return eq_stage_bytes(ears) + kEqTotalsBytes + kEqCarryBytes; }   // 73,984 / 38,144: two workgroups per CU / four
+constexpr int kEqLdsBytes = eq_lds_bytes(2);
+constexpr int kEqTabDoubles = 5 + kEqChunk * 2 + kEqScanSteps * 4;        // 97 per filter
 
 // Per-state tables, built on the host in double (host/eq.cpp).
 struct EqTables {
@@ -57,10 +58,10 @@ struct EqTables {
     // kernel takes the pointer as a `const __restrict__` argument, so hipcc issues scalar loads (s_load) and the
     // values reach the FMAs as SGPR operands — no LDS or VGPR traffic for them:
     //   [0,5)   b0 b1 b2 a1 a2 (normalised by a0)
-    //   [5,37)  row 0 of M^j, j = 0 .. kEqChunk-1          (zero-input response)
-    //   [37,65) P^(2^s), s = 0 .. 6, P = M^kEqChunk, row-major 2x2
+    //   [5,69)  row 0 of M^j, j = 0 .. kEqChunk-1          (zero-input response)
+    //   [69,97) P^(2^s), s = 0 .. 6, P = M^kEqChunk, row-major 2x2 (the kernel uses s = 0 .. 3 and 6)
     const double *tab;
-    const double *plane;  // [K][64][4]  P^lane, lane = 0 .. 63 (per-lane: vector loads)
+    const double *plane;  // [K][64][4]  P^(m+1), m = 0 .. 63 (per-lane: vector loads)
     double preamp;        // 10^(dB/20)
     int n_filters;
 };
@@ -89,30 +90,41 @@ template <int E> AW_HD void eq_apply(const double *P, const double (&q)[2 * E], 
     }
 }
 
-// scan slots: component c of thread t at scan[c * kEqThreads + t] (component-major: conflict-free 8-B accesses)
-template <int E> AW_HD void eq_put(double *scan, int t, const double (&v)[2 * E]) {
-#pragma unroll
-    for (int c = 0; c < 2 * E; ++c) scan[c * kEqThreads + t] = v[c];
-}
-template <int E> AW_HD void eq_get(const double *scan, int t, double (&q)[2 * E]) {
-#pragma unroll
-    for (int c = 0; c < 2 * E; ++c) q[c] = scan[c * kEqThreads + t];
-}
+template <int E> struct EqRaw;                    // what one lane loads per frame: both ears (8 B) or one (4 B)
+template <> struct EqRaw<2> {
+    typedef cf type;
+    static AW_HD cf zero() { return mk(0.f, 0.f); }
+    static AW_HD cf load(const float *q) { return *reinterpret_cast<const cf *>(q); }
+    static AW_HD void store(float *q, cf v) { *reinterpret_cast<cf *>(q) = v; }
+};
+template <> struct EqRaw<1> {
+    typedef float type;
+    static AW_HD float zero() { return 0.f; }
+    static AW_HD float load(const float *q) { return *q; }
+    static AW_HD void store(float *q, float v) { *q = v; }
+};
 
 // One workgroup walks one stream's timeline for E ears starting at ear0: E = 2 (both ears in every thread)
-// or E = 1 (a workgroup per (stream, ear): twice the waves in flight for small batches; the kernel is
-// latency bound — VALU 40 % busy at 2 waves/SIMD, rocprofv3 PMC — so occupancy is what it needs).
+// or E = 1 (a workgroup per (stream, ear): twice the waves in flight for small batches).
 // p.frames must be a multiple of kEqChunk.
+//
+// Memory: the span's frames are fetched with kEqChunk independent coalesced loads per lane that are all in flight at
+// once (a first version guarded and awaited every load separately: 16 serial round trips per span, 40 % of the kernel's
+// time); the second workgroup of the CU computes meanwhile.  The last, partial span takes the guarded form.
+// Scan: inside a wave the chunk recurrence is scanned in registers with DPP moves — row_shr:1/2/4/8 (rows of 16 lanes,
+// uniform powers P^1..P^8), then row_bcast:15 and row_bcast:31 with the per-lane powers P^(m+1) — no LDS round trips,
+// no branches; only the four wave totals go through LDS (one barrier per filter).
 template <class Ctx, int E> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParams &p, long long stream, int ear0) {
     constexpr int S = 2 * E;                     // state doubles per filter handled here
+    typedef EqRaw<E> Raw;
+    typedef typename Raw::type raw_t;
     const int tid = ctx.tid();
     const int lane = tid & 63;
     char *lds = reinterpret_cast<char *>(ctx.lds());
     float *stage = reinterpret_cast<float *>(lds);                         // [chunk][kEqChunk * E + pad] floats
-    double *scan = reinterpret_cast<double *>(lds + kEqStageBytes);
-    double *totals = reinterpret_cast<double *>(lds + kEqStageBytes + kEqScanBytes);
-    double *carry = reinterpret_cast<double *>(lds + kEqStageBytes + kEqScanBytes + kEqTotalsBytes);
-    constexpr int kStride = kEqChunk * E + (E == 2 ? 4 : 1);               // floats per chunk row: 36 (16-B units) / 17
+    double *totals = reinterpret_cast<double *>(lds + eq_stage_bytes(E));
+    double *carry = reinterpret_cast<double *>(lds + eq_stage_bytes(E) + kEqTotalsBytes);
+    constexpr int kStride = kEqChunk * E + (E == 2 ? 4 : 1);               // floats per chunk row: 68 (16-B units) / 33
     const int wave = ctx.wave();
     const int K = p.t.n_filters;
     double *zs = p.z + stream * (long long)K * 4 + ear0 * 2;               // [K][4]: this workgroup's S of every 4
@@ -123,23 +135,33 @@ template <class Ctx, int E> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParam
     for (int i = tid; i < K * S; i += kEqThreads) carry[i] = zs[(i / S) * 4 + (i % S)];
     int par = 0;
 
+    raw_t raw[kEqChunk];
+    auto fetch = [&](long long base, int nfr) {
+        if (nfr == kEqSpan) {
+#pragma unroll
+            for (int j = 0; j < kEqChunk; ++j) raw[j] = Raw::load(in + (base + j * kEqThreads + tid) * 2);
+        } else {
+#pragma unroll
+            for (int j = 0; j < kEqChunk; ++j) {
+                const int f = j * kEqThreads + tid;
+                raw[j] = Raw::zero();
+                if (f < nfr) raw[j] = Raw::load(in + (base + f) * 2);
+            }
+        }
+    };
+    auto span_frames = [&](long long base) { const long long rem = p.frames - base; return rem < kEqSpan ? (int)rem : kEqSpan; };
+    if (AW_EQ_PREFETCH && p.frames > 0) fetch(0, span_frames(0));
+
     for (long long base = 0; base < p.frames; base += kEqSpan) {
-        const long long rem = p.frames - base;
-        const int nfr = rem < kEqSpan ? (int)rem : kEqSpan;
+        const int nfr = span_frames(base);
         const int nchunks = nfr / kEqChunk;
+        if (!AW_EQ_PREFETCH) fetch(base, nfr);
         ctx.barrier();   // stage reads of the previous span and the carry writes are complete
-        // HBM -> LDS coalesced, LDS -> registers transposed to one chunk per thread
+        // registers -> LDS in frame order, LDS -> registers transposed to one chunk per thread
 #pragma unroll
         for (int j = 0; j < kEqChunk; ++j) {
             const int f = j * kEqThreads + tid;
-            float *dst = stage + (f / kEqChunk) * kStride + (f % kEqChunk) * E;
-            if constexpr (E == 2) {
-                cf v = mk(0.f, 0.f);
-                if (f < nfr) v = *reinterpret_cast<const cf *>(in + (base + f) * 2);
-                *reinterpret_cast<cf *>(dst) = v;
-            } else {
-                *dst = f < nfr ? in[(base + f) * 2] : 0.f;
-            }
+            Raw::store(stage + (f / kEqChunk) * kStride + (f % kEqChunk) * E, raw[j]);
         }
         ctx.barrier();
         double x[E][kEqChunk];
@@ -147,13 +169,17 @@ template <class Ctx, int E> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParam
         for (int j = 0; j < kEqChunk; ++j)
 #pragma unroll
             for (int e = 0; e < E; ++e) x[e][j] = (double)stage[tid * kStride + j * E + e] * preamp;   // :67-69
+        if (AW_EQ_PREFETCH && base + kEqSpan < p.frames) fetch(base + kEqSpan, span_frames(base + kEqSpan));              // lands during the filter loop
 
         for (int k = 0; k < K; ++k) {
             const double *c = p.t.tab + (long long)k * kEqTabDoubles;      // uniform: scalar loads
             const double b0 = c[0], b1 = c[1], b2 = c[2], na1 = -c[3], na2 = -c[4];
-            // this lane's power of P for step (2c): issued now, consumed after the chunk's recurrence
-            const double *plp = p.t.plane + ((long long)k * 64 + lane) * 4;
-            const double pl[4] = {plp[0], plp[1], plp[2], plp[3]};
+            const double *pp = c + 5 + kEqChunk * 2;
+            // this lane's powers of P: D[m] = P^(m+1).  Issued now, consumed after the chunk's recurrence
+            const double *dk = p.t.plane + (long long)k * 64 * 4;
+            double d16[4], d32[4], d64[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { d16[i] = dk[(lane & 15) * 4 + i]; d32[i] = dk[(lane & 31) * 4 + i]; d64[i] = dk[lane * 4 + i]; }
             // (1) zero-state response of this chunk, in place (:71-87 with z = 0)
             double st[S];
 #pragma unroll
@@ -162,31 +188,39 @@ template <class Ctx, int E> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParam
             for (int j = 0; j < ((AW_EQ_ABL & 1) ? 1 : kEqChunk); ++j)
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    const double lo = __builtin_fma(b0, x[e][j], st[2 * e]);
-                    st[2 * e] = __builtin_fma(na1, lo, __builtin_fma(b1, x[e][j], st[2 * e + 1]));
-                    st[2 * e + 1] = __builtin_fma(na2, lo, b2 * x[e][j]);
-                    x[e][j] = lo;
+                    // the output is the LAST reader of the input and takes its register (no copies at the loop's back edge)
+                    const double t1 = __builtin_fma(b1, x[e][j], st[2 * e + 1]), t2 = b2 * x[e][j];
+                    ctx.fma_in_place(x[e][j], b0, st[2 * e], t1, t2);      // x = b0 x + st, after t1 and t2
+                    st[2 * e] = __builtin_fma(na1, x[e][j], t1);
+                    st[2 * e + 1] = __builtin_fma(na2, x[e][j], t2);
                 }
-            const double *pp = c + 5 + kEqChunk * 2;
-            double end[S];
+            // (2a) inclusive scan of s[c+1] = P s[c] + e[c] inside the wave, in registers.  Rows of 16 lanes first
+            // (lanes that have no partner d lanes below in their row receive zeros) ...
+            double q[S];
+            if (!(AW_EQ_ABL & 2)) {
 #pragma unroll
-            for (int i = 0; i < S; ++i) end[i] = st[i];
-            // (2a) inclusive Hillis-Steele scan INSIDE each wave (d = 1 .. 32) through wave-private slots
+                for (int i = 0; i < S; ++i) q[i] = ctx.template row_shr<1>(st[i]);
+                eq_apply<E>(pp + 0, q, st);
 #pragma unroll
-            for (int s = 0; s < ((AW_EQ_ABL & 2) ? 1 : 6); ++s) {
-                const int d = 1 << s;
-                eq_put<E>(scan, tid, st);
-                ctx.wave_sync();
-                if (lane >= d) {
-                    double q[S];
-                    eq_get<E>(scan, tid - d, q);
-                    eq_apply<E>(pp + s * 4, q, st);
-                }
-                ctx.wave_sync();
+                for (int i = 0; i < S; ++i) q[i] = ctx.template row_shr<2>(st[i]);
+                eq_apply<E>(pp + 4, q, st);
+#pragma unroll
+                for (int i = 0; i < S; ++i) q[i] = ctx.template row_shr<4>(st[i]);
+                eq_apply<E>(pp + 8, q, st);
+#pragma unroll
+                for (int i = 0; i < S; ++i) q[i] = ctx.template row_shr<8>(st[i]);
+                eq_apply<E>(pp + 12, q, st);
+                // ... then rows 1 and 3 take the total of the row below (its lane 15) times P^(lane % 16 + 1), and rows 2
+                // and 3 the running total at lane 31 times P^(lane - 31); the other rows receive zeros
+#pragma unroll
+                for (int i = 0; i < S; ++i) q[i] = ctx.row_bcast15(st[i]);
+                eq_apply<E>(d16, q, st);
+#pragma unroll
+                for (int i = 0; i < S; ++i) q[i] = ctx.row_bcast31(st[i]);
+                eq_apply<E>(d32, q, st);
             }
-            // wave totals -> LDS (ping-pong by filter parity), exclusive in-wave value from lane - 1
+            // wave totals -> LDS (ping-pong by filter parity)
             double *tot = totals + (k & 1) * (kEqThreads / 64) * 4;
-            eq_put<E>(scan, tid, st);
             if (lane == 63) {
 #pragma unroll
                 for (int i = 0; i < S; ++i) tot[wave * 4 + i] = st[i];
@@ -197,27 +231,31 @@ template <class Ctx, int E> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParam
             double w[S];
 #pragma unroll
             for (int i = 0; i < S; ++i) w[i] = cin[i];
-            for (int i = 0; i < ((AW_EQ_ABL & 4) ? 0 : wave); ++i) {
-                double n[S];
+            if (!(AW_EQ_ABL & 4)) {
+                double tw[kEqThreads / 64 - 1][S];     // all totals are read at once (one LDS latency), then chained
 #pragma unroll
-                for (int m = 0; m < S; ++m) n[m] = tot[i * 4 + m];
-                eq_apply<E>(pp + 6 * 4, w, n);
+                for (int i = 0; i < kEqThreads / 64 - 1; ++i)
 #pragma unroll
-                for (int m = 0; m < S; ++m) w[m] = n[m];
+                    for (int m = 0; m < S; ++m) tw[i][m] = tot[i * 4 + m];
+#pragma unroll
+                for (int i = 0; i < kEqThreads / 64 - 1; ++i)
+                    if (i < wave) {                    // wave-uniform
+                        eq_apply<E>(pp + 6 * 4, w, tw[i]);
+#pragma unroll
+                        for (int m = 0; m < S; ++m) w[m] = tw[i][m];
+                    }
             }
-            // (2c) state entering this chunk: in-wave exclusive prefix + P^lane W_w
-            double sin_[S];
-#pragma unroll
-            for (int i = 0; i < S; ++i) sin_[i] = 0.0;
-            if (lane > 0) eq_get<E>(scan, tid - 1, sin_);
-            eq_apply<E>(pl, w, sin_);
+            // (2c) state leaving this chunk = in-wave inclusive prefix + P^(lane + 1) W_w; the state entering it is the
+            // one leaving the lane below (lane 0: W_w itself)
+            eq_apply<E>(d64, w, st);
             if (tid == nchunks - 1) {   // state after the last active chunk -> next span / next call
                 double *cout = carry + (par ^ 1) * kEqMaxFilters * 4 + k * S;
-                eq_apply<E>(pp, sin_, end);
 #pragma unroll
-                for (int i = 0; i < S; ++i) cout[i] = end[i];
+                for (int i = 0; i < S; ++i) cout[i] = st[i];
             }
-            ctx.wave_sync();   // the exclusive reads above precede the next filter's slot writes
+            double sin_[S];
+#pragma unroll
+            for (int i = 0; i < S; ++i) sin_[i] = ctx.wave_shr1(st[i], w[i]);
             // (3) zero-input response of the entering state
             const double *g = c + 5;
 #pragma unroll
@@ -229,18 +267,23 @@ template <class Ctx, int E> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParam
         }
         par = K ? par ^ 1 : par;
 
+        // each thread rewrites its own row of the stage (it was the only reader of it), then frame order -> HBM
 #pragma unroll
         for (int j = 0; j < kEqChunk; ++j)
 #pragma unroll
             for (int e = 0; e < E; ++e) stage[tid * kStride + j * E + e] = (float)x[e][j];   // :88-89
         ctx.barrier();
+        if (nfr == kEqSpan) {
 #pragma unroll
-        for (int j = 0; j < kEqChunk; ++j) {
-            const int f = j * kEqThreads + tid;
-            const float *src = stage + (f / kEqChunk) * kStride + (f % kEqChunk) * E;
-            if (f < nfr) {
-                if constexpr (E == 2) *reinterpret_cast<cf *>(out + (base + f) * 2) = *reinterpret_cast<const cf *>(src);
-                else out[(base + f) * 2] = *src;
+            for (int j = 0; j < kEqChunk; ++j) {
+                const int f = j * kEqThreads + tid;
+                Raw::store(out + (base + f) * 2, Raw::load(stage + (f / kEqChunk) * kStride + (f % kEqChunk) * E));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kEqChunk; ++j) {
+                const int f = j * kEqThreads + tid;
+                if (f < nfr) Raw::store(out + (base + f) * 2, Raw::load(stage + (f / kEqChunk) * kStride + (f % kEqChunk) * E));
             }
         }
     }

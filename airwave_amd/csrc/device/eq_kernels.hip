@@ -16,29 +16,46 @@ struct EqGpuCtx {
     __device__ __forceinline__ int wave() const { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
     __device__ __forceinline__ cf *lds() const { return lds_; }
     __device__ __forceinline__ void barrier() const { __syncthreads(); }
-    // exchanges inside one wave: LDS instructions of a wave execute in issue order, the fences only
-    // pin the compiler's ordering
-    __device__ __forceinline__ void wave_sync() const {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // Cross-lane moves of the in-register scan (two DPP v_mov_b32 per double).  Lanes without a source receive zero
+    // (row_shr: bound_ctrl; row_bcast: the rows outside the row mask keep the zero `old`).
+    template <int CTRL, int ROW_MASK, bool BOUND>
+    static __device__ __forceinline__ double dpp(double old, double v) {
+        const unsigned long long o = __builtin_bit_cast(unsigned long long, old), u = __builtin_bit_cast(unsigned long long, v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)u, CTRL, ROW_MASK, 0xf, BOUND);
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xf, BOUND);
+        return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
     }
+    // x = a x + c in x's own register (a tied operand): the filter loop carries the 2 x 16 samples in fixed registers, without
+    // it hipcc renames them in every filter and copies all 32 back at the loop's back edge.  `after0/1` only order the
+    // statement behind the other readers of the old x.
+    __device__ __forceinline__ void fma_in_place(double &x, double a, double c, double after0, double after1) const {
+        asm("v_fma_f64 %0, %1, %0, %2" : "+v"(x) : "s"(a), "v"(c), "v"(after0), "v"(after1));
+    }
+    template <int D> __device__ __forceinline__ double row_shr(double v) const { return dpp<0x110 + D, 0xf, true>(0.0, v); }   // lane - D of the same 16-lane row
+    __device__ __forceinline__ double row_bcast15(double v) const { return dpp<0x142, 0xa, false>(0.0, v); }   // rows 1, 3 <- lane 15 of the row below
+    __device__ __forceinline__ double row_bcast31(double v) const { return dpp<0x143, 0xc, false>(0.0, v); }   // rows 2, 3 <- lane 31
+    __device__ __forceinline__ double wave_shr1(double v, double fill) const { return dpp<0x138, 0xf, false>(fill, v); }   // lane - 1; lane 0 <- fill
 };
 
 }  // namespace
 
 // The tables come in as `const __restrict__` kernel arguments (not inside the struct): with a wave-uniform
 // index that is what lets hipcc read them with scalar loads.  in/out may alias (in place) and are not restrict.
-// E = 2: one workgroup per stream; E = 1: one per (stream, ear).
+// E = 2: one workgroup per stream, two waves per SIMD.  E = 1: one per (stream, ear), three waves per SIMD (<= 168 VGPRs,
+// 38 KB of LDS); workgroups b and b + 8 — the same XCD under the round-robin dispatch — take the two ears of one stream,
+// so the frames both of them load cross the fabric once.
 template <int E>
-__global__ void __launch_bounds__(kEqThreads, AW_EQ_WAVES) aw_eq_cascade_kernel(EqParams p, const double *__restrict__ tab,
-                                                                        const double *__restrict__ plane) {
+__global__ void __launch_bounds__(kEqThreads, E == 2 ? AW_EQ_WAVES : (kEqChunk <= 16 ? 4 : kEqChunk <= 32 ? 3 : 2)) aw_eq_cascade_kernel(EqParams p, const double *__restrict__ tab,
+                                                                                      const double *__restrict__ plane, int n_streams) {
     extern __shared__ __align__(16) unsigned char eq_lds[];
     EqGpuCtx ctx{reinterpret_cast<cf *>(eq_lds)};
     p.t.tab = tab;
     p.t.plane = plane;
     if constexpr (E == 2) eq_cascade_stream<EqGpuCtx, 2>(ctx, p, (long long)blockIdx.x, 0);
-    else eq_cascade_stream<EqGpuCtx, 1>(ctx, p, (long long)(blockIdx.x >> 1), (int)(blockIdx.x & 1));
+    else {
+        const int b = (int)blockIdx.x, stream = (b >> 4) * 8 + (b & 7);
+        if (stream < n_streams) eq_cascade_stream<EqGpuCtx, 1>(ctx, p, (long long)stream, (b >> 3) & 1);
+    }
 }
 
 __global__ void aw_eq_sequential_kernel(EqParams p, int n_streams) {
@@ -71,15 +88,15 @@ __global__ void aw_eq_copy_kernel(const float *__restrict__ src, long long src_s
 
 hipError_t launch_eq_cascade(const EqParams &p, int n_streams, hipStream_t stream) {
     if (n_streams <= 0 || p.frames <= 0) return hipSuccess;
-    // split the ears over two workgroups while one workgroup per stream leaves CUs idle (measured: 128 streams
-    // 2.84 -> 2.25 ms; at 512 streams the unsplit kernel wins, 7.1 vs 9.8 ms: the split reads every line twice
-    // and halves each thread's independent FMA chains)
+    // split the ears over two workgroups while the per-ear grid still fits the CUs in one round (three workgroups per CU):
+    // 128 streams 2.34 -> 1.76 ms, 384 streams 3.80 -> 3.42 ms; 448 streams 3.92 vs 4.53 ms and 512 streams 4.14 vs 4.61 ms
+    // the other way (tools/ab_eq_split.sh)
     const int cus = p.cus > 0 ? p.cus : 256, force = p.ear_split;       // from the context (read once at its creation)
-    const bool split = force >= 0 ? force != 0 : 2 * n_streams < 3 * cus;
+    const bool split = force >= 0 ? force != 0 : 2 * n_streams <= 3 * cus;
     if (split)
-        hipLaunchKernelGGL(aw_eq_cascade_kernel<1>, dim3((unsigned)n_streams * 2), dim3(kEqThreads), kEqLdsBytes, stream, p, p.t.tab, p.t.plane);
+        hipLaunchKernelGGL(aw_eq_cascade_kernel<1>, dim3((unsigned)((n_streams + 7) / 8) * 16), dim3(kEqThreads), eq_lds_bytes(1), stream, p, p.t.tab, p.t.plane, n_streams);
     else
-        hipLaunchKernelGGL(aw_eq_cascade_kernel<2>, dim3((unsigned)n_streams), dim3(kEqThreads), kEqLdsBytes, stream, p, p.t.tab, p.t.plane);
+        hipLaunchKernelGGL(aw_eq_cascade_kernel<2>, dim3((unsigned)n_streams), dim3(kEqThreads), eq_lds_bytes(2), stream, p, p.t.tab, p.t.plane, n_streams);
     return hipGetLastError();
 }
 

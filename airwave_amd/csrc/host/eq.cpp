@@ -318,9 +318,9 @@ int eq_prepare(const EqDefinition *def, double fs, EqPrepared &out, int *bad_ind
         }
         double P[4] = {Mj[0], Mj[1], Mj[2], Mj[3]};   // M^chunk
         double Pl[4] = {1, 0, 0, 1};
-        for (int l = 0; l < 64; ++l) {
-            std::memcpy(&out.plane[((size_t)k * 64 + l) * 4], Pl, sizeof(Pl));
+        for (int l = 0; l < 64; ++l) {          // entry m holds P^(m+1)
             mat2_mul(P, Pl, Pl);
+            std::memcpy(&out.plane[((size_t)k * 64 + l) * 4], Pl, sizeof(Pl));
         }
         for (int s = 0; s < awk::kEqScanSteps; ++s) {
             std::memcpy(&ppow[s * 4], P, sizeof(P));

@@ -38,7 +38,7 @@ bool eq_parse(const void *data, size_t len, EqDefinition &def, std::vector<EqIss
 // ParametricEqualizerProcessor.prepare :168-212 plus the kernel's scan tables.
 struct EqPrepared {
     std::vector<double> tab;    // [K][65]: coef 5 | zero-input rows chunk x 2 | P powers steps x 4  (device/eq_cascade.hpp EqTables)
-    std::vector<double> plane;  // [K][64][4]
+    std::vector<double> plane;  // [K][64][4]  P^(m+1)
     double preamp = 1.0;
     int n_filters = 0;
 };

@@ -72,6 +72,20 @@ struct EmuCtx {
         sh->wave[tid_ >> 6]->arrive_and_wait();
         return r;
     }
+    // in-register scan moves of eq_cascade.hpp (DPP on the GPU): value of another lane of the wave, or zero / fill
+    double lane_value(double v, int src_lane, double otherwise) const {     // src_lane < 0: no source
+        double *box = reinterpret_cast<double *>(&sh->xs[(size_t)tid_ * 2]);
+        *box = v;
+        sh->wave[tid_ >> 6]->arrive_and_wait();
+        const double r = src_lane < 0 ? otherwise : *reinterpret_cast<const double *>(&sh->xs[(size_t)((tid_ & ~63) + src_lane) * 2]);
+        sh->wave[tid_ >> 6]->arrive_and_wait();
+        return r;
+    }
+    void fma_in_place(double &x, double a, double c, double, double) const { x = __builtin_fma(a, x, c); }
+    template <int D> double row_shr(double v) const { const int l = tid_ & 63; return lane_value(v, (l & 15) >= D ? l - D : -1, 0.0); }
+    double row_bcast15(double v) const { const int l = tid_ & 63; return lane_value(v, ((l >> 4) & 1) ? (l & ~15) - 1 : -1, 0.0); }
+    double row_bcast31(double v) const { const int l = tid_ & 63; return lane_value(v, l >= 32 ? 31 : -1, 0.0); }
+    double wave_shr1(double v, double fill) const { const int l = tid_ & 63; return lane_value(v, l > 0 ? l - 1 : -1, fill); }
     // sibling flags: the emulation runs workgroups one after the other, the even-bin one first
     void flag_release(int *flag, int epoch) const { sh->wg.arrive_and_wait(); if (tid_ == 0) *flag = epoch; }
     awk::cf ld_out(const float *q) const { return *reinterpret_cast<const awk::cf *>(q); }

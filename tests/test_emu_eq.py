@@ -23,7 +23,7 @@ def _oracle_run(oracle, fs, preamp, filters, calls):
 
 
 @pytest.mark.parametrize("ear_split", [False, True])
-@pytest.mark.parametrize("frames", [5, 16, 31, 4096, 4096 + 16 * 3 + 7, 2 * 4096 + 16])
+@pytest.mark.parametrize("frames", [5, 32, 63, 8192, 8192 + 32 * 3 + 7, 2 * 8192 + 32])
 def test_cascade_matches_sequential_recurrence(oracle, frames, ear_split):
     rng = np.random.default_rng(frames)
     x = rng.uniform(-0.5, 0.5, (2, frames, 2)).astype(np.float32)
@@ -33,7 +33,7 @@ def test_cascade_matches_sequential_recurrence(oracle, frames, ear_split):
     e, e2 = _oracle_run(oracle, 48000.0, -2.56, FILTERS, [x, x2])
     # Float64 reassociation only: at most 1 ulp of the Float32 output
     assert np.max(np.abs(y - e)) <= 6e-8 and np.max(np.abs(y2 - e2)) <= 6e-8
-    if frames < 16:
+    if frames < 32:
         assert np.array_equal(y, e)                                 # the sequential kernel is the recurrence itself
 
 

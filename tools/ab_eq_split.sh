@@ -1,4 +1,5 @@
+# A/B of one workgroup per stream (E = 2) against one per (stream, ear) (E = 1): tools/ab_eq_split.sh [streams ...]
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_eq.py -x -q -m gpu 2>&1 | tail -1
-for split in 0 1; do for n in "128 480000" "512 960000" "2048 240000"; do echo -n "split=$split $n: "; AW_EQ_EAR_SPLIT=$split python tools/eq_probe.py $n 2>/dev/null | tail -1; done; done
-AW_EQ_EAR_SPLIT=1 python -m pytest tests/test_gpu_eq.py -x -q -m gpu 2>&1 | tail -1
+for S in ${@:-128 256 384 512 1024}; do for sp in 0 1; do
+  echo -n "streams=$S split=$sp: "; AW_EQ_EAR_SPLIT=$sp python tools/eq_probe.py $S 960000 2>/dev/null | tail -1
+done; done

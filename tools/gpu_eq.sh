@@ -1,5 +1,7 @@
-#!/bin/bash
-# GPU check of the EQ row: tests, then timing of the cascade kernel on a cfg-4 shaped batch.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_eq.py -x -q -m gpu 2>&1 | tail -25
-timeout 300 python tools/eq_probe.py 2>&1 | tail -10
+# EQ kernel: GPU tests + timing probe at the cfg 4 shape and two other batch sizes
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_eq.py -x -q 2>&1 | tail -3
+python tools/eq_probe.py 512 960000 2>&1 | tail -1
+python tools/eq_probe.py 256 960000 2>&1 | tail -1
+python tools/eq_probe.py 128 960000 2>&1 | tail -1
+python tools/eq_probe.py 2048 240000 2>&1 | tail -1

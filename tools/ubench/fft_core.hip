@@ -36,6 +36,7 @@ __global__ void __launch_bounds__(kThreads) k_core(const cf *tw1, const cf *twa_
             else { fft16<false>(y); for (int k1 = 1; k1 < 16; ++k1) y[k1] = cmul(y[k1], pw[k1]); acc = acc + y[5]; }
         }
         if constexpr (!(VARIANT & 8)) ctx.barrier();
+        ctx.stagger(wave, 0);
         if constexpr (VARIANT & 2) { acc = acc + buf0[t]; continue; }      // no sub-FFTs
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -55,6 +56,44 @@ __global__ void __launch_bounds__(kThreads) k_core(const cf *tw1, const cf *twa_
     sink[blockIdx.x * kThreads + t] = acc;
 }
 }
+namespace awk {
+__global__ void __launch_bounds__(kThreads, 4) k_core1(const cf *tw1, const cf *twa_g, const cf *twb_g, cf *sink, int reps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
+    const int t = ctx.tid(), lane = ctx.lane(), wave = ctx.wave();
+    cf *buf0 = ctx.lds(), *twa = buf0 + kBufElems, *twb = twa + kTwaElems;
+    const cf w1 = tw1[t];
+    twa[t] = twa_g[t];
+    if (t < kTwbElems) twb[t] = twb_g[t];
+    cf x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = mk(0.001f * (t + j), 0.002f * (t - j));
+    cf acc = mk(0.f, 0.f);
+    for (int r = 0; r < reps; ++r) {
+        if (r > 0) ctx.barrier();
+        {
+            cf pw[16];
+            tw_powers(ctx.opaque(w1), pw);
+            cf y[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) y[j] = x[j];
+            pair_pass1(y, pw, buf0, t);
+        }
+        ctx.barrier();
+        cf *row0 = buf0 + wave_row(wave, 0) * kRowStride;
+        cf *row1 = buf0 + wave_row(wave, 1) * kRowStride;
+        cf z[2][8];
+        ctx.template ld8x2<64>(z[0], row0 + lane, z[1], row1 + lane);
+        ctx.wave_sync();
+        sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) { acc = acc + z[0][kc]; acc = acc + z[1][kc]; }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j].x += 1e-6f * acc.x;
+    }
+    sink[blockIdx.x * kThreads + t] = acc;
+}
+}
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 int main() {
     using namespace awk;
@@ -63,7 +102,7 @@ int main() {
     for (int ka = 0; ka < 8; ++ka) for (int l = 0; l < 64; ++l) twa[ka * 64 + l] = mk(cosf(-2 * 3.14159265f * l * ka / 512), sinf(-2 * 3.14159265f * l * ka / 512));
     for (int kb = 0; kb < 8; ++kb) for (int l = 0; l < 8; ++l) twb[kb * 8 + l] = mk(cosf(-2 * 3.14159265f * l * kb / 64), sinf(-2 * 3.14159265f * l * kb / 64));
     cf *d1, *da, *db, *sink;
-    CK(hipMalloc((void **)&d1, 512 * 8)); CK(hipMalloc((void **)&da, 512 * 8)); CK(hipMalloc((void **)&db, 64 * 8)); CK(hipMalloc((void **)&sink, 256 * 512 * 8));
+    CK(hipMalloc((void **)&d1, 512 * 8)); CK(hipMalloc((void **)&da, 512 * 8)); CK(hipMalloc((void **)&db, 64 * 8)); CK(hipMalloc((void **)&sink, 1024 * 512 * 8));
     CK(hipMemcpy(d1, tw1.data(), 512 * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(da, twa.data(), 512 * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(db, twb.data(), 64 * 8, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int reps = 200;
@@ -80,6 +119,20 @@ int main() {
         printf("%-44s %.3f us per pair transform per CU\n", name, best * 1e3 / (2.0 * reps));
     };
     run(k_core<0>, "full (pass 1 + barrier + sub-FFTs)");
+    {   // one pair per barrier interval, 78 KB of LDS, two workgroups per CU (512 workgroups, REPS transforms each)
+        (void)hipFuncSetAttribute((const void *)k_core1, hipFuncAttributeMaxDynamicSharedMemorySize, kInvLdsBytes);
+        for (int wgs : {256, 512}) {
+            float best = 1e9f;
+            for (int it = 0; it < 3; ++it) {
+                (void)hipEventRecord(e0);
+                hipLaunchKernelGGL(k_core1, dim3(wgs), dim3(kThreads), kInvLdsBytes, 0, d1, da, db, sink, reps);
+                (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+                float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+                best = ms < best ? ms : best;
+            }
+            printf("one pair per interval, %d workgroups (%d per CU): %.3f us per pair transform per CU\n", wgs, wgs / 256, best * 1e3 / (reps * (wgs / 256.0)));
+        }
+    }
     run(k_core<1>, "pass 1 without its LDS scatter");
     run(k_core<2>, "no sub-FFTs (pass 1 + barriers only)");
     run(k_core<3>, "butterflies of pass 1 only");
