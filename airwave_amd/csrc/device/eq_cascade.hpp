@@ -39,6 +39,9 @@ constexpr int kEqThreads = 256;
 #endif
 constexpr int kEqChunk = AW_EQ_CHUNK;            // frames per thread and span (power of two)
 constexpr int kEqSpan = kEqThreads * kEqChunk;   // 8192 frames
+#ifndef AW_EQ_COEF_AHEAD
+#define AW_EQ_COEF_AHEAD 0                       // 1: coefficient tables fetched one filter ahead (50 more SGPRs: spills, 3 % slower)
+#endif
 #ifndef AW_EQ_PREFETCH
 #define AW_EQ_PREFETCH 0                         // 1: the next span's loads are issued before the filter loop (kEqChunk x E more VGPRs; no faster at 16, spills at 32)
 #endif
@@ -171,10 +174,27 @@ template <class Ctx, int E> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParam
             for (int e = 0; e < E; ++e) x[e][j] = (double)stage[tid * kStride + j * E + e] * preamp;   // :67-69
         if (AW_EQ_PREFETCH && base + kEqSpan < p.frames) fetch(base + kEqSpan, span_frames(base + kEqSpan));              // lands during the filter loop
 
+        // the filter's coefficients and scan powers (25 wave-uniform doubles) come in ONE batch of scalar loads at the top of
+        // its iteration (left to itself hipcc loads the scan powers where they are used: two more stalls per filter)
+        double ck[5], pk[20];
+        auto fetch_coefs = [&](int k) {
+            const double *c = p.t.tab + (long long)k * kEqTabDoubles;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) ck[i] = c[i];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pk[i] = c[5 + kEqChunk * 2 + i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pk[16 + i] = c[5 + kEqChunk * 2 + 6 * 4 + i];
+        };
+        if (AW_EQ_COEF_AHEAD && K > 0) fetch_coefs(0);
         for (int k = 0; k < K; ++k) {
             const double *c = p.t.tab + (long long)k * kEqTabDoubles;      // uniform: scalar loads
-            const double b0 = c[0], b1 = c[1], b2 = c[2], na1 = -c[3], na2 = -c[4];
-            const double *pp = c + 5 + kEqChunk * 2;
+            if (!AW_EQ_COEF_AHEAD) fetch_coefs(k);
+            const double b0 = ck[0], b1 = ck[1], b2 = ck[2], na1 = -ck[3], na2 = -ck[4];
+            double pp[20];
+#pragma unroll
+            for (int i = 0; i < 20; ++i) pp[i] = pk[i];
+            if (AW_EQ_COEF_AHEAD) fetch_coefs(k + 1 < K ? k + 1 : k);
             // this lane's powers of P: D[m] = P^(m+1).  Issued now, consumed after the chunk's recurrence
             const double *dk = p.t.plane + (long long)k * 64 * 4;
             double d16[4], d32[4], d64[4];
@@ -240,7 +260,7 @@ template <class Ctx, int E> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParam
 #pragma unroll
                 for (int i = 0; i < kEqThreads / 64 - 1; ++i)
                     if (i < wave) {                    // wave-uniform
-                        eq_apply<E>(pp + 6 * 4, w, tw[i]);
+                        eq_apply<E>(pp + 16, w, tw[i]);
 #pragma unroll
                         for (int m = 0; m < S; ++m) w[m] = tw[i][m];
                     }

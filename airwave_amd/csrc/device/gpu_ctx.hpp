@@ -77,6 +77,8 @@ struct GpuCtx {
         r.x = __uint_as_float((unsigned)v);
         r.y = __uint_as_float((unsigned)(v >> 32));
         return r;
+#elif AW_LDS_ATOMIC_READS
+        return ld_single(p);
 #else
         return *p;
 #endif
@@ -87,6 +89,9 @@ struct GpuCtx {
     // a volatile access to stop the fusion turns into flat loads.  AW_ASM_LDS_READS=0: plain reads.
 #ifndef AW_ASM_LDS_READS
 #define AW_ASM_LDS_READS 0
+#endif
+#ifndef AW_LDS_ATOMIC_READS
+#define AW_LDS_ATOMIC_READS 0
 #endif
     template <int STRIDE>
     __device__ __forceinline__ void ld8x2(cf (&a)[8], const cf *p0, cf (&b)[8], const cf *p1) const {
@@ -113,10 +118,24 @@ struct GpuCtx {
         a[4] = mk(r4.x, r4.y); a[5] = mk(r5.x, r5.y); a[6] = mk(r6.x, r6.y); a[7] = mk(r7.x, r7.y);
         b[0] = mk(q0.x, q0.y); b[1] = mk(q1.x, q1.y); b[2] = mk(q2.x, q2.y); b[3] = mk(q3.x, q3.y);
         b[4] = mk(q4.x, q4.y); b[5] = mk(q5.x, q5.y); b[6] = mk(q6.x, q6.y); b[7] = mk(q7.x, q7.y);
+#elif AW_LDS_ATOMIC_READS
+        // relaxed wavefront-scope atomic loads: still ds_read_b64, but SILoadStoreOptimizer leaves atomics alone (no read2 fusion)
+        // and the compiler keeps placing the waits itself
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a[i] = ld_single(p0 + i * STRIDE); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { b[i] = ld_single(p1 + i * STRIDE); }
 #else
 #pragma unroll
         for (int i = 0; i < 8; ++i) { a[i] = p0[i * STRIDE]; b[i] = p1[i * STRIDE]; }
 #endif
+    }
+    __device__ __forceinline__ cf ld_single(const cf *p) const {
+        const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        cf r;
+        r.x = __uint_as_float((unsigned)v);
+        r.y = __uint_as_float((unsigned)(v >> 32));
+        return r;
     }
     // Scheduling fence (no instruction): keeps hipcc from interleaving the two rows' butterflies,
     // which doubles their temporaries at the register-pressure peak.
