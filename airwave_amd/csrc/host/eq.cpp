@@ -271,11 +271,33 @@ bool eq_parse(const void *data, size_t len, EqDefinition &def, std::vector<EqIss
 }
 
 // ---- prepare ------------------------------------------------------------------------------------
-static void mat2_mul(const double *a, const double *b, double *c) {
-    const double r0 = a[0] * b[0] + a[1] * b[2], r1 = a[0] * b[1] + a[1] * b[3];
-    const double r2 = a[2] * b[0] + a[3] * b[2], r3 = a[2] * b[1] + a[3] * b[3];
-    c[0] = r0; c[1] = r1; c[2] = r2; c[3] = r3;
+// The kernel's tables are powers of M up to M^(64 chunk) = M^2048.  A low-frequency section's M is nearly defective
+// (a double pole next to z = 1: 20 Hz at 96 kHz is an angle of 1.3e-3), and products formed in double lose
+// n eps / angle^2 of their entries — 1e-7 at n = 2048, which reached the Float32 output (4.6 ulp of the peak on one of 12 000
+// randomised 64-filter scripts, tools/fuzz_eq.py).  The powers are therefore formed in double-double arithmetic
+// (error-free two_sum / two_prod, ~32 digits) and rounded once.
+struct DD { double hi, lo; };
+static inline DD dd_norm(double s, double e) { const double hi = s + e; return {hi, e - (hi - s)}; }
+static inline DD dd_add(DD x, DD y) {
+    const double s = x.hi + y.hi, bb = s - x.hi;
+    const double e = (x.hi - (s - bb)) + (y.hi - bb) + x.lo + y.lo;
+    return dd_norm(s, e);
 }
+static inline DD dd_mul(DD x, DD y) {
+    const double p = x.hi * y.hi;
+    const double e = std::fma(x.hi, y.hi, -p) + (x.hi * y.lo + x.lo * y.hi);
+    return dd_norm(p, e);
+}
+struct Mat2 { DD m[4]; };
+static Mat2 mat2_mul(const Mat2 &a, const Mat2 &b) {
+    Mat2 c;
+    c.m[0] = dd_add(dd_mul(a.m[0], b.m[0]), dd_mul(a.m[1], b.m[2]));
+    c.m[1] = dd_add(dd_mul(a.m[0], b.m[1]), dd_mul(a.m[1], b.m[3]));
+    c.m[2] = dd_add(dd_mul(a.m[2], b.m[0]), dd_mul(a.m[3], b.m[2]));
+    c.m[3] = dd_add(dd_mul(a.m[2], b.m[1]), dd_mul(a.m[3], b.m[3]));
+    return c;
+}
+static void mat2_store(const Mat2 &a, double *dst) { for (int i = 0; i < 4; ++i) dst[i] = a.m[i].hi + a.m[i].lo; }
 
 int eq_prepare(const EqDefinition *def, double fs, EqPrepared &out, int *bad_index, int *bad_kind) {
     if (!std::isfinite(fs) || !(fs > 0)) return kEqPrepInvalidSampleRate;                 // :172-174
@@ -309,22 +331,22 @@ int eq_prepare(const EqDefinition *def, double fs, EqPrepared &out, int *bad_ind
         cf[0] = c.b0; cf[1] = c.b1; cf[2] = c.b2; cf[3] = c.a1; cf[4] = c.a2;
         // zero-input state matrix of the transposed direct form II section (x = 0 in :71-77):
         //   z1' = -a1 z1 + z2,  z2' = -a2 z1,  y = z1
-        const double M[4] = {-c.a1, 1.0, -c.a2, 0.0};
-        double Mj[4] = {1, 0, 0, 1};
+        const Mat2 M{{{-c.a1, 0.0}, {1.0, 0.0}, {-c.a2, 0.0}, {0.0, 0.0}}};
+        Mat2 Mj{{{1.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {1.0, 0.0}}};
         for (int j = 0; j < awk::kEqChunk; ++j) {
-            zir[j * 2] = Mj[0];
-            zir[j * 2 + 1] = Mj[1];
-            mat2_mul(M, Mj, Mj);
+            zir[j * 2] = Mj.m[0].hi + Mj.m[0].lo;
+            zir[j * 2 + 1] = Mj.m[1].hi + Mj.m[1].lo;
+            Mj = mat2_mul(M, Mj);
         }
-        double P[4] = {Mj[0], Mj[1], Mj[2], Mj[3]};   // M^chunk
-        double Pl[4] = {1, 0, 0, 1};
+        Mat2 P = Mj;                                  // M^chunk
+        Mat2 Pl{{{1.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {1.0, 0.0}}};
         for (int l = 0; l < 64; ++l) {          // entry m holds P^(m+1)
-            mat2_mul(P, Pl, Pl);
-            std::memcpy(&out.plane[((size_t)k * 64 + l) * 4], Pl, sizeof(Pl));
+            Pl = mat2_mul(P, Pl);
+            mat2_store(Pl, &out.plane[((size_t)k * 64 + l) * 4]);
         }
         for (int s = 0; s < awk::kEqScanSteps; ++s) {
-            std::memcpy(&ppow[s * 4], P, sizeof(P));
-            mat2_mul(P, P, P);
+            mat2_store(P, &ppow[s * 4]);
+            P = mat2_mul(P, P);
         }
     }
     return kEqPrepOk;

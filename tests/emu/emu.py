@@ -92,3 +92,19 @@ def eq_process(x, sample_rate, preamp_db, filters, z=None, ear_split=False):
                               fl.ctypes.data_as(dp), K, int(ear_split))
     assert rc == K, rc
     return out, z
+
+
+def eq_tables(sample_rate, preamp_db, filters):
+    """Host-built tables of the EQ kernel: (tab [K][tab_doubles], plane [K][64][4], chunk)."""
+    fl = np.ascontiguousarray(np.asarray(filters, dtype=np.float64).reshape(-1, 4))
+    K = fl.shape[0]
+    dp = ctypes.POINTER(ctypes.c_double)
+    td, ch = ctypes.c_int(), ctypes.c_int()
+    rc = lib().emu_eq_tables(ctypes.c_double(sample_rate), ctypes.c_double(preamp_db), fl.ctypes.data_as(dp), K, None, None, ctypes.byref(td), ctypes.byref(ch))
+    assert rc == K, rc
+    tab = np.empty((K, td.value), np.float64)
+    plane = np.empty((K, 64, 4), np.float64)
+    rc = lib().emu_eq_tables(ctypes.c_double(sample_rate), ctypes.c_double(preamp_db), fl.ctypes.data_as(dp), K, tab.ctypes.data_as(dp), plane.ctypes.data_as(dp),
+                             ctypes.byref(td), ctypes.byref(ch))
+    assert rc == K, rc
+    return tab, plane, ch.value

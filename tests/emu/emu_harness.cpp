@@ -396,6 +396,28 @@ int emu_fft_small(float *data, int n, int inverse) {
     return 0;
 }
 
+// The host-built EQ tables of a filter set (awh::eq_prepare), for the table-precision test: tab [K][kEqTabDoubles],
+// plane [K][64][4].  Returns K (or a negative prepare error); *tab_doubles = kEqTabDoubles, *chunk = kEqChunk.
+int emu_eq_tables(double sample_rate, double preamp_db, const double *filters, int n_filters, double *tab, double *plane,
+                  int *tab_doubles, int *chunk) {
+    awh::EqDefinition def;
+    def.preamp_db = preamp_db;
+    for (int i = 0; i < n_filters; ++i) {
+        awh::EqFilter f;
+        f.type = (int)filters[i * 4]; f.frequency_hz = filters[i * 4 + 1]; f.gain_db = filters[i * 4 + 2]; f.q = filters[i * 4 + 3];
+        def.filters.push_back(f);
+    }
+    awh::EqPrepared prep;
+    int bi = 0, bk = 0;
+    const int rc = awh::eq_prepare(&def, sample_rate, prep, &bi, &bk);
+    if (rc) return -rc;
+    *tab_doubles = awk::kEqTabDoubles; *chunk = awk::kEqChunk;
+    if (tab) std::memcpy(tab, prep.tab.data(), prep.tab.size() * sizeof(double));
+    if (plane) std::memcpy(plane, prep.plane.data(), prep.plane.size() * sizeof(double));
+    return prep.n_filters;
+}
+
+
 // Parametric EQ cascade: one emulated workgroup (kEqThreads) per stream for the chunk-aligned part,
 // eq_sequential for the tail — the same split runtime.cpp makes.  filters: [n][4] = type, fc, gain, q.
 // z: [stream][K][4] state, carried in and out.  Returns K or a negative prepare error.

@@ -46,3 +46,55 @@ def test_unity_and_many_filters(oracle):
     y, _ = emu.eq_process(x, 96000.0, -6.0, many)
     (e,) = _oracle_run(oracle, 96000.0, -6.0, many, [x])
     assert np.max(np.abs(y - e)) <= 1e-6 * np.max(np.abs(e))
+
+
+def test_table_powers_are_exact_to_the_last_bit_or_two():
+    """The kernel's tables are powers of the zero-input state matrix M up to M^(64 chunk).  For a low-frequency section M is
+    nearly defective (a double pole next to z = 1) and powers formed in double lose n eps / angle^2 of their entries: 1e-7 at
+    n = 2048, which reached the Float32 output at the wave boundaries (4.6 ulp of the peak on a 64-filter script of
+    tools/fuzz_eq.py).  The host forms them in double-double; checked against exact rational arithmetic."""
+    from fractions import Fraction
+    filters = [(0, 20.0, 6.0, 6.0), (1, 23.0, 5.4, 2.49), (2, 31.0, -5.9, 4.7), (0, 45.0, 11.7, 1.7), (1, 400.0, -3.0, 0.7), (2, 9000.0, 4.0, 1.0)]
+    tab, plane, chunk = emu.eq_tables(96000.0, 0.0, filters)
+    for k in range(len(filters)):
+        a1, a2 = Fraction(float(tab[k, 3])), Fraction(float(tab[k, 4]))
+        M = ((-a1, Fraction(1)), (-a2, Fraction(0)))
+
+        def mul(a, b):
+            return ((a[0][0] * b[0][0] + a[0][1] * b[1][0], a[0][0] * b[0][1] + a[0][1] * b[1][1]),
+                    (a[1][0] * b[0][0] + a[1][1] * b[1][0], a[1][0] * b[0][1] + a[1][1] * b[1][1]))
+
+        def close(got, exact):
+            ex = np.array([[float(v) for v in row] for row in exact]).reshape(-1)
+            scale = max(np.max(np.abs(ex)), 1e-300)
+            assert np.max(np.abs(np.asarray(got).reshape(-1) - ex)) <= 4e-16 * scale, (k, np.asarray(got), ex)
+
+        Mj = ((Fraction(1), Fraction(0)), (Fraction(0), Fraction(1)))
+        for j in range(chunk):
+            ex = np.array([float(Mj[0][0]), float(Mj[0][1])])
+            assert np.max(np.abs(tab[k, 5 + 2 * j:7 + 2 * j] - ex)) <= 4e-16 * max(np.max(np.abs(ex)), 1e-300)
+            Mj = mul(M, Mj)
+        P = Mj
+        Pl = P
+        for m in range(64):                      # plane[m] = P^(m+1)
+            close(plane[k, m], Pl)
+            Pl = mul(P, Pl)
+        Ps = P
+        for s_ in range(7):                      # P^(2^s)
+            close(tab[k, 5 + 2 * chunk + 4 * s_:9 + 2 * chunk + 4 * s_], Ps)
+            Ps = mul(Ps, Ps)
+
+
+def test_low_frequency_sections_keep_full_precision(oracle):
+    """Sections with a double pole next to z = 1 (20-45 Hz at 96 kHz): the kernel's tables are powers of the state matrix up
+    to M^2048, which lose n eps / angle^2 when they are formed in double (4.6 ulp of the peak at the wave boundaries of a
+    64-filter script of tools/fuzz_eq.py, before the host formed them in double-double).  Three spans, so that carried
+    state crosses every wave boundary."""
+    rng = np.random.default_rng(77)
+    lows = [(int(i % 3), 20.0 + 3.1 * i, (11.5 if i % 2 else -10.5), 2.0 + 0.5 * (i % 8)) for i in range(8)]
+    frames = 2 * 8192 + 1500
+    x = rng.uniform(-0.5, 0.5, (1, frames, 2)).astype(np.float32)
+    y, _ = emu.eq_process(x, 96000.0, -3.0, lows)
+    (e,) = _oracle_run(oracle, 96000.0, -3.0, lows, [x])
+    peak = float(np.max(np.abs(e)))
+    assert np.max(np.abs(y - e)) <= 1.5 * 2.0 ** -23 * max(1.0, peak)

@@ -61,7 +61,11 @@ while time.time() < t_end:
                 for s, r in refs.items():
                     el, er = r.process(x[s, :, 0], x[s, :, 1])
                     scale = max(1.0, float(np.max(np.abs(el))), float(np.max(np.abs(er))))
-                    worst = max(worst, float(np.max(np.abs(y[s, :, 0] - el))) / scale, float(np.max(np.abs(y[s, :, 1] - er))) / scale)
+                    dev = max(float(np.max(np.abs(y[s, :, 0] - el))), float(np.max(np.abs(y[s, :, 1] - er)))) / scale
+                    if dev > 4 * ULP and os.environ.get("AW_FUZZ_TRACE"):
+                        i = int(np.argmax(np.abs(y[s, :, 0] - el)))
+                        print(f"TRACE call {len(script)} frames {m} stream {s}: dev {dev / ULP:.2f} ulp at frame {i}, peak {scale:.3g}, got {y[s, i, 0]!r} want {el[i]!r}", flush=True)
+                    worst = max(worst, dev)
         ok = worst <= 4 * ULP
     except Exception as e:                              # noqa: BLE001
         ok, worst = False, repr(e)
