@@ -147,7 +147,10 @@ static bool ols2_slp_layout(int C) { return C == 4 || C == 6 || C == 8; }      /
 #define AW_FOR_EACH_VEC(X) X(2, 1) X(4, 2) X(6, 3) X(7, 4) X(8, 4) X(12, 0) X(14, 0) X(16, 0)
 #define AW_FOR_EACH_GEN(X) X(1) X(2) X(3) X(4) X(0)
 // wide layouts (interior tiles): (channels, pairs of the first pass, pairs of the accumulating second pass)
-#define AW_FOR_EACH_WIDE(X) X(10, 4, 1) X(12, 4, 2) X(14, 4, 3) X(16, 4, 4)
+#define AW_FOR_EACH_WIDE(X) X(10, 4, 1) X(12, 4, 2) X(14, 4, 3) X(15, 4, 4) X(16, 4, 4)
+// 10-14 channels in one pass: (channels, pairs).  16 channels stay on two passes (one pass: 292 B of scratch per thread,
+// 13.5 against 13.9 G frames/s)
+#define AW_FOR_EACH_WIDE1(X) X(9, 5) X(10, 5) X(11, 6) X(12, 6) X(13, 7) X(14, 7)
 // boundary tiles of the common layouts keep whole-frame vector loads (history / zero-page selects per frame)
 #define AW_FOR_EACH_BVEC(X) X(2, 1) X(4, 2) X(8, 4)
 
@@ -165,7 +168,7 @@ hipError_t prepare_kernels(LaunchCfg *cfg) {
         // the persistent kernels deal tiles to 8 XCD groups (blockIdx % 8): a grid below 8 workgroups with more tiles than
         // workgroups would leave groups without a workgroup and their tiles uncomputed
         if (g_persistent_wgs < 8) g_persistent_wgs = 8;
-        if (const char *e3 = getenv("AW_WIDE_TWO_PASS")) cfg->wide_two_pass = atoi(e3) != 0;
+        if (const char *e3 = getenv("AW_WIDE_TWO_PASS")) cfg->wide_two_pass = atoi(e3) != 0;      // A/B: 1 = two passes, 0 = run-time loop
         if (const char *e4 = getenv("AW_OLSH_WGS_PER_CU")) cfg->olsh_wgs_per_cu = atoi(e4) > 0 ? atoi(e4) : 2;
         cfg->debug_occupancy = getenv("AW_DEBUG_OCCUPANCY") != nullptr;
         if (const char *e5 = getenv("AW_STAMP_THREAD")) cfg->stamp_thread = atoi(e5);
@@ -193,6 +196,7 @@ hipError_t prepare_kernels(LaunchCfg *cfg) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     AW_FOR_EACH_WIDE(AW_SET_WIDE)
 #undef AW_SET_WIDE
+    AW_FOR_EACH_WIDE1(AW_SET_VEC)
 #define AW_SET_GENACC(NP)                                                                                      \
     if (e == hipSuccess)                                                                                       \
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols_kernel<0, NP, false, true>),      \
@@ -269,7 +273,7 @@ hipError_t prepare_kernels(LaunchCfg *cfg) {
 }
 
 static bool has_vec_variant(int C) { return C == 2 || C == 4 || C == 6 || C == 7 || C == 8 || C == 12 || C == 14 || C == 16; }
-static bool has_fused_vec_variant(int C) { return has_vec_variant(C) || C == 10; }       // 10 channels: two-pass kernels only
+static bool has_fused_vec_variant(int C) { return has_vec_variant(C) || (C >= 9 && C <= 15); }       // 9, 10, 11, 13, 15 channels: the fused kernels only
 
 const char *fused_ols_kernel_name(int C) {
     switch (C) {
@@ -278,9 +282,13 @@ const char *fused_ols_kernel_name(int C) {
         case 6: return "aw_fused_ols_kernel<6, 3, true>";
         case 7: return "aw_fused_ols_kernel<7, 4, true>";
         case 8: return "aw_fused_ols_kernel<8, 4, true>";
-        case 10: return "aw_fused_ols_kernel<10, 4, true> + <10, 1, true, accumulate>";
-        case 14: return "aw_fused_ols_kernel<14, 4, true> + <14, 3, true, accumulate>";
-        case 12: return "aw_fused_ols_kernel<12, 4, true> + <12, 2, true, accumulate>";
+        case 9: return "aw_fused_ols_kernel<9, 5, true>";
+        case 10: return "aw_fused_ols_kernel<10, 5, true>";
+        case 11: return "aw_fused_ols_kernel<11, 6, true>";
+        case 12: return "aw_fused_ols_kernel<12, 6, true>";
+        case 13: return "aw_fused_ols_kernel<13, 7, true>";
+        case 14: return "aw_fused_ols_kernel<14, 7, true>";
+        case 15: return "aw_fused_ols_kernel<15, 4, true> + <15, 4, true, accumulate>";
         case 16: return "aw_fused_ols_kernel<16, 4, true> + <16, 4, true, accumulate>";
         default: return "aw_fused_ols_kernel<0, NP, false>";
     }
@@ -293,6 +301,14 @@ static dim3 persistent_grid(long long n_tiles, const TileParams &p) {
 
 static void launch_vec(const TileParams &p, long long n_tiles, hipStream_t stream) {
     const dim3 grid = persistent_grid(n_tiles, p), block(kThreads);
+    if (p.wide_two_pass == 2) {      // 10/12/14 channels in one pass over two eight-channel groups (the default)
+        switch (p.n_channels) {
+#define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_fused_ols_kernel<CS, NP, true>), grid, block, kLdsBytes, stream, p, n_tiles); return;
+            AW_FOR_EACH_WIDE1(AW_CASE)
+#undef AW_CASE
+            default: break;
+        }
+    }
     if (p.wide_two_pass || p.n_channels == 10) {
         // second pass: input and tables shifted by the first pass's 4 pairs (8 channels), result added to the output
         TileParams q = p;
@@ -359,7 +375,7 @@ hipError_t launch_fused_ols(const TileParams &p_in, int n_streams, hipStream_t s
     if (hi > p.tiles_per_stream) hi = p.tiles_per_stream;
     if (hi < lo) hi = lo;
     if (lo > p.tiles_per_stream) { lo = p.tiles_per_stream; hi = lo; }
-    if (!has_fused_vec_variant(p.n_channels)) { lo = 0; hi = 0; }  // everything through the generic kernels
+    if (!has_fused_vec_variant(p.n_channels) || (p.wide_two_pass != 2 && p.n_channels > 8 && (p.n_channels & 1))) { lo = 0; hi = 0; }  // everything through the generic kernels
     p.tile_lo = (int)lo; p.tile_hi = (int)hi;
     const long long n_int = (long long)n_streams * (hi - lo);
     const long long n_bnd = (long long)n_streams * (p.tiles_per_stream - (hi - lo));

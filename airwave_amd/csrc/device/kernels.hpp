@@ -59,7 +59,7 @@ hipError_t launch_deinterleave2(const float *src, float *left, float *right, int
 struct LaunchCfg {
     int cus = 256;                // compute units of the context's device
     int persistent_wgs = 256;     // grid of the persistent tile kernels (AW_PERSISTENT_WGS; >= 8: the kernels deal tiles to 8 XCD groups)
-    int wide_two_pass = 1;        // 9-16 channels as two compile-time passes (AW_WIDE_TWO_PASS=0: the run-time-loop kernels)
+    int wide_two_pass = 2;        // 10/12/14 channels: 2 = one pass over two eight-channel groups (16: two passes), 1 = two compile-time passes (AW_WIDE_TWO_PASS=1), 0 = the run-time-loop kernels (AW_WIDE_TWO_PASS=0)
     int olsh_wgs_per_cu = 2;      // sibling-workgroup kernels (AW_OLSH_WGS_PER_CU)
     int debug_occupancy = 0;      // AW_DEBUG_OCCUPANCY
     int stamp_thread = 0;         // AW_STAMP_THREAD (diagnostic builds)

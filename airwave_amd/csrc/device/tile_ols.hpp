@@ -209,6 +209,7 @@ AW_HD void sub_fft512x2(Ctx &ctx, cf (&a)[2][8], cf *scr0, cf *scr1, const cf *t
 struct alignas(16) f4 { float x, y, z, w; };
 struct alignas(8) f2 { float x, y; };
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };   // 16 bytes at dword alignment
+struct __attribute__((packed, aligned(4))) f2u { float x, y; };    // 8 bytes at dword alignment
 
 // One interleaved frame -> registers (channels c0 .. c0+3, zero padded).  Frames before the call
 // come from the history buffer (previous calls' tail; zeros after create/reset), frames past the
@@ -295,7 +296,12 @@ AW_HD void load_batch(const TileParams &p, const float *in_s, const float *hist_
 #ifndef AW_WHOLE_FRAMES
 #define AW_WHOLE_FRAMES 1
 #endif
-template <int CS>
+#ifndef AW_WIDE_LATE_B
+#define AW_WIDE_LATE_B 0     // 1: the second batch of a wide layout's second channel group is fetched one pair later (measured: 14 channels 17.1 -> 15.9 G frames/s)
+#endif
+// SECOND: floats of the second batch that are fetched — 4 (all), 2 (a seventh pair is the group's last: 13-14 channels) or
+// 0 (9-12 channels: the last eight-channel group has one batch).
+template <int CS, int SECOND = 4, bool FIRST = true>
 AW_HD void load_batch2(const float *in_s, long long f0, int t, float (&ra)[16][kBatchCh], float (&rb)[16][kBatchCh]) {
     static_assert(CS >= 5, "two batches of four channels (the first eight channels from the base pointer; wide layouts shift the base)");
     const float *lane_base = in_s + f0 * CS;            // uniform
@@ -303,16 +309,32 @@ AW_HD void load_batch2(const float *in_s, long long f0, int t, float (&ra)[16][k
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const float *src = lane_base + (long long)j * 512 * CS + lane_off;
-        if constexpr (CS % 4 == 0) {
-            const f4 a = *reinterpret_cast<const f4 *>(src);
-            const f4 b = *reinterpret_cast<const f4 *>(src + 4);
-            ra[j][0] = a.x; ra[j][1] = a.y; ra[j][2] = a.z; ra[j][3] = a.w;
-            rb[j][0] = b.x; rb[j][1] = b.y; rb[j][2] = b.z; rb[j][3] = b.w;
-        } else {
-            const f4u a = *reinterpret_cast<const f4u *>(src);
-            const f4u b = *reinterpret_cast<const f4u *>(src + 4);      // runs up to 3 floats into the next frame: zero tables (see load_batch)
-            ra[j][0] = a.x; ra[j][1] = a.y; ra[j][2] = a.z; ra[j][3] = a.w;
-            rb[j][0] = b.x; rb[j][1] = b.y; rb[j][2] = b.z; rb[j][3] = b.w;
+        if constexpr (FIRST) {
+            if constexpr (CS % 4 == 0) {
+                const f4 a = *reinterpret_cast<const f4 *>(src);
+                ra[j][0] = a.x; ra[j][1] = a.y; ra[j][2] = a.z; ra[j][3] = a.w;
+            } else {
+                const f4u a = *reinterpret_cast<const f4u *>(src);
+                ra[j][0] = a.x; ra[j][1] = a.y; ra[j][2] = a.z; ra[j][3] = a.w;
+            }
+        }
+        if constexpr (SECOND == 4) {
+            if constexpr (CS % 4 == 0) {
+                const f4 b = *reinterpret_cast<const f4 *>(src + 4);
+                rb[j][0] = b.x; rb[j][1] = b.y; rb[j][2] = b.z; rb[j][3] = b.w;
+            } else {
+                const f4u b = *reinterpret_cast<const f4u *>(src + 4);      // runs up to 3 floats into the next frame: zero tables (see load_batch)
+                rb[j][0] = b.x; rb[j][1] = b.y; rb[j][2] = b.z; rb[j][3] = b.w;
+            }
+        } else if constexpr (SECOND == 2) {
+            if constexpr (CS % 2 == 0) {
+                const f2 b = *reinterpret_cast<const f2 *>(src + 4);
+                rb[j][0] = b.x; rb[j][1] = b.y;
+            } else {
+                const f2u b = *reinterpret_cast<const f2u *>(src + 4);      // .y is the next frame's first sample: zero tables
+                rb[j][0] = b.x; rb[j][1] = b.y;
+            }
+            rb[j][2] = 0.f; rb[j][3] = 0.f;
         }
     }
 }
@@ -518,7 +540,12 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
     if (t < kTwbElems) twb[t] = p.twb[t];                // visible after the first barrier below
 
     // whole-frame mode: both batches of a tile are loaded together (load_batch2), batch 1 waits in raw_b
-    constexpr bool kWhole = AW_WHOLE_FRAMES != 0 && INTERIOR && CS >= 5 && (NP == 3 || NP == 4);    // also both passes of the wide layouts
+    // kWide (9-16 channels in ONE pass, 5-8 compile-time pairs): two groups of eight channels; the second group is fetched
+    // while the first one's last pair is transformed — raw is free since batch 0's pass 1, raw_b since batch 1's — and takes
+    // the first group's place.  One accumulator, one inverse transform and one output store for all pairs (the two-pass form
+    // pays a second inverse and an output read-modify-write: 9 transforms instead of 8 for 14 channels).
+    constexpr bool kWide = AW_WHOLE_FRAMES != 0 && INTERIOR && !ACC && CS >= 9 && NP >= 5 && NP <= 8;
+    constexpr bool kWhole = kWide || (AW_WHOLE_FRAMES != 0 && INTERIOR && CS >= 5 && (NP == 3 || NP == 4));    // also both passes of the two-pass wide form
     float raw[16][kBatchCh];
     float raw_b[kWhole ? 16 : 1][kBatchCh];
     {
@@ -558,7 +585,7 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
             tw_powers(ctx.opaque(w1), pw);       // opaque: keep the 15 powers out of long-lived registers
             cf x[16];
             if constexpr (kWhole) {
-                if (pair0 > 0) {                 // compile-time after unrolling: the second batch waits in raw_b
+                if ((pair0 & 2) != 0) {          // compile-time after unrolling: the second batch of a group waits in raw_b
 #pragma unroll
                     for (int j = 0; j < 16; ++j) x[j] = mk(raw_b[j][0], raw_b[j][1]);
                     pair_pass1(x, pw, buf0, t);
@@ -596,8 +623,14 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
         ctx.stamp(pair0 > 0 ? 9 : 4);
         const int pair1 = pair0 + 1;     // a phantom second pair (odd pair count, runtime loop) lands on the zero pair after the last one
         if (two && kTabEarly1) load_tab(p, pair1, wave, lane, tab);
+        if constexpr (kWide) {
+            if (pair0 == 2) load_batch2<CS, (NP == 8 && !AW_WIDE_LATE_B ? 4 : NP == 7 && !AW_WIDE_LATE_B ? 2 : 0)>(in_s + 8, f0, t, raw, raw_b);      // channels 8-15 (a 9-12 channel layout: 8-11 only)
+        }
         if (!kWhole && kPrefetchRawEarly && more) load_batch<CS, INTERIOR>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
         if (two) pair_subfft_cmac(ctx, p, pair1, buf1, twa, twb, tab, lane, wave, wacc, kTabEarly1);
+        if constexpr (kWide && AW_WIDE_LATE_B != 0 && NP >= 7) {      // the group's second batch one pair later (an L2 hit): fewer values live through the CMAC
+            if (pair0 == 2) load_batch2<CS, (NP == 8 ? 4 : 2), false>(in_s + 8, f0, t, raw, raw_b);
+        }
         if (!kWhole && !kPrefetchRawEarly && more) load_batch<CS, INTERIOR>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
         ctx.stamp(pair0 > 0 ? 10 : 5);
     };
@@ -802,7 +835,6 @@ AW_HD void tile_part_forward(Ctx &ctx, const TileParams &p, long long stream, in
 // no register batch of four channels, so two workgroups share a CU like the inverse kernel's (which moves the same bytes
 // per transform and runs 4.4 us per transform against 6.2 here with one 152-KB workgroup per CU).  The four pair
 // workgroups of a window are neighbours in the launch order of one XCD: the lines they all read meet in its L2.
-struct __attribute__((packed, aligned(4))) f2u { float x, y; };    // 8 bytes at dword alignment
 
 template <class Ctx, int CS, int MODE>
 AW_HD void tile_part_forward1(Ctx &ctx, const TileParams &p, long long stream, int widx, int pair) {

@@ -275,10 +275,11 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
         const int min_streams = c == 1 ? 8 : c == 2 ? 24 : c == 3 ? 12 : c == 5 ? 24 : 16;
         if (window == awk::kN2 && n_streams < min_streams && fits1) window = awk::kN;
     }
-    // (4) 9+ channels near the end of the 8192-frame window's range (hop down to ~2000 frames) against the partitioned path
-    //     (8192 / partitioned): 9 channels from ~5600 taps (5300: 15.4 / 13.6; 5800: 13.4 / 13.7), the others only at the very end
-    //     (12 channels 6145 taps: 12.1 / 11.8; 14: 10.3 / 10.3; 16: 9.2 / 9.5)
-    const bool prefer_partitioned = getenv("AW_WINDOW") == nullptr && n_in >= 9 && hrir->taps >= (n_in == 9 ? 5600 : 6100);
+    // (4) 9+ channels near the end of the 8192-frame window's range (hop down to 2048 frames) against the partitioned path
+    //     (8192 / partitioned, G frames/s at 6145 taps, tools/path_sweep.py): with the one-pass vector kernels of round 2 the fused
+    //     kernels win to the end for 9-15 channels (9: 16.3 / 13.4, 12: 14.3 / 11.6, 14: 11.3 / 10.2, 15: 9.2 / 8.9); 16 channels
+    //     cross at ~6000 taps (5800: 10.1 / 9.5; 6145: 9.1 / 9.4)
+    const bool prefer_partitioned = getenv("AW_WINDOW") == nullptr && n_in >= 16 && hrir->taps >= 6000;
     const bool force_partitioned = window == 4096 || prefer_partitioned;       // AW_WINDOW=4096: the partitioned path (A/B)
     if (!force_partitioned && ((window == awk::kN2 && fits2) || (!fits1 && fused2_ok))) {
         sp->path = 0; sp->fused2 = true;

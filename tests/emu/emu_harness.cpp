@@ -186,8 +186,8 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
     if (hi < lo) hi = lo;
     if (lo > p.tiles_per_stream) { lo = p.tiles_per_stream; hi = lo; }
     const bool vec = n_channels == 2 || n_channels == 4 || n_channels == 6 || n_channels == 7 || n_channels == 8 ||
-                     n_channels == 10 || n_channels == 12 || n_channels == 14 || n_channels == 16;
-    if (!vec || (variant != 1 && variant != 4)) { lo = 0; hi = 0; }
+                     (n_channels >= 9 && n_channels <= 15 && (variant != 5 || !(n_channels & 1))) || n_channels == 16;
+    if (!vec || (variant != 1 && variant != 4 && variant != 5)) { lo = 0; hi = 0; }
     p.tile_lo = (int)lo; p.tile_hi = (int)hi;
     EmuShared sh;
     std::vector<int> flags((size_t)n_streams * p.tiles_per_stream + 1, 0);
@@ -248,12 +248,20 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
                             case 6: tiles_fused_ols<EmuCtx, 6, 3, true>(ctx, p, g, G, n_tiles); break;
                             case 7: tiles_fused_ols<EmuCtx, 7, 4, true>(ctx, p, g, G, n_tiles); break;
                             case 8: tiles_fused_ols<EmuCtx, 8, 4, true>(ctx, p, g, G, n_tiles); break;
-                            case 10: tiles_fused_ols<EmuCtx, 10, 4, true>(ctx, p, g, G, n_tiles); ctx.barrier(); tiles_fused_ols<EmuCtx, 10, 1, true, true>(ctx, q, g, G, n_tiles); break;
-                            case 14: tiles_fused_ols<EmuCtx, 14, 4, true>(ctx, p, g, G, n_tiles); ctx.barrier(); tiles_fused_ols<EmuCtx, 14, 3, true, true>(ctx, q, g, G, n_tiles); break;
-                            case 12: tiles_fused_ols<EmuCtx, 12, 4, true>(ctx, p, g, G, n_tiles); ctx.barrier(); tiles_fused_ols<EmuCtx, 12, 2, true, true>(ctx, q, g, G, n_tiles); break;
+                            // variant 1 (the default): one pass over two eight-channel groups; variant 5: the two-pass form (AW_WIDE_TWO_PASS=1)
+                            case 15: tiles_fused_ols<EmuCtx, 15, 4, true>(ctx, p, g, G, n_tiles); ctx.barrier(); tiles_fused_ols<EmuCtx, 15, 4, true, true>(ctx, q, g, G, n_tiles); break;
+                            case 9: tiles_fused_ols<EmuCtx, 9, 5, true>(ctx, p, g, G, n_tiles); break;
+                            case 11: tiles_fused_ols<EmuCtx, 11, 6, true>(ctx, p, g, G, n_tiles); break;
+                            case 13: tiles_fused_ols<EmuCtx, 13, 7, true>(ctx, p, g, G, n_tiles); break;
+                            case 10: if (variant != 5) { tiles_fused_ols<EmuCtx, 10, 5, true>(ctx, p, g, G, n_tiles); break; }
+                                     tiles_fused_ols<EmuCtx, 10, 4, true>(ctx, p, g, G, n_tiles); ctx.barrier(); tiles_fused_ols<EmuCtx, 10, 1, true, true>(ctx, q, g, G, n_tiles); break;
+                            case 14: if (variant != 5) { tiles_fused_ols<EmuCtx, 14, 7, true>(ctx, p, g, G, n_tiles); break; }
+                                     tiles_fused_ols<EmuCtx, 14, 4, true>(ctx, p, g, G, n_tiles); ctx.barrier(); tiles_fused_ols<EmuCtx, 14, 3, true, true>(ctx, q, g, G, n_tiles); break;
+                            case 12: if (variant != 5) { tiles_fused_ols<EmuCtx, 12, 6, true>(ctx, p, g, G, n_tiles); break; }
+                                     tiles_fused_ols<EmuCtx, 12, 4, true>(ctx, p, g, G, n_tiles); ctx.barrier(); tiles_fused_ols<EmuCtx, 12, 2, true, true>(ctx, q, g, G, n_tiles); break;
                             default: tiles_fused_ols<EmuCtx, 16, 4, true>(ctx, p, g, G, n_tiles); ctx.barrier(); tiles_fused_ols<EmuCtx, 16, 4, true, true>(ctx, q, g, G, n_tiles); break;
                         }
-                    } else if (p.n_pairs > 4 && p.n_pairs <= 8 && variant == 1) {      // launch_gen's two passes for 9-16 channels
+                    } else if (p.n_pairs > 4 && p.n_pairs <= 8 && (variant == 1 || variant == 5)) {      // launch_gen's two passes for 9-16 channels
                         TileParams q = p;
                         q.in = p.in + 8; q.hist = p.hist + 8; q.tab = p.tab + 4 * (long long)kN; q.ch_base = 8;
                         tiles_fused_ols<EmuCtx, 0, 4, false>(ctx, p, g, G, n_tiles);
@@ -265,7 +273,7 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
                             default: tiles_fused_ols<EmuCtx, 0, 4, false, true>(ctx, q, g, G, n_tiles); break;
                         }
                     } else {
-                        switch (p.n_pairs <= 4 && variant == 1 ? p.n_pairs : 0) {
+                        switch (p.n_pairs <= 4 && (variant == 1 || variant == 5) ? p.n_pairs : 0) {
                             case 1: tiles_fused_ols<EmuCtx, 0, 1, false>(ctx, p, g, G, n_tiles); break;
                             case 2: tiles_fused_ols<EmuCtx, 0, 2, false>(ctx, p, g, G, n_tiles); break;
                             case 3: tiles_fused_ols<EmuCtx, 0, 3, false>(ctx, p, g, G, n_tiles); break;

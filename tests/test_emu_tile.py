@@ -23,8 +23,10 @@ def test_small_butterflies_match_numpy():
         assert np.abs(emu.fft_small(v, True) - iref).max() < 2e-6 * n
 
 
-@pytest.mark.parametrize("channels", [1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("channels", [1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, (10, 5), (14, 5)])
 def test_emulated_tile_matches_truth(oracle, golden_dir, channels):
+    # (channels, 5): the two-pass form of the wide layouts (AW_WIDE_TWO_PASS=1); the default is one pass over two eight-channel groups
+    channels, variant = channels if isinstance(channels, tuple) else (channels, 1)
     wav = oracle.wav_load(os.path.join(golden_dir, "hrtf", "RoomSH1.0.wav"))
     spk = oracle.layout_detect(8)[:channels] if channels <= 8 else oracle.layout_detect(8) + ["FL", "FR", "BL", "BR", "SL", "SR", "FC", "LFE"][: channels - 8]
     cmap = oracle.map_hesuvi14(oracle.layout_detect(8))
@@ -33,7 +35,7 @@ def test_emulated_tile_matches_truth(oracle, golden_dir, channels):
     rt = np.array([cmap[s][1] for s in spk], dtype=np.int32)
     frames = 16500                   # boundary tiles (history, ragged end) and interior ones
     x = oracle.synth_input(1, frames, channels)
-    y = emu.fused_ols(x, tracks, lt, rt)
+    y = emu.fused_ols(x, tracks, lt, rt, variant=variant)
     assert not np.isnan(y).any()
     ref = oracle.spatialize_f64(x[0], tracks, lt, rt)
     for ear in range(2):
