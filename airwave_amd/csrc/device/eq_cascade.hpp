@@ -93,18 +93,33 @@ template <int E> AW_HD void eq_apply(const double *P, const double (&q)[2 * E], 
     }
 }
 
-template <int E> struct EqRaw;                    // what one lane loads per frame: both ears (8 B) or one (4 B)
+// What one lane moves per load / store of a span: two whole stereo frames (16 B at dword alignment: a stream's first frame is
+// only 8-byte aligned when the stride is odd) or one ear of one frame (4 B).
+struct __attribute__((packed, aligned(4))) EqF4 { float a, b, c, d; };
+struct alignas(16) EqF4A { float a, b, c, d; };          // the stage rows are 16-byte aligned: one ds_read/write_b128
+template <int E> struct EqRaw;
 template <> struct EqRaw<2> {
-    typedef cf type;
-    static AW_HD cf zero() { return mk(0.f, 0.f); }
-    static AW_HD cf load(const float *q) { return *reinterpret_cast<const cf *>(q); }
-    static AW_HD void store(float *q, cf v) { *reinterpret_cast<cf *>(q) = v; }
+    typedef EqF4 type;
+    static constexpr int kFrames = 2;
+    static AW_HD EqF4 zero() { return EqF4{0.f, 0.f, 0.f, 0.f}; }
+    static AW_HD EqF4 load(const float *q) { return *reinterpret_cast<const EqF4 *>(q); }
+    static AW_HD void store(float *q, EqF4 v) { *reinterpret_cast<EqF4 *>(q) = v; }
+    // the span's last pair of frames may be half inside
+    static AW_HD EqF4 load_partial(const float *q) { return EqF4{q[0], q[1], 0.f, 0.f}; }
+    static AW_HD void store_partial(float *q, EqF4 v) { q[0] = v.a; q[1] = v.b; }
+    static AW_HD EqF4 lds_load(const float *q) { const EqF4A v = *reinterpret_cast<const EqF4A *>(q); return EqF4{v.a, v.b, v.c, v.d}; }
+    static AW_HD void lds_store(float *q, EqF4 v) { *reinterpret_cast<EqF4A *>(q) = EqF4A{v.a, v.b, v.c, v.d}; }
 };
 template <> struct EqRaw<1> {
     typedef float type;
+    static constexpr int kFrames = 1;
     static AW_HD float zero() { return 0.f; }
     static AW_HD float load(const float *q) { return *q; }
     static AW_HD void store(float *q, float v) { *q = v; }
+    static AW_HD float load_partial(const float *q) { return *q; }
+    static AW_HD void store_partial(float *q, float v) { *q = v; }
+    static AW_HD float lds_load(const float *q) { return *q; }
+    static AW_HD void lds_store(float *q, float v) { *q = v; }
 };
 
 // One workgroup walks one stream's timeline for E ears starting at ear0: E = 2 (both ears in every thread)
@@ -138,17 +153,19 @@ template <class Ctx, int E> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParam
     for (int i = tid; i < K * S; i += kEqThreads) carry[i] = zs[(i / S) * 4 + (i % S)];
     int par = 0;
 
-    raw_t raw[kEqChunk];
+    constexpr int kPer = Raw::kFrames, kLoads = kEqChunk / kPer;      // frames per element, elements per lane and span
+    raw_t raw[kLoads];
     auto fetch = [&](long long base, int nfr) {
         if (nfr == kEqSpan) {
 #pragma unroll
-            for (int j = 0; j < kEqChunk; ++j) raw[j] = Raw::load(in + (base + j * kEqThreads + tid) * 2);
+            for (int j = 0; j < kLoads; ++j) raw[j] = Raw::load(in + (base + (long long)(j * kEqThreads + tid) * kPer) * 2);
         } else {
 #pragma unroll
-            for (int j = 0; j < kEqChunk; ++j) {
-                const int f = j * kEqThreads + tid;
+            for (int j = 0; j < kLoads; ++j) {
+                const int f = (j * kEqThreads + tid) * kPer;
                 raw[j] = Raw::zero();
-                if (f < nfr) raw[j] = Raw::load(in + (base + f) * 2);
+                if (f + kPer <= nfr) raw[j] = Raw::load(in + (base + f) * 2);
+                else if (f < nfr) raw[j] = Raw::load_partial(in + (base + f) * 2);
             }
         }
     };
@@ -162,9 +179,9 @@ template <class Ctx, int E> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParam
         ctx.barrier();   // stage reads of the previous span and the carry writes are complete
         // registers -> LDS in frame order, LDS -> registers transposed to one chunk per thread
 #pragma unroll
-        for (int j = 0; j < kEqChunk; ++j) {
-            const int f = j * kEqThreads + tid;
-            Raw::store(stage + (f / kEqChunk) * kStride + (f % kEqChunk) * E, raw[j]);
+        for (int j = 0; j < kLoads; ++j) {
+            const int f = (j * kEqThreads + tid) * kPer;      // kPer frames never straddle a chunk (kEqChunk is even)
+            Raw::lds_store(stage + (f / kEqChunk) * kStride + (f % kEqChunk) * E, raw[j]);
         }
         ctx.barrier();
         double x[E][kEqChunk];
@@ -295,15 +312,17 @@ template <class Ctx, int E> AW_HD void eq_cascade_stream(Ctx &ctx, const EqParam
         ctx.barrier();
         if (nfr == kEqSpan) {
 #pragma unroll
-            for (int j = 0; j < kEqChunk; ++j) {
-                const int f = j * kEqThreads + tid;
-                Raw::store(out + (base + f) * 2, Raw::load(stage + (f / kEqChunk) * kStride + (f % kEqChunk) * E));
+            for (int j = 0; j < kLoads; ++j) {
+                const int f = (j * kEqThreads + tid) * kPer;
+                Raw::store(out + (base + f) * 2, Raw::lds_load(stage + (f / kEqChunk) * kStride + (f % kEqChunk) * E));
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < kEqChunk; ++j) {
-                const int f = j * kEqThreads + tid;
-                if (f < nfr) Raw::store(out + (base + f) * 2, Raw::load(stage + (f / kEqChunk) * kStride + (f % kEqChunk) * E));
+            for (int j = 0; j < kLoads; ++j) {
+                const int f = (j * kEqThreads + tid) * kPer;
+                const raw_t v = Raw::lds_load(stage + (f / kEqChunk) * kStride + (f % kEqChunk) * E);
+                if (f + kPer <= nfr) Raw::store(out + (base + f) * 2, v);
+                else if (f < nfr) Raw::store_partial(out + (base + f) * 2, v);
             }
         }
     }

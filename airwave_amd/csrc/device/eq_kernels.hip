@@ -86,6 +86,13 @@ __global__ void aw_eq_copy_kernel(const float *__restrict__ src, long long src_s
     if (f < frames) reinterpret_cast<float2 *>(dst)[s * dst_stride + f] = reinterpret_cast<const float2 *>(src)[s * src_stride + f];
 }
 
+// 74 KB (both ears) / 38 KB of dynamic LDS: above the 64 KB a kernel gets without asking.  Called from aw_context_create.
+hipError_t prepare_eq_kernels() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_eq_cascade_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, eq_lds_bytes(2));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_eq_cascade_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, eq_lds_bytes(1));
+    return e;
+}
+
 hipError_t launch_eq_cascade(const EqParams &p, int n_streams, hipStream_t stream) {
     if (n_streams <= 0 || p.frames <= 0) return hipSuccess;
     // split the ears over two workgroups while the per-ear grid still fits the CUs in one round (three workgroups per CU):

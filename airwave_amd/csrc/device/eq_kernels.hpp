@@ -8,6 +8,7 @@ namespace awk {
 
 // Chunk-parallel cascade over p.frames (multiple of kEqChunk) frames of every stream: one workgroup
 // of kEqThreads per stream.
+hipError_t prepare_eq_kernels();     // dynamic-LDS attribute of the cascade kernels (more than 64 KB); once per context
 hipError_t launch_eq_cascade(const EqParams &p, int n_streams, hipStream_t stream);
 // The sequential recurrence, one thread per (stream, ear): short calls and tails.
 hipError_t launch_eq_sequential(const EqParams &p, int n_streams, hipStream_t stream);

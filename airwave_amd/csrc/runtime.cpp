@@ -9,6 +9,7 @@
 #include <mutex>
 #include <new>
 
+#include "device/eq_kernels.hpp"
 #include "host/tables.hpp"
 
 // Default fused window: 8192 frames; 16384 (tile_ols2.hpp) where measurements favour it.
@@ -88,6 +89,7 @@ static aw_status context_create_impl(int32_t device, void *ext_stream, bool use_
     hipError_t e = hipEventCreate(&c->t0);
     if (e == hipSuccess) e = hipEventCreate(&c->t1);
     if (e == hipSuccess) e = awk::prepare_kernels(&c->cfg);
+    if (e == hipSuccess) e = awk::prepare_eq_kernels();
     awh::Twiddles tw;
     awh::build_twiddles(tw);
     auto upload = [&](const std::vector<awk::cf> &v, awk::cf **d) -> hipError_t {
