@@ -54,9 +54,15 @@ while time.time() < t_end:
         info = sp.info()
         y = np.concatenate([sp.process(x[:, a:b]) for a, b in zip(bounds[:-1], bounds[1:])], axis=1)
         err = 0.0
+        # the tolerance is relative to the output peak; a call of a few frames can have a peak far below the scale of the terms
+        # that were summed (one frame: a single random dot product), so the peak is floored at a quarter of the typical output
+        # level max|x| * sqrt(sum of the mapped tracks' energies) — seed 31 found a 1-frame call at 1.06e-5 of its own peak
+        used = [t for t in list(lt) + list(rt) if t >= 0]
+        floor = 0.25 * float(np.max(np.abs(x))) * float(np.sqrt(sum(float(np.sum(h[t].astype(np.float64) ** 2)) for t in used) / 2.0)) if used else 0.0
         for s in range(S):
             ref = orc.spatialize_f64(x[s], h, lt, rt)
-            err = max(err, orc.peak_rel_error(y[s], ref))
+            peak = max(float(np.max(np.abs(ref))), floor, 1e-30)
+            err = max(err, float(np.max(np.abs(y[s].astype(np.float64) - ref))) / peak)
         ok = np.isfinite(y).all() and err < TOL
     except Exception as e:                              # noqa: BLE001
         ok, err, info = False, repr(e), None
