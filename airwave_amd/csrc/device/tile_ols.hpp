@@ -364,6 +364,29 @@ AW_HD void load_batch_head(const TileParams &p, const float *in_s, const float *
     }
 }
 
+// Both four-channel batches of a head window's frames back to back (5-8 channels), as load_batch2 does for interior windows.
+template <int CS>
+AW_HD void load_batch2_head(const TileParams &p, const float *in_s, const float *hist_s, long long f0, int t,
+                            float (&ra)[16][kBatchCh], float (&rb)[16][kBatchCh]) {
+    static_assert(CS >= 5 && CS <= 8, "two batches of four channels");
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const long long f = f0 + t + 512 * j;
+        const float *src = f < 0 ? hist_s + ((long long)p.hist_len + f) * CS : in_s + f * CS;
+        if constexpr (CS % 4 == 0) {
+            const f4 a = *reinterpret_cast<const f4 *>(src);
+            const f4 b = *reinterpret_cast<const f4 *>(src + 4);
+            ra[j][0] = a.x; ra[j][1] = a.y; ra[j][2] = a.z; ra[j][3] = a.w;
+            rb[j][0] = b.x; rb[j][1] = b.y; rb[j][2] = b.z; rb[j][3] = b.w;
+        } else {
+            const f4u a = *reinterpret_cast<const f4u *>(src);
+            const f4u b = *reinterpret_cast<const f4u *>(src + 4);      // up to 3 floats into the next frame (history: its allocation's slack)
+            ra[j][0] = a.x; ra[j][1] = a.y; ra[j][2] = a.z; ra[j][3] = a.w;
+            rb[j][0] = b.x; rb[j][1] = b.y; rb[j][2] = b.z; rb[j][3] = b.w;
+        }
+    }
+}
+
 // pass 1 of one pair: radix-16 over the thread's 16 window samples, twiddle, scatter to rows.
 AW_HD void pair_pass1(cf (&x)[16], const cf (&pw)[16], cf *buf, int t) {
     fft16<false>(x);
@@ -741,14 +764,15 @@ AW_HD void tiles_part_forward(Ctx &ctx, const TileParams &p, long long first, lo
 
     // whole-frame mode (interior windows of 5-8 channel layouts): both four-channel batches of a window are loaded together
     // (load_batch2: every line crosses the L2 -> L1 path once), the second batch waits in raw_b
-    constexpr bool kWhole = AW_WHOLE_FRAMES != 0 && MODE == 1 && CS >= 5 && CS <= 8;
+    constexpr bool kWhole = AW_WHOLE_FRAMES != 0 && (MODE == 1 || MODE == 2) && CS >= 5 && CS <= 8;
     float raw[16][kBatchCh];
     float raw_b[kWhole ? 16 : 1][kBatchCh];
     auto load_window = [&](const PartWin &w) {
         const float *in_w = p.in + w.stream * p.frames * Cn;
         const long long fw = ((long long)w.w - p.partitions) * p.hop;
         if constexpr (kWhole) {
-            load_batch2<CS>(in_w, fw, t, raw, raw_b);
+            if constexpr (MODE == 2) load_batch2_head<CS>(p, in_w, p.hist + w.stream * (long long)p.hist_len * Cn, fw, t, raw, raw_b);
+            else load_batch2<CS>(in_w, fw, t, raw, raw_b);
             if constexpr ((CS & 1) != 0) {                  // the padding lane of an odd layout's last pair must be a real zero (herm_last)
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
