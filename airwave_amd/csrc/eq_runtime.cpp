@@ -268,9 +268,14 @@ aw_status aw_eq_create(aw_context *ctx, double sample_rate, int32_t n_streams, i
     const size_t n = (size_t)n_streams * eq->transition_length * 2;
     hipError_t he = hipMalloc(reinterpret_cast<void **>(&eq->d_old), n * sizeof(float));
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&eq->d_new), n * sizeof(float));
-    if (he != hipSuccess) {                      // a failed second allocation must not leak the first: destroy frees whatever exists
+    // the planar (plug-in) entry's staging buffer for the largest callback: process never allocates afterwards
+    if (he == hipSuccess && n_streams == 1 && max_frames > 0) {
+        he = hipMalloc(reinterpret_cast<void **>(&eq->d_stage), (size_t)max_frames * 4 * sizeof(float));
+        if (he == hipSuccess) eq->stage_cap = (size_t)max_frames * 4;
+    }
+    if (he != hipSuccess) {                      // a failed later allocation must not leak the earlier ones: destroy frees whatever exists
         aw_eq_destroy(eq.release());
-        return awr::hip_fail(he, "crossfade scratch");
+        return awr::hip_fail(he, "crossfade / staging scratch");
     }
     *out = eq.release();
     return AW_OK;
