@@ -144,7 +144,7 @@ static bool ols2_slp_layout(int C) { return C == 4 || C == 6 || C == 8; }      /
 // case — the few boundary tiles of those, and all tiles of the other channel counts — runs the
 // generic-addressing kernels <0, NP, false> (NP = compile-time pair count 1..4; NP = 0 loops over
 // batches of two pairs at run time: more than 8 channels, where full unrolling only spills).
-#define AW_FOR_EACH_VEC(X) X(2, 1) X(4, 2) X(6, 3) X(7, 4) X(8, 4) X(12, 0) X(14, 0) X(16, 0)
+#define AW_FOR_EACH_VEC(X) X(2, 1) X(3, 2) X(4, 2) X(5, 3) X(6, 3) X(7, 4) X(8, 4) X(12, 0) X(14, 0) X(16, 0)
 #define AW_FOR_EACH_GEN(X) X(1) X(2) X(3) X(4) X(0)
 // wide layouts (interior tiles): (channels, pairs of the first pass, pairs of the accumulating second pass)
 #define AW_FOR_EACH_WIDE(X) X(10, 4, 1) X(12, 4, 2) X(14, 4, 3) X(15, 4, 4) X(16, 4, 4)
@@ -272,13 +272,15 @@ hipError_t prepare_kernels(LaunchCfg *cfg) {
     return e;
 }
 
-static bool has_vec_variant(int C) { return C == 2 || C == 4 || C == 6 || C == 7 || C == 8 || C == 12 || C == 14 || C == 16; }
+static bool has_vec_variant(int C) { return (C >= 2 && C <= 8) || C == 12 || C == 14 || C == 16; }
 static bool has_fused_vec_variant(int C) { return has_vec_variant(C) || (C >= 9 && C <= 15); }       // 9, 10, 11, 13, 15 channels: the fused kernels only
 
 const char *fused_ols_kernel_name(int C) {
     switch (C) {
         case 2: return "aw_fused_ols_kernel<2, 1, true>";
+        case 3: return "aw_fused_ols_kernel<3, 2, true>";
         case 4: return "aw_fused_ols_kernel<4, 2, true>";
+        case 5: return "aw_fused_ols_kernel<5, 3, true>";
         case 6: return "aw_fused_ols_kernel<6, 3, true>";
         case 7: return "aw_fused_ols_kernel<7, 4, true>";
         case 8: return "aw_fused_ols_kernel<8, 4, true>";

@@ -264,12 +264,13 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
     const bool fused2_ok = fits2 && hrir->taps <= upto;
     if (window == 0) {
         // (2) 8192- against 16384-frame windows where both can hold the HRIR (8192 / 16384): mono always 16384 (4320 taps 93 / 202),
-        //     stereo from ~2000 taps (2048: 157 / 160; 4320: 105 / 143), 3 channels from ~1000 (4320: 61 / 98), 5 from ~2000
-        //     (2048: 61 / 63; 4320: 40 / 55), 7 from ~4400 (4320: 35.9 / 35.6; 5000: 29.7 / 33.2); 4, 6 and 8 channels only at the very
+        //     stereo from ~2000 taps (2048: 157 / 160; 4320: 105 / 143), 3 channels from ~1800 (1024: 120 / 113; 2048: 107 / 111;
+        //     4320: 67 / 101), 5 from ~3200 (3000: 57.6 / 56.2; 3600: 52.4 / 56.9; 4320: 43 / 55) — both with the 8192-frame vector
+        //     variants <3,2> and <5,3> of the end of round 2 (generic kernels before: crossovers at ~1000 / ~2000) —, 7 from ~4400 (4320: 35.9 / 35.6; 5000: 29.7 / 33.2); 4, 6 and 8 channels only at the very
         //     end of the 8192-frame window's range (6 and 8 from ~6100: 26.4 / 27.5 and 21.1 / 21.2 at 6145; 4 never: 38.2 / 36.9).
         //     Odd counts cross early: the 8192-frame kernels pad them to whole pairs, the polyphase view has 2C pseudo-channels.
         const int c = n_in;
-        const int from = c == 1 ? 0 : c == 2 ? 2000 : c == 3 ? 1000 : c == 5 ? 2000 : c == 7 ? 4400 : (c == 6 || c == 8) ? 6100 : (1 << 30);
+        const int from = c == 1 ? 0 : c == 2 ? 2000 : c == 3 ? 1800 : c == 5 ? 3200 : c == 7 ? 4400 : (c == 6 || c == 8) ? 6100 : (1 << 30);
         window = (hrir->taps >= from && fused2_ok) ? awk::kN2 : AW_DEFAULT_WINDOW;
         // (3) small batches cannot fill 256 CUs with 16384-frame tiles (a 10 s stream is 40 of them): the 8192-frame kernels give
         //     three times the tiles.  Crossover in streams (tools/small_batch_sweep.py, 4320 taps, 10 s per stream): mono 8

@@ -185,7 +185,7 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
     if (hi > p.tiles_per_stream) hi = p.tiles_per_stream;
     if (hi < lo) hi = lo;
     if (lo > p.tiles_per_stream) { lo = p.tiles_per_stream; hi = lo; }
-    const bool vec = n_channels == 2 || n_channels == 4 || n_channels == 6 || n_channels == 7 || n_channels == 8 ||
+    const bool vec = (n_channels >= 2 && n_channels <= 8) ||
                      (n_channels >= 9 && n_channels <= 15 && (variant != 5 || !(n_channels & 1))) || n_channels == 16;
     if (!vec || (variant != 1 && variant != 4 && variant != 5)) { lo = 0; hi = 0; }
     p.tile_lo = (int)lo; p.tile_hi = (int)hi;
@@ -244,7 +244,9 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
                         q.tab = p.tab + 4 * (long long)kN;
                         switch (n_channels) {
                             case 2: tiles_fused_ols<EmuCtx, 2, 1, true>(ctx, p, g, G, n_tiles); break;
+                            case 3: tiles_fused_ols<EmuCtx, 3, 2, true>(ctx, p, g, G, n_tiles); break;
                             case 4: tiles_fused_ols<EmuCtx, 4, 2, true>(ctx, p, g, G, n_tiles); break;
+                            case 5: tiles_fused_ols<EmuCtx, 5, 3, true>(ctx, p, g, G, n_tiles); break;
                             case 6: tiles_fused_ols<EmuCtx, 6, 3, true>(ctx, p, g, G, n_tiles); break;
                             case 7: tiles_fused_ols<EmuCtx, 7, 4, true>(ctx, p, g, G, n_tiles); break;
                             case 8: tiles_fused_ols<EmuCtx, 8, 4, true>(ctx, p, g, G, n_tiles); break;
@@ -326,7 +328,7 @@ int emu_partitioned(const float *in, float *out, const float *hist, const float 
                 for (auto &x : th) x.join();
             }
     };
-    {   // interior / head / generic split of awk::launch_part_forward (vector variants exist for 7 and 8 channels here)
+    {   // interior / head / generic split of awk::launch_part_forward (vector variants are emulated for 5, 7 and 8 channels here)
         const long long usable = frames - ((n_channels % 4 != 0 && n_channels != 2) ? 1 : 0);
         const long long d = usable - kN;
         long long lo = P, hi = (d >= 0 ? d / B : -((-d + B - 1) / B)) + P + 1;       // floor((usable - N) / B) + P + 1, as awk::launch_part_forward
@@ -335,14 +337,16 @@ int emu_partitioned(const float *in, float *out, const float *hist, const float 
         if (hi < lo) lo = hi;
         if (hi < 0) hi = 0;
         if (lo < 0) lo = 0;
-        if (n_channels != 7 && n_channels != 8) { lo = 0; hi = 0; }
+        if (n_channels != 7 && n_channels != 8 && n_channels != 5) { lo = 0; hi = 0; }
         if (cmac_variant == 1)             // with the block-group CMAC: the all-pairs-per-workgroup forward kernel
         run([&](EmuCtx &ctx, int s, int w) {
             if (w >= lo && w < hi) {
                 if (n_channels == 7) tile_part_forward<EmuCtx, 7, 1>(ctx, p, s, w);
+                else if (n_channels == 5) tile_part_forward<EmuCtx, 5, 1>(ctx, p, s, w);
                 else tile_part_forward<EmuCtx, 8, 1>(ctx, p, s, w);
             } else if (w < lo) {
                 if (n_channels == 7) tile_part_forward<EmuCtx, 7, 2>(ctx, p, s, w);
+                else if (n_channels == 5) tile_part_forward<EmuCtx, 5, 2>(ctx, p, s, w);
                 else tile_part_forward<EmuCtx, 8, 2>(ctx, p, s, w);
             } else tile_part_forward<EmuCtx, 0, 0>(ctx, p, s, w);
         }, n_windows);
@@ -351,9 +355,11 @@ int emu_partitioned(const float *in, float *out, const float *hist, const float 
         run([&](EmuCtx &ctx, int s, int w) {
             if (w >= lo && w < hi) {
                 if (n_channels == 7) tile_part_forward1<EmuCtx, 7, 1>(ctx, p, s, w, pair);
+                else if (n_channels == 5) tile_part_forward1<EmuCtx, 5, 1>(ctx, p, s, w, pair);
                 else tile_part_forward1<EmuCtx, 8, 1>(ctx, p, s, w, pair);
             } else if (w < lo) {
                 if (n_channels == 7) tile_part_forward1<EmuCtx, 7, 2>(ctx, p, s, w, pair);
+                else if (n_channels == 5) tile_part_forward1<EmuCtx, 5, 2>(ctx, p, s, w, pair);
                 else tile_part_forward1<EmuCtx, 8, 2>(ctx, p, s, w, pair);
             } else tile_part_forward1<EmuCtx, 0, 0>(ctx, p, s, w, pair);
         }, n_windows);

@@ -23,7 +23,7 @@ def test_small_butterflies_match_numpy():
         assert np.abs(emu.fft_small(v, True) - iref).max() < 2e-6 * n
 
 
-@pytest.mark.parametrize("channels", [1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, (10, 5), (14, 5)])
+@pytest.mark.parametrize("channels", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, (10, 5), (14, 5)])
 def test_emulated_tile_matches_truth(oracle, golden_dir, channels):
     # (channels, 5): the two-pass form of the wide layouts (AW_WIDE_TWO_PASS=1); the default is one pass over two eight-channel groups
     channels, variant = channels if isinstance(channels, tuple) else (channels, 1)
@@ -64,7 +64,7 @@ def test_emulated_partitioned_long_hrir(oracle, golden_dir):
     assert oracle.peak_rel_error(y[0], g["expected"]) < TOL
 
 
-@pytest.mark.parametrize("channels", [7, 8])
+@pytest.mark.parametrize("channels", [5, 7, 8])
 def test_emulated_partitioned_interior_windows(oracle, channels):
     """Long enough for interior windows of the forward kernel (whole-frame vector loads; 7-channel frames run into
     the next frame) next to the boundary ones; 9000 taps = 3 partitions."""
