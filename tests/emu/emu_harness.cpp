@@ -185,8 +185,9 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
     if (hi > p.tiles_per_stream) hi = p.tiles_per_stream;
     if (hi < lo) hi = lo;
     if (lo > p.tiles_per_stream) { lo = p.tiles_per_stream; hi = lo; }
-    const bool vec = (n_channels >= 2 && n_channels <= 8) ||
-                     (n_channels >= 9 && n_channels <= 15 && (variant != 5 || !(n_channels & 1))) || n_channels == 16;
+    const bool vec = variant == 4 ? ((n_channels >= 2 && n_channels <= 8) || n_channels == 12 || n_channels == 14 || n_channels == 16)      // awk::has_vec_variant
+                                  : ((n_channels >= 2 && n_channels <= 8) ||
+                                     (n_channels >= 9 && n_channels <= 15 && (variant != 5 || !(n_channels & 1))) || n_channels == 16);
     if (!vec || (variant != 1 && variant != 4 && variant != 5)) { lo = 0; hi = 0; }
     p.tile_lo = (int)lo; p.tile_hi = (int)hi;
     EmuShared sh;
@@ -208,7 +209,9 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
                         if (interior) {
                             switch (n_channels) {
                                 case 2: tiles_fused_olsq<EmuCtx, 2, 1, true>(ctx, p, g2, G, n_tiles, q); break;
+                                case 3: tiles_fused_olsq<EmuCtx, 3, 2, true>(ctx, p, g2, G, n_tiles, q); break;
                                 case 4: tiles_fused_olsq<EmuCtx, 4, 2, true>(ctx, p, g2, G, n_tiles, q); break;
+                                case 5: tiles_fused_olsq<EmuCtx, 5, 3, true>(ctx, p, g2, G, n_tiles, q); break;
                                 case 6: tiles_fused_olsq<EmuCtx, 6, 3, true>(ctx, p, g2, G, n_tiles, q); break;
                                 case 7: tiles_fused_olsq<EmuCtx, 7, 4, true>(ctx, p, g2, G, n_tiles, q); break;
                                 case 8: tiles_fused_olsq<EmuCtx, 8, 4, true>(ctx, p, g2, G, n_tiles, q); break;
