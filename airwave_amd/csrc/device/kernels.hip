@@ -139,11 +139,12 @@ const char *fused_ols2_kernel_name(int C) {
 static bool has_vec2_variant(int C) { return C >= 1 && C <= 8; }
 static bool ols2_slp_layout(int C) { return C == 4 || C == 6 || C == 8; }      // built in ols2_even_kernels.hip
 
-// Kernel variants.  Vectorised interior kernels <CS, NP, true> exist for the channel counts whose
-// frames are whole float4s/float2s (2, 4, 8, 12, 16 channels: stereo ... 7.1.4 + 4); every other
-// case — the few boundary tiles of those, and all tiles of the other channel counts — runs the
-// generic-addressing kernels <0, NP, false> (NP = compile-time pair count 1..4; NP = 0 loops over
-// batches of two pairs at run time: more than 8 channels, where full unrolling only spills).
+// Kernel variants.  Vectorised interior kernels <CS, NP, true> exist for 2-16 channels (frames that are not whole float4s are
+// loaded 16 B per lane at dword alignment, zero tables cancel the lanes that run into the next frame; 9-14 channels in one
+// pass over two eight-channel groups, 15-16 in two passes); the boundary tiles of every layout, and mono, run the
+// generic-addressing kernels <0, NP, false> (NP = compile-time pair count 1..4; NP = 0 loops over batches of two pairs at
+// run time).  The (12, 0) (14, 0) (16, 0) entries are the round-1 run-time-loop kernels (AW_WIDE_TWO_PASS=0) and the wide
+// layouts' forward kernels of the partitioned path.
 #define AW_FOR_EACH_VEC(X) X(2, 1) X(3, 2) X(4, 2) X(5, 3) X(6, 3) X(7, 4) X(8, 4) X(12, 0) X(14, 0) X(16, 0)
 #define AW_FOR_EACH_GEN(X) X(1) X(2) X(3) X(4) X(0)
 // wide layouts (interior tiles): (channels, pairs of the first pass, pairs of the accumulating second pass)
