@@ -20,6 +20,7 @@ ARCH = "gfx950"
 SOURCES = [
     "device/kernels.hip",
     "device/march_kernels.hip",
+    "device/lw_kernels.hip",
     "device/ols2_even_kernels.hip",
     "device/eq_kernels.hip",
     "runtime.cpp",
@@ -33,6 +34,7 @@ EXTRA_FLAGS = {"device/march_kernels.hip": [] if os.environ.get("AW_MARCH_SLP") 
                # the tile kernels too: SLP packs butterflies into v_pk_add/mul/fma_f32, which issue at HALF the rate of the scalar
                # forms on gfx950 (tools/ubench/valu_rate: 4.7 against 2.45 cycles) and need v_mov pairs on top — the FFT core alone
                # runs 3.03 instead of 3.78 us per transform without it (tools/ubench/fft_core), cfg 4 / 5 gain 10-13 %, cfg 3 4 %
+               "device/lw_kernels.hip": ["-fno-slp-vectorize"],
                "device/kernels.hip": [] if os.environ.get("AW_KERNELS_SLP") else ["-fno-slp-vectorize"]}
 HEADERS = sorted(os.path.relpath(os.path.join(d, f), CSRC) for d, _, fs in os.walk(CSRC) for f in fs if f.endswith((".hpp", ".h"))) + [
     "../../include/airwave_hip.h",

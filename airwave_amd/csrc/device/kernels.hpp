@@ -7,6 +7,7 @@
 #include "tile_ols2.hpp"
 #include "tile_olsh.hpp"
 #include "tile_march.hpp"
+#include "tile_lw.hpp"
 
 namespace awk {
 
@@ -41,6 +42,12 @@ hipError_t launch_part_forward(const TileParams &p, int n_streams, hipStream_t s
 hipError_t launch_part_cmac(const TileParams &p, int n_streams, hipStream_t stream, StageTimer *tm = nullptr);      // block-group kernel (A/B: AW_PART_CMAC=group)
 hipError_t launch_part_march(const TileParams &p, int n_streams, hipStream_t stream, StageTimer *tm = nullptr);     // marched kernel (tile_march.hpp), the default
 hipError_t launch_part_inverse(const TileParams &p, int n_streams, hipStream_t stream, StageTimer *tm = nullptr);
+
+// Long-window path (tile_lw.hpp, lw_kernels.hip): windows of R x 4096 frames through split -> rows -> merge.
+hipError_t prepare_lw_kernels();
+hipError_t launch_lw_split(const LwParams &p, int n_streams, hipStream_t stream, StageTimer *tm = nullptr);
+hipError_t launch_lw_rows(const LwParams &p, int n_streams, hipStream_t stream, StageTimer *tm = nullptr);
+hipError_t launch_lw_merge(const LwParams &p, int n_streams, hipStream_t stream, StageTimer *tm = nullptr);
 
 // hist_new[s][i][c] <- frame (frames - hist_len + i) of (hist_old ++ in), for every stream.
 hipError_t launch_hist_update(const float *in, const float *hist_old, float *hist_new, long long frames,

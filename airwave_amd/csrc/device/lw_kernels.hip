@@ -1,0 +1,131 @@
+// lw_kernels.hip — the three kernels of the long-window path (tile_lw.hpp): split, rows, merge.
+// Its own translation unit (built with -fno-slp-vectorize like the other tile kernels, airwave_amd/build.py).
+#include "kernels.hpp"
+#include "gpu_ctx.hpp"
+#include "tile_lw.hpp"
+
+namespace awk {
+
+// Tile id = (stream, window) * 64 + t-chunk: workgroups that run at the same time read and write neighbouring 64-frame
+// pieces of the same R strided sub-sequences (whole DRAM pages between them).
+template <int RA, int CS>
+__global__ void __launch_bounds__(kThreads, RA == 16 ? 2 : 4) aw_lw_split_kernel(LwParams p, long long n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
+    lw_split_tiles<GpuCtx, RA, CS>(ctx, p, (long long)blockIdx.x, (long long)gridDim.x, n_tiles);
+}
+
+// Row pairs are pinned to XCDs (blockIdx % 8 labels the XCD): XCD x walks the row pairs x, x + 8, ... one after the other
+// and, within a row pair, every (stream, window); its 32 workgroups therefore share one 512 KB table slice at a time.
+template <int NP, bool REAL_LAST>
+__global__ void __launch_bounds__(kThreads) aw_lw_rows_kernel(LwParams p, long long n_sw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
+    const int g = (int)gridDim.x, b = (int)blockIdx.x;
+    const int xcd = b % 8, slot = b / 8;
+    const int per_xcd_wg = (g - xcd + 7) / 8;
+    const int n_rp = p.R / 2;
+    const int n_rp_x = (n_rp - xcd + 7) / 8;
+    lw_rows_tiles<GpuCtx, NP, REAL_LAST>(ctx, p, (long long)slot, (long long)per_xcd_wg, (long long)n_rp_x * n_sw, n_sw, xcd, 8);
+}
+
+template <int RA>
+__global__ void __launch_bounds__(kThreads, 4) aw_lw_merge_kernel(LwParams p, long long n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
+    lw_merge_tiles<GpuCtx, RA>(ctx, p, (long long)blockIdx.x, (long long)gridDim.x, n_tiles);
+}
+
+#define AW_LW_FOR_CS(X, RA) X(RA, 1) X(RA, 2) X(RA, 3) X(RA, 4) X(RA, 5) X(RA, 6) X(RA, 7) X(RA, 8)
+#define AW_LW_FOR_RA_CS(X) AW_LW_FOR_CS(X, 4) AW_LW_FOR_CS(X, 8) AW_LW_FOR_CS(X, 16)
+
+template <int RA> constexpr int lw_split_lds_bytes() { return lw_split_lds_elems<RA>() * (int)sizeof(cf); }
+template <int RA> constexpr int lw_merge_lds_bytes() { return lw_merge_lds_elems<RA>() * (int)sizeof(cf); }
+
+hipError_t prepare_lw_kernels() {
+    hipError_t e = hipSuccess;
+#define AW_SET(RA, CS)                                                                                 \
+    if (e == hipSuccess)                                                                               \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_split_kernel<RA, CS>),           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lw_split_lds_bytes<RA>());
+    AW_LW_FOR_RA_CS(AW_SET)
+#undef AW_SET
+#define AW_SET(NP)                                                                                     \
+    if (e == hipSuccess)                                                                               \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_rows_kernel<NP, false>),         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);                \
+    if (e == hipSuccess)                                                                               \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_rows_kernel<NP, true>),          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    AW_SET(1) AW_SET(2) AW_SET(3) AW_SET(4)
+#undef AW_SET
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_merge_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lw_merge_lds_bytes<4>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_merge_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lw_merge_lds_bytes<8>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_merge_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lw_merge_lds_bytes<16>());
+    return e;
+}
+
+static unsigned lw_grid(long long n_tiles, const LwParams &p, int wgs_per_cu) {
+    long long wgs = (long long)(p.persistent_wgs >= 8 ? p.persistent_wgs : 256) * wgs_per_cu;
+    return (unsigned)(n_tiles < wgs ? n_tiles : wgs);
+}
+
+hipError_t launch_lw_split(const LwParams &p, int n_streams, hipStream_t stream, StageTimer *tm) {
+    const long long n_tiles = (long long)n_streams * p.n_windows * kLwChunks;
+    if (n_tiles <= 0) return hipSuccess;
+    if (n_tiles > 0x7fffffffLL || p.n_channels < 1 || p.n_channels > 8) return hipErrorInvalidValue;
+    const int ra = p.R / 8;
+    if (tm) tm->begin();
+    bool done = false;
+#define AW_CASE(RA, CS)                                                                                                        \
+    if (!done && ra == RA && p.n_channels == CS) {                                                                             \
+        hipLaunchKernelGGL((aw_lw_split_kernel<RA, CS>), dim3(lw_grid(n_tiles, p, RA == 16 ? 1 : 2)), dim3(kThreads),          \
+                           lw_split_lds_bytes<RA>(), stream, p, n_tiles);                                                      \
+        done = true;                                                                                                           \
+    }
+    AW_LW_FOR_RA_CS(AW_CASE)
+#undef AW_CASE
+    if (tm) tm->end("aw_lw_split_kernel");
+    return done ? hipGetLastError() : hipErrorInvalidValue;
+}
+
+hipError_t launch_lw_rows(const LwParams &p, int n_streams, hipStream_t stream, StageTimer *tm) {
+    const long long n_sw = (long long)n_streams * p.n_windows;
+    const long long n_tiles = n_sw * (p.R / 2);
+    if (n_tiles <= 0) return hipSuccess;
+    if (n_tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    // 8 XCD groups: a grid that is a multiple of 8 (every group has the same number of workgroups), at least 8
+    unsigned grid = lw_grid((n_tiles + 7) / 8 * 8, p, 1) / 8 * 8;
+    if (grid < 8) grid = 8;
+    if (tm) tm->begin();
+    const bool real = p.real_last != 0;
+    switch (p.n_pairs) {
+#define AW_CASE(NP)                                                                                                       \
+        case NP:                                                                                                          \
+            if (real) hipLaunchKernelGGL((aw_lw_rows_kernel<NP, true>), dim3(grid), dim3(kThreads), kLdsBytes, stream, p, n_sw);   \
+            else hipLaunchKernelGGL((aw_lw_rows_kernel<NP, false>), dim3(grid), dim3(kThreads), kLdsBytes, stream, p, n_sw);       \
+            break;
+        AW_CASE(1) AW_CASE(2) AW_CASE(3) AW_CASE(4)
+#undef AW_CASE
+        default: return hipErrorInvalidValue;
+    }
+    if (tm) tm->end("aw_lw_rows_kernel");
+    return hipGetLastError();
+}
+
+hipError_t launch_lw_merge(const LwParams &p, int n_streams, hipStream_t stream, StageTimer *tm) {
+    const long long n_tiles = (long long)n_streams * p.n_windows * kLwChunks;
+    if (n_tiles <= 0) return hipSuccess;
+    if (n_tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (tm) tm->begin();
+    switch (p.R) {
+        case 32: hipLaunchKernelGGL((aw_lw_merge_kernel<4>), dim3(lw_grid(n_tiles, p, 2)), dim3(kThreads), lw_merge_lds_bytes<4>(), stream, p, n_tiles); break;
+        case 64: hipLaunchKernelGGL((aw_lw_merge_kernel<8>), dim3(lw_grid(n_tiles, p, 2)), dim3(kThreads), lw_merge_lds_bytes<8>(), stream, p, n_tiles); break;
+        case 128: hipLaunchKernelGGL((aw_lw_merge_kernel<16>), dim3(lw_grid(n_tiles, p, 2)), dim3(kThreads), lw_merge_lds_bytes<16>(), stream, p, n_tiles); break;
+        default: return hipErrorInvalidValue;
+    }
+    if (tm) tm->end("aw_lw_merge_kernel");
+    return hipGetLastError();
+}
+
+}  // namespace awk

@@ -1,0 +1,477 @@
+// tile_lw.hpp — the LONG-WINDOW path for long HRIRs (cfg 3: 32 768 taps): single-partition overlap-save on windows of
+// N = R x 4096 frames (R = 32, 64, 128: N = 131 072 ... 524 288), the transform run as a four-step FFT through HBM scratch.
+//
+// Replaces, for a whole window of one stream at once, what ConvolutionEngine.process does per 512-frame block with a
+// frequency-domain delay line (Airwave/ConvolutionEngine.swift:232-367) and what RealtimeAudioProcessor.processPendingBlock
+// sums over speakers (Airwave/RealtimeAudioProcessor.swift:141-172).  Against the partitioned path of tile_ols.hpp /
+// tile_march.hpp (B = 4096, 2x overlap, spectra of every window written and read once per partition step) a window
+// N >> taps overlaps by N / (N - taps) only (1.07 for 10 s streams on N = 524 288) and needs no delay line at all:
+// 115 instead of 203 bytes of fabric traffic per output frame on cfg 3.
+//
+// Odd-frequency transform.  All spectra are sampled at k + 1/2:  X[k] = sum_n x[n] w_N^{n (k + 1/2)}, w_N = exp(-2 pi i / N).
+// The wrap-around of the product then carries a minus sign (negacyclic), which overlap-save discards anyway, and the
+// Hermitian partner of bin k is N-1-k: with k = k1 + R k2 the partner of row k1 is row R-1-k1 — never the row itself —
+// so ALL R/2 row pairs look alike (no DC / Nyquist special rows).
+//
+//   kernel 1  lw_split  (per stream, window, 64 consecutive t):   n = 4096 j + t
+//       D[k1] = sum_j z[4096 j + t] w_R^{j (k1 + 1/2)}            odd DFT of size R over the stride-4096 frames, two levels:
+//                                                                 j = j1 + 8 j2 in-thread over j2 (size RA = R/8), then
+//                                                                 across the 8 waves (j1) through LDS
+//       rows k1 <  R/2 :  S[k1][t] = D[k1] w_N^{t (k1 + 1/2)}
+//       rows k1 >= R/2 :  S[k1][t] = conj(D[k1]) w_N^{t (R-1-k1 + 1/2)}        "conj-reversed": FFT_4096(S[k1])[k2] =
+//                                                                 conj(X[N-1-k]) at k = (R-1-k1) + R k2 — the partner
+//                                                                 bin of the lower row lands in the SAME lane
+//       A real last channel (odd channel count) gives S[R-1-k1] == S[k1]: its upper rows are neither stored nor transformed.
+//   kernel 2  lw_rows   (per stream, window, row pair {ra, rb = R-1-ra}; row pairs pinned to XCDs, the 512 KB table slice
+//                        of a row pair stays in that XCD's L2 while every stream passes):
+//       Z1 = FFT_4096(S[ra]),  V = FFT_4096(S[rb])  per channel pair        (8 x 512: radix-8 pass + per-wave 512-point sub-FFTs)
+//       W1 += Z1 T0 + V T1 ;  W2 += V T2 + Z1 T3                          2x2 complex MAC per bin, all in-lane: no partner
+//                                                                            exchange, no split of the packed real channels
+//       s1 = IFFT_4096(W1), s2 = IFFT_4096(W2)  -> scratch
+//   kernel 3  lw_merge  (per stream, window, 64 consecutive t): the mirror image of kernel 1 on (s1, s2), stores the
+//       last `hop` frames of the window as interleaved stereo.
+// Tables T0..T3 (host, float64, csrc/host/tables.cpp build_lw_tables): with A_p, B_p as in tile_ols.hpp but sampled at
+// k + 1/2 and k' = N-1-k:  T0 = A[k], T1 = B[k], T2 = conj(A[k']), T3 = conj(B[k']).
+// The algebra is checked in float64 by tools/lw/math_check.py; this file under CPU thread emulation by tests/test_emu_lw.py.
+#pragma once
+#include "tile_ols.hpp"
+
+namespace awk {
+
+constexpr int kLwM = 4096;                  // row length (frames between the R strided sub-sequences of a window)
+constexpr int kLwInner = kLwM / kSub;       // 8 inner rows of 512 per row: radix of the row kernel's pass 1
+constexpr int kLwTw = 64;                   // frames t per split / merge tile: one wave wide
+constexpr int kLwChunks = kLwM / kLwTw;     // 64 tiles per (stream, window)
+
+struct alignas(16) LwTab { cf t0, t1, t2, t3; };
+
+struct LwParams {
+    const float *in;        // [stream][frames][C] interleaved
+    float *out;             // [stream][frames][2]
+    const float *hist;      // [stream][hist_len][C]: the frames preceding in[...][0]
+    const float *zeros;     // >= 64 bytes of zeros
+    long long frames;       // frames per stream in this call
+    int n_channels, n_pairs;
+    int real_last;          // odd channel count: the last pair's second channel is absent (real input)
+    int hist_len;           // N - hop >= taps - 1: window positions below it are discarded
+    int hop;                // new output frames per window
+    int n_windows;          // ceil(frames / hop)
+    int R, N;               // R = 8 RA rows of kLwM frames
+    cf *spec;               // [stream][window][pair][rows: R, or R/2 for a real last pair][4096]
+    long long spec_per_sw;  // complex elements of spec per (stream, window)
+    cf *wrows;              // [stream][window][row pair][2][4096]: s1, s2
+    const LwTab *tab;       // [row pair][pair][8][512]: bin k2 = q1 + 8 q2 of the row pair at [q1][q2]
+    const cf *tw_coarse;    // [2N/64]: w_{2N}^{64 e}
+    const cf *tw_fine;      // [R/2][64]: w_{2N}^{lane (2 k1 + 1)}
+    const cf *tw_r;         // [8][RA]: w_{2R}^{j1 (2 ka + 1)}
+    const cf *tw1m;         // [512]: w_4096^{t}
+    const cf *twa, *twb;    // sub-FFT twiddles of the context (tile_ols.hpp)
+    int persistent_wgs;
+};
+
+// ---- compile-time constants: w_32^m = cos(pi m/16) - i sin(pi m/16) ---------------------------------------------
+constexpr float lw_cos16_q(int m) {       // cos(pi m / 16), 0 <= m <= 8
+    return m == 0 ? 1.0f : m == 1 ? 0.98078528040323044913f : m == 2 ? 0.92387953251128675613f : m == 3 ? 0.83146961230254523708f
+         : m == 4 ? 0.70710678118654752440f : m == 5 ? 0.55557023301960222474f : m == 6 ? 0.38268343236508977173f
+         : m == 7 ? 0.19509032201612826785f : 0.0f;
+}
+constexpr float lw_cos16(int m) {
+    m &= 31;
+    return m <= 8 ? lw_cos16_q(m) : m <= 16 ? -lw_cos16_q(16 - m) : m <= 24 ? -lw_cos16_q(m - 16) : lw_cos16_q(32 - m);
+}
+constexpr float lw_sin16(int m) { return lw_cos16(m - 8); }
+
+// a * w_32^M (forward) or a * conj(w_32^M) (INV)
+template <bool INV, int M> AW_HD cf lw_mul_w32(cf a) {
+    constexpr int m = M & 31;
+    if constexpr (m == 0) return a;
+    else if constexpr (m == 8) return rot90<INV>(a);
+    else if constexpr (m == 16) return mk(-a.x, -a.y);
+    else if constexpr (m == 24) return rot90<!INV>(a);
+    else {
+        constexpr float c = lw_cos16(m), s = INV ? lw_sin16(m) : -lw_sin16(m);
+        return mk(a.x * c - a.y * s, a.x * s + a.y * c);
+    }
+}
+
+template <int I> struct LwIdx { static constexpr int value = I; };
+template <int NN, int I = 0, class F> AW_HD void lw_unroll(F &&f) {
+    if constexpr (I < NN) { f(LwIdx<I>{}); lw_unroll<NN, I + 1>(f); }
+}
+
+template <bool INV, int NN> AW_HD void lw_fft(cf (&v)[NN]) {
+    static_assert(NN == 2 || NN == 4 || NN == 8 || NN == 16, "in-register radix");
+    if constexpr (NN == 16) fft16<INV>(v);
+    else if constexpr (NN == 8) fft8<INV>(v);
+    else if constexpr (NN == 4) fft4<INV>(v[0], v[1], v[2], v[3]);
+    else { const cf a = v[0] + v[1], b = v[0] - v[1]; v[0] = a; v[1] = b; }
+}
+
+// odd DFT of size NN over the register index:  v[k] <- sum_j v[j] w_NN^{j (k + 1/2)}   (INV: conjugate kernel)
+template <bool INV, int NN> AW_HD void lw_odd_dft(cf (&v)[NN]) {
+    if constexpr (!INV) lw_unroll<NN>([&](auto J) { v[J.value] = lw_mul_w32<false, J.value * (16 / NN)>(v[J.value]); });
+    lw_fft<INV, NN>(v);
+    if constexpr (INV) lw_unroll<NN>([&](auto J) { v[J.value] = lw_mul_w32<true, J.value * (16 / NN)>(v[J.value]); });
+}
+
+struct __attribute__((packed, aligned(4))) f3u { float x, y, z; };
+
+// One whole interleaved frame of CS channels -> registers (dword-aligned vector loads; exactly CS floats are read).
+template <int CS> AW_HD void lw_load_frame(const float *src, float (&d)[CS]) {
+    constexpr int n4 = CS / 4, rem = CS % 4;
+#pragma unroll
+    for (int g = 0; g < n4; ++g) {
+        if constexpr (CS % 4 == 0) {
+            const f4 v = *reinterpret_cast<const f4 *>(src + 4 * g);
+            d[4 * g] = v.x; d[4 * g + 1] = v.y; d[4 * g + 2] = v.z; d[4 * g + 3] = v.w;
+        } else {
+            const f4u v = *reinterpret_cast<const f4u *>(src + 4 * g);
+            d[4 * g] = v.x; d[4 * g + 1] = v.y; d[4 * g + 2] = v.z; d[4 * g + 3] = v.w;
+        }
+    }
+    if constexpr (rem == 3) {
+        const f3u v = *reinterpret_cast<const f3u *>(src + 4 * n4);
+        d[4 * n4] = v.x; d[4 * n4 + 1] = v.y; d[4 * n4 + 2] = v.z;
+    } else if constexpr (rem == 2) {
+        if constexpr (CS % 2 == 0) { const f2 v = *reinterpret_cast<const f2 *>(src + 4 * n4); d[4 * n4] = v.x; d[4 * n4 + 1] = v.y; }
+        else { const f2u v = *reinterpret_cast<const f2u *>(src + 4 * n4); d[4 * n4] = v.x; d[4 * n4 + 1] = v.y; }
+    } else if constexpr (rem == 1) {
+        d[4 * n4] = src[4 * n4];
+    }
+}
+
+// w_N^{t (k1 + 1/2)} for t = 64 tc + lane, k1 < R/2: one wave-uniform (scalar) and one lane-contiguous table read
+AW_HD cf lw_tau(const LwParams &p, int tc, int lane, int k1) {
+    const cf c = p.tw_coarse[(tc * (2 * k1 + 1)) & (p.N / 32 - 1)];
+    const cf f = p.tw_fine[k1 * 64 + lane];
+    return cmul(c, f);
+}
+
+// ---- kernel 1: split ---------------------------------------------------------------------------------------------
+// Tile id = (stream, window) * 64 + tc.  512 threads: wave = j1, lane = t - 64 tc.  LDS: [2][RA][8][64] complex.
+template <int RA> constexpr int lw_split_lds_elems() { return 2 * RA * 8 * 64; }
+
+template <class Ctx, int RA, int CS>
+AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long long step, long long end) {
+    static_assert(RA == 4 || RA == 8 || RA == 16, "R = 32, 64 or 128 rows");
+    static_assert(CS >= 1 && CS <= 8, "up to eight channels per group");
+    constexpr int R = 8 * RA, NP = (CS + 1) / 2, NPASS = (NP + 1) / 2, NCOMBO = RA / 4, G = RA >= 8 ? RA / 8 : 1;
+    if (first >= end) return;
+    const int lane = ctx.lane(), wave = ctx.wave();
+    cf *lds = ctx.lds();
+    float raw[RA][CS];
+    auto load_tile = [&](long long id) {
+        const long long sw = (long long)((unsigned long long)id / (unsigned)kLwChunks);
+        const int tc = (int)(id - sw * kLwChunks);
+        const long long stream = sw / p.n_windows;
+        const int win = (int)(sw - stream * p.n_windows);
+        const float *in_s = p.in + stream * p.frames * CS;
+        const float *hist_s = p.hist + stream * (long long)p.hist_len * CS;
+        const long long fb = (long long)win * p.hop - p.hist_len + (long long)kLwM * wave + tc * kLwTw + lane;
+#pragma unroll
+        for (int j2 = 0; j2 < RA; ++j2) {
+            const long long f = fb + (long long)kLwM * 8 * j2;
+            // frames before the call: the history buffer; past its end: a page of zeros (a pointer select, never a select on data)
+            const float *src = f < 0 ? hist_s + ((long long)p.hist_len + f) * CS : (f >= p.frames ? p.zeros : in_s + f * CS);
+            lw_load_frame<CS>(src, raw[j2]);
+        }
+    };
+    load_tile(first);
+    for (long long id = first; id < end; id += step) {
+        const long long sw = (long long)((unsigned long long)id / (unsigned)kLwChunks);
+        const int tc = (int)(id - sw * kLwChunks);
+        const int t = tc * kLwTw + lane;
+        cf *spec_sw = p.spec + sw * p.spec_per_sw;
+        lw_unroll<NPASS>([&](auto PP) {
+            constexpr int pp = PP.value;
+            if (pp > 0 || id != first) ctx.barrier();                 // every wave is done reading the exchange buffer
+            // step 1: odd DFT over j2 (this thread's RA frames), twiddle w_R^{j1 (ka + 1/2)}, to LDS [q][ka][j1][lane]
+            lw_unroll<2>([&](auto Q) {
+                constexpr int q = Q.value, pair = 2 * pp + q;
+                if constexpr (pair < NP) {
+                    cf x[RA];
+#pragma unroll
+                    for (int j2 = 0; j2 < RA; ++j2) x[j2] = mk(raw[j2][2 * pair], 2 * pair + 1 < CS ? raw[j2][(2 * pair + 1) % CS] : 0.0f);
+                    lw_odd_dft<false, RA>(x);
+#pragma unroll
+                    for (int ka = 0; ka < RA; ++ka)
+                        lds[((q * RA + ka) * 8 + wave) * 64 + lane] = cmul(x[ka], p.tw_r[wave * RA + ka]);
+                }
+            });
+            if constexpr (pp == NPASS - 1) load_tile(id + step < end ? id + step : id);     // the frames are consumed: fetch the next tile's (the last one re-reads its own)
+            ctx.barrier();
+            // step 3: DFT-8 over j1 -> kb, row k1 = RA kb + ka; twiddle; rows to scratch (512 contiguous bytes per wave and row)
+#pragma unroll
+            for (int i = 0; i < NCOMBO; ++i) {
+                const int q = RA >= 8 ? i / G : wave / RA;                      // uniform
+                const int ka = RA >= 8 ? wave + 8 * (i % G) : wave % RA;
+                const int pair = 2 * pp + q;
+                if (pair >= NP) continue;
+                cf v[8];
+#pragma unroll
+                for (int j1 = 0; j1 < 8; ++j1) v[j1] = ctx.ld(lds + ((q * RA + ka) * 8 + j1) * 64 + lane);
+                fft8<false>(v);
+                const bool real_pair = (CS & 1) && pair == NP - 1;
+                cf *dst = spec_sw + (long long)pair * p.N + t;
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) {
+                    const int k1 = RA * kb + ka;
+                    if (kb < 4) {
+                        ctx.st_stream(dst + (long long)k1 * kLwM, cmul(v[kb], lw_tau(p, tc, lane, k1)));
+                    } else if (!real_pair) {
+                        ctx.st_stream(dst + (long long)k1 * kLwM, cmul(conj(v[kb]), lw_tau(p, tc, lane, R - 1 - k1)));
+                    }
+                }
+            }
+        });
+    }
+}
+
+// ---- kernel 2: rows ------------------------------------------------------------------------------------------------
+// One 512-point DFT over the lane dimension (sub_fft512x2 of tile_ols.hpp with one row).
+template <bool INV, class Ctx>
+AW_HD void lw_sub_fft512(Ctx &ctx, cf (&a)[8], cf *scr, const cf *twa, const cf *twb, int lane) {
+    fft8<INV>(a);
+#pragma unroll
+    for (int ka = 1; ka < 8; ++ka) a[ka] = twmul<INV>(a[ka], ctx.ld(twa + ka * 64 + lane));
+    const int l0 = lane & 7, kap = lane >> 3;
+#pragma unroll
+    for (int ka = 0; ka < 8; ++ka) scr[ka * 72 + lane] = a[ka];
+    ctx.wave_sync();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = ctx.ld(scr + kap * 72 + l0 + 8 * i);
+    ctx.wave_sync();
+    fft8<INV>(a);
+#pragma unroll
+    for (int kb = 1; kb < 8; ++kb) a[kb] = twmul<INV>(a[kb], ctx.ld(twb + kb * 8 + l0));
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) scr[(kb * 8 + kap) * 9 + l0] = a[kb];
+    ctx.wave_sync();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = ctx.ld(scr + lane * 9 + i);
+    ctx.wave_sync();
+    fft8<INV>(a);
+}
+
+// w^0 .. w^7 by a depth-3 product tree
+AW_HD void lw_powers8(cf w, cf (&pw)[8]) {
+    pw[0] = mk(1.f, 0.f);
+    pw[1] = w;
+    pw[2] = cmul(w, w);
+    pw[3] = cmul(pw[2], w);
+    pw[4] = cmul(pw[2], pw[2]);
+    pw[5] = cmul(pw[4], w);
+    pw[6] = cmul(pw[4], pw[2]);
+    pw[7] = cmul(pw[4], pw[3]);
+}
+
+// Virtual tile id vid -> (row pair, stream-window): rp = rp0 + rp_step * (vid / n_sw), sw = vid % n_sw.  The GPU kernel
+// gives every XCD the row pairs rp = xcd (mod 8), walked one after the other: the 32 workgroups of an XCD work on the
+// same row pair at a time and its 512 KB table slice stays in their L2.
+struct LwRowTile { int rp; long long sw; };
+AW_HD LwRowTile lw_row_tile(long long vid, long long n_sw, int rp0, int rp_step) {
+    LwRowTile r;
+    const long long q = vid / n_sw;
+    r.rp = rp0 + rp_step * (int)q;
+    r.sw = vid - q * n_sw;
+    return r;
+}
+
+template <class Ctx, int NP, bool REAL_LAST>
+AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long step, long long end, long long n_sw, int rp0, int rp_step) {
+    static_assert(NP >= 1 && NP <= 8, "channel pairs");
+    constexpr int NB = (NP + 1) / 2;
+    if (first >= end) return;
+    const int t0 = ctx.tid();
+    int t = t0, lane = ctx.lane();
+    const int wave = ctx.wave();
+    cf *buf0 = ctx.lds();
+    cf *buf1 = buf0 + kBufElems;
+    cf *twa = buf1 + kBufElems;
+    cf *twb = twa + kTwaElems;
+    const cf w1 = p.tw1m[t];
+    twa[t] = p.twa[t];
+    if (t < kTwbElems) twb[t] = p.twb[t];
+    const int R = p.R;
+
+    cf raw[2][2][8];          // [pair of the batch][row ra / rb][j2]: row samples t + 512 j2
+    auto load_batch = [&](long long vid, int b) {
+        const LwRowTile tl = lw_row_tile(vid, n_sw, rp0, rp_step);
+        const cf *spec_sw = p.spec + tl.sw * p.spec_per_sw;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pair = 2 * b + h;
+            if (pair >= NP) break;                                     // compile-time after unrolling
+            const cf *base = spec_sw + (long long)pair * p.N + t;
+#pragma unroll
+            for (int j2 = 0; j2 < 8; ++j2) raw[h][0][j2] = ctx.ld_stream(base + (long long)tl.rp * kLwM + 512 * j2);
+            if (!(REAL_LAST && pair == NP - 1)) {
+#pragma unroll
+                for (int j2 = 0; j2 < 8; ++j2) raw[h][1][j2] = ctx.ld_stream(base + (long long)(R - 1 - tl.rp) * kLwM + 512 * j2);
+            }
+        }
+    };
+    load_batch(first, 0);
+    for (long long vid = first; vid < end; vid += step) {
+        t = ctx.opaque_i(t0);                          // keeps lane-dependent addresses from living across the tile loop
+        lane = t & 63;
+        const LwRowTile tl = lw_row_tile(vid, n_sw, rp0, rp_step);
+        cf wacc[2][8];                                 // W1, W2 of this wave's inner row: bins q2 = lane + 64 kc
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wacc[s][i] = mk(0.f, 0.f);
+
+        lw_unroll<NB>([&](auto BB) {
+            constexpr int b = BB.value;
+            if (b > 0) ctx.barrier();                  // every wave is done reading buf0 / buf1
+            {   // pass 1: radix-8 over j2 -> q1, twiddle w_4096^{t q1}; rows 0-7 of a buffer = row ra, rows 8-15 = row rb
+                cf pw[8];
+                lw_powers8(ctx.opaque(w1), pw);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    constexpr int pair0 = 2 * b;
+                    if (pair0 + h >= NP) break;
+                    cf *buf = h == 0 ? buf0 : buf1;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        if (r == 1 && REAL_LAST && pair0 + h == NP - 1) break;
+                        cf x[8];
+#pragma unroll
+                        for (int j2 = 0; j2 < 8; ++j2) x[j2] = raw[h][r][j2];
+                        fft8<false>(x);
+#pragma unroll
+                        for (int q1 = 1; q1 < 8; ++q1) x[q1] = cmul(x[q1], pw[q1]);
+#pragma unroll
+                        for (int q1 = 0; q1 < 8; ++q1) buf[(8 * r + q1) * kRowStride + t] = x[q1];
+                    }
+                }
+            }
+            if constexpr (b + 1 < NB) load_batch(vid, b + 1);          // the next batch's rows travel under this batch's sub-FFTs
+            ctx.barrier();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                constexpr int pair0 = 2 * b;
+                const int pair = pair0 + h;
+                if (pair >= NP) break;
+                cf *buf = h == 0 ? buf0 : buf1;
+                cf *row0 = buf + wave * kRowStride, *row1 = buf + (8 + wave) * kRowStride;
+                const LwTab *tb = p.tab + (((long long)tl.rp * NP + pair) * kLwInner + wave) * kSub + lane;
+                if (REAL_LAST && pair == NP - 1) {
+                    // real channel: V == Z1; the host has folded T1 into T0 and T2 into T3
+                    cf z[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) z[i] = ctx.ld(row0 + lane + 64 * i);
+                    ctx.wave_sync();
+                    lw_sub_fft512<false>(ctx, z, row0, twa, twb, lane);
+#pragma unroll
+                    for (int kc = 0; kc < 8; ++kc) {
+                        const LwTab T = tb[64 * kc];
+                        wacc[0][kc] = cfma(z[kc], T.t0, wacc[0][kc]);
+                        wacc[1][kc] = cfma(z[kc], T.t3, wacc[1][kc]);
+                    }
+                } else {
+                    cf z[2][8];
+                    ctx.template ld8x2<64>(z[0], row0 + lane, z[1], row1 + lane);
+                    ctx.wave_sync();
+                    sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
+#pragma unroll
+                    for (int kc = 0; kc < 8; ++kc) {
+                        const LwTab T = tb[64 * kc];
+                        wacc[0][kc] = cfma(z[0][kc], T.t0, wacc[0][kc]);
+                        wacc[0][kc] = cfma(z[1][kc], T.t1, wacc[0][kc]);
+                        wacc[1][kc] = cfma(z[1][kc], T.t2, wacc[1][kc]);
+                        wacc[1][kc] = cfma(z[0][kc], T.t3, wacc[1][kc]);
+                    }
+                }
+            }
+        });
+        // inverse: per-wave 512-point inverse sub-FFTs of (W1, W2), rows published in buf0 (rows w and 8 + w are this wave's
+        // own until the barrier), then radix-8 across the inner rows
+        {
+            cf *row0 = buf0 + wave * kRowStride, *row1 = buf0 + (8 + wave) * kRowStride;
+            ctx.wave_sync();                                  // this wave's forward reads of its rows are complete
+            sub_fft512x2<true>(ctx, wacc, row0, row1, twa, twb, lane);
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) { row0[lane + 64 * kc] = wacc[0][kc]; row1[lane + 64 * kc] = wacc[1][kc]; }
+        }
+        load_batch(vid + step < end ? vid + step : vid, 0);      // the next tile's first batch, under the final pass (the last tile re-reads its own)
+        ctx.barrier();
+        {
+            cf pw[8];
+            lw_powers8(ctx.opaque(w1), pw);
+            cf *dst = p.wrows + (tl.sw * (R / 2) + tl.rp) * (long long)(2 * kLwM) + t;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                cf y[8];
+#pragma unroll
+                for (int q1 = 0; q1 < 8; ++q1) y[q1] = ctx.ld(buf0 + (8 * r + q1) * kRowStride + t);
+#pragma unroll
+                for (int q1 = 1; q1 < 8; ++q1) y[q1] = cmulc(y[q1], pw[q1]);
+                fft8<true>(y);
+#pragma unroll
+                for (int j2 = 0; j2 < 8; ++j2) ctx.st_stream(dst + r * kLwM + 512 * j2, y[j2]);
+            }
+        }
+        ctx.barrier();                                        // the final exchange has been read before buf0 is rewritten
+    }
+}
+
+// ---- kernel 3: merge -------------------------------------------------------------------------------------------------
+// Tile id = (stream, window) * 64 + tc.  512 threads.  LDS: [RA][8][64] complex.
+template <int RA> constexpr int lw_merge_lds_elems() { return RA * 8 * 64; }
+
+template <class Ctx, int RA>
+AW_HD void lw_merge_tiles(Ctx &ctx, const LwParams &p, long long first, long long step, long long end) {
+    static_assert(RA == 4 || RA == 8 || RA == 16, "R = 32, 64 or 128 rows");
+    constexpr int R = 8 * RA, NKA = RA >= 8 ? RA / 8 : 1;
+    const int lane = ctx.lane(), wave = ctx.wave();
+    cf *lds = ctx.lds();
+    for (long long id = first; id < end; id += step) {
+        const long long sw = (long long)((unsigned long long)id / (unsigned)kLwChunks);
+        const int tc = (int)(id - sw * kLwChunks);
+        const int t = tc * kLwTw + lane;
+        const long long stream = sw / p.n_windows;
+        const int win = (int)(sw - stream * p.n_windows);
+        const cf *wr = p.wrows + sw * (long long)p.N + t;
+        if (id != first) ctx.barrier();
+        // step 1: rows k1 = RA kb + ka, kb = 0..7: untwiddle (upper rows: conj-reversed form), inverse DFT-8 over kb -> j1
+#pragma unroll
+        for (int i = 0; i < NKA; ++i) {
+            const int ka = wave + 8 * i;
+            if (ka >= RA) break;                                   // RA = 4: waves 4-7 only take part in step 2
+            cf g[8];
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const int k1 = RA * kb + ka;
+                const int rp = kb < 4 ? k1 : R - 1 - k1;
+                g[kb] = ctx.ld_stream(wr + ((long long)rp * 2 + (kb < 4 ? 0 : 1)) * kLwM);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const int k1 = RA * kb + ka;
+                const int rp = kb < 4 ? k1 : R - 1 - k1;
+                const cf v = cmulc(g[kb], lw_tau(p, tc, lane, rp));
+                g[kb] = kb < 4 ? v : conj(v);
+            }
+            fft8<true>(g);
+#pragma unroll
+            for (int j1 = 0; j1 < 8; ++j1) lds[(ka * 8 + j1) * 64 + lane] = cmulc(g[j1], p.tw_r[j1 * RA + ka]);
+        }
+        ctx.barrier();
+        // step 2: wave = j1; inverse odd DFT over ka -> j2; frame 4096 (j1 + 8 j2) + t of the window
+        cf F[RA];
+#pragma unroll
+        for (int ka = 0; ka < RA; ++ka) F[ka] = ctx.ld(lds + (ka * 8 + wave) * 64 + lane);
+        lw_odd_dft<true, RA>(F);
+        const long long f0 = (long long)win * p.hop - p.hist_len;
+#pragma unroll
+        for (int j2 = 0; j2 < RA; ++j2) {
+            const int n = kLwM * (wave + 8 * j2) + t;
+            const long long f = f0 + n;
+            if (n >= p.hist_len && f < p.frames) ctx.st_stream(reinterpret_cast<cf *>(p.out + (stream * p.frames + f) * 2), F[j2]);
+        }
+    }
+}
+
+}  // namespace awk

@@ -114,4 +114,83 @@ void build_poly_tables(const float *tracks, int n_tracks, int taps, int n_channe
     for (size_t i = 0; i < out.size(); ++i) { out[i].e = tab[0][i]; out[i].o = tab[1][i]; }
 }
 
+// FFT with a precomputed twiddle table tw[k] = exp(-2 pi i k / n), k < n/2 (every entry one cos/sin in double)
+static void fft_inplace_tw(std::vector<cd> &a, const std::vector<cd> &tw) {
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const size_t stride = n / len;
+        for (size_t i = 0; i < n; i += len) {
+            for (size_t k = 0; k < len / 2; ++k) {
+                const cd u = a[i + k], v = a[i + k + len / 2] * tw[k * stride];
+                a[i + k] = u + v;
+                a[i + k + len / 2] = u - v;
+            }
+        }
+    }
+}
+
+void build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
+                     const int32_t *right_track, int R, LwTables &out) {
+    const int M = awk::kLwM;
+    const size_t N = (size_t)R * M;
+    const int n_pairs = (n_channels + 1) / 2;
+    const bool real_last = (n_channels & 1) != 0;
+    // twiddles
+    out.coarse.resize(N / 32);
+    for (size_t e = 0; e < N / 32; ++e) out.coarse[e] = unit(64.0 * (double)e, 2.0 * (double)N);
+    out.fine.resize((size_t)(R / 2) * 64);
+    for (int k1 = 0; k1 < R / 2; ++k1)
+        for (int l = 0; l < 64; ++l) out.fine[(size_t)k1 * 64 + l] = unit((double)l * (2 * k1 + 1), 2.0 * (double)N);
+    const int RA = R / 8;
+    out.tw_r.resize((size_t)8 * RA);
+    for (int j1 = 0; j1 < 8; ++j1)
+        for (int ka = 0; ka < RA; ++ka) out.tw_r[(size_t)j1 * RA + ka] = unit((double)j1 * (2 * ka + 1), 2.0 * R);
+    out.tw1m.resize(512);
+    for (int t = 0; t < 512; ++t) out.tw1m[t] = unit((double)t, (double)M);
+    // filter tables
+    std::vector<cd> tw(N / 2), mod(N);
+    for (size_t k = 0; k < N / 2; ++k) { const double a = -2.0 * M_PI * (double)k / (double)N; tw[k] = cd(std::cos(a), std::sin(a)); }
+    for (size_t n = 0; n < N; ++n) { const double a = -M_PI * (double)n / (double)N; mod[n] = cd(std::cos(a), std::sin(a)); }     // w_N^{n/2}
+    out.tab.assign((size_t)(R / 2) * n_pairs * M, awk::LwTab{awk::mk(0, 0), awk::mk(0, 0), awk::mk(0, 0), awk::mk(0, 0)});
+    const double scale = 1.0 / (2.0 * (double)N);
+    std::vector<cd> zl(N), zr(N);
+    auto tap = [&](int track, size_t i) -> double {
+        if (track < 0 || track >= n_tracks) return 0.0;
+        return i < (size_t)taps ? (double)tracks[(size_t)track * taps + i] : 0.0;
+    };
+    const cd I(0.0, 1.0);
+    auto c32 = [](cd v) { return awk::mk((float)v.real(), (float)v.imag()); };
+    for (int p = 0; p < n_pairs; ++p) {
+        const int a = 2 * p, b = 2 * p + 1;
+        const int la = left_track[a], ra_ = right_track[a];
+        const int lb = b < n_channels ? left_track[b] : -1, rb_ = b < n_channels ? right_track[b] : -1;
+        const bool use_a = la >= 0 && ra_ >= 0, use_b = lb >= 0 && rb_ >= 0;       // both ears mapped, like build_pair_tables
+        for (size_t i = 0; i < N; ++i) {
+            zl[i] = i < (size_t)taps ? cd(use_a ? tap(la, i) : 0.0, use_b ? tap(lb, i) : 0.0) * mod[i] : cd(0.0, 0.0);
+            zr[i] = i < (size_t)taps ? cd(use_a ? tap(ra_, i) : 0.0, use_b ? tap(rb_, i) : 0.0) * mod[i] : cd(0.0, 0.0);
+        }
+        fft_inplace_tw(zl, tw);
+        fft_inplace_tw(zr, tw);
+        const bool fold = real_last && p == n_pairs - 1;
+        for (int rp = 0; rp < R / 2; ++rp) {
+            for (int k2 = 0; k2 < M; ++k2) {
+                const size_t k = (size_t)rp + (size_t)R * k2, kp = N - 1 - k;
+                const cd Ak = (std::conj(zl[kp]) + I * std::conj(zr[kp])) * scale, Bk = (zl[k] + I * zr[k]) * scale;
+                const cd Akp = (std::conj(zl[k]) + I * std::conj(zr[k])) * scale, Bkp = (zl[kp] + I * zr[kp]) * scale;
+                cd t0 = Ak, t1 = Bk, t2 = std::conj(Akp), t3 = std::conj(Bkp);
+                if (fold) { t0 += t1; t3 += t2; t1 = cd(0, 0); t2 = cd(0, 0); }
+                const int q1 = k2 & 7, q2 = k2 >> 3;
+                awk::LwTab &e = out.tab[(((size_t)rp * n_pairs + p) * awk::kLwInner + q1) * awk::kSub + q2];
+                e.t0 = c32(t0); e.t1 = c32(t1); e.t2 = c32(t2); e.t3 = c32(t3);
+            }
+        }
+    }
+}
+
 }  // namespace awh

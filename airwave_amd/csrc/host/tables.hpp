@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../device/tile_ols2.hpp"
+#include "../device/tile_lw.hpp"
 
 namespace awh {
 
@@ -33,5 +34,17 @@ void build_pair_tables(const float *tracks, int n_tracks, int taps, int n_channe
 void build_poly_tables(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
                        const int32_t *right_track, std::vector<awk::cf4> &out);
 inline int poly_history_frames(int taps) { return 2 * (taps / 2); }          // real frames kept between calls (= N2 - hop)
+
+// Long-window path (device/tile_lw.hpp): tables and twiddles of one window length N = R x 4096, R in {32, 64, 128}.
+//   tab    [R/2][pairs][8][512] {T0, T1, T2, T3}: the odd-frequency spectra (k + 1/2) of the pair filters at bin
+//          k = ra + R k2 (k2 = q1 + 8 q2 stored at [q1][q2]) and at its partner k' = N-1-k, scale 1/(2N) folded in; a real last
+//          channel (odd channel count) has T1 folded into T0 and T2 into T3
+//   coarse [N/32]: w_2N^{64 e};  fine [R/2][64]: w_2N^{lane (2 k1 + 1)};  tw_r [8][R/8]: w_2R^{j1 (2 ka + 1)};  tw1m [512]: w_4096^t
+struct LwTables {
+    std::vector<awk::LwTab> tab;
+    std::vector<awk::cf> coarse, fine, tw_r, tw1m;
+};
+void build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
+                     const int32_t *right_track, int R, LwTables &out);
 
 }  // namespace awh

@@ -89,6 +89,7 @@ static aw_status context_create_impl(int32_t device, void *ext_stream, bool use_
     hipError_t e = hipEventCreate(&c->t0);
     if (e == hipSuccess) e = hipEventCreate(&c->t1);
     if (e == hipSuccess) e = awk::prepare_kernels(&c->cfg);
+    if (e == hipSuccess) e = awk::prepare_lw_kernels();
     if (e == hipSuccess) e = awk::prepare_eq_kernels();
     awh::Twiddles tw;
     awh::build_twiddles(tw);
@@ -315,6 +316,13 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
         sp->fwd_one_pair = sp->n_pairs > 4;
         if (const char *e = getenv("AW_PART_FWD")) sp->fwd_one_pair = atoi(e) == 1;
         if (const char *e = getenv("AW_PART_HERM")) sp->herm_ok = atoi(e) != 0;          // A/B: 0 stores the last pair's redundant half too
+        // long calls of this spatializer run on the long-window kernels (device/tile_lw.hpp) — chosen per call, see lw_choose()
+        if (const char *e = getenv("AW_LW")) sp->lw_mode = atoi(e);
+        if (n_in > 8) sp->lw_mode = 0;                                                   // up to four channel pairs
+        if (sp->lw_mode != 0) {
+            sp->lw_tracks = hrir->tracks; sp->lw_n_tracks = hrir->n_tracks;
+            sp->lw_left.assign(left_track, left_track + n_in); sp->lw_right.assign(right_track, right_track + n_in);
+        }
     }
     std::vector<awk::cf2> tab, all;
     if (sp->fused2) {
@@ -356,6 +364,13 @@ void aw_spatializer_destroy(aw_spatializer *sp) {
     for (int i = 0; i < 2; ++i)
         if (sp->d_hist[i]) (void)hipFree(sp->d_hist[i]);
     if (sp->d_spec) (void)hipFree(sp->d_spec);
+    for (auto &pl : sp->lw_plans) {
+        if (pl.d_tab) (void)hipFree(pl.d_tab);
+        if (pl.d_coarse) (void)hipFree(pl.d_coarse);
+        if (pl.d_fine) (void)hipFree(pl.d_fine);
+        if (pl.d_tw_r) (void)hipFree(pl.d_tw_r);
+        if (pl.d_tw1m) (void)hipFree(pl.d_tw1m);
+    }
     if (sp->d_flags) (void)hipFree(sp->d_flags);
     if (sp->d_dbg) (void)hipFree(sp->d_dbg);
     if (sp->d_stage_in) (void)hipFree(sp->d_stage_in);
@@ -379,6 +394,7 @@ int64_t aw_spatializer_info(const aw_spatializer *sp, int32_t what) {
         case 3: return sp->path;
         case 4: return sp->hist_len;
         case 5: return sp->dominant_frames;   // output frames covered by the launch aw_spatializer_kernel_time() times (last call)
+        case 7: return sp->last_lw_R;         // long-window path: rows R of the last call's windows (N = R x 4096); 0 = the partitioned kernels ran
         case 6: return (int64_t)(sp->spec_capacity * sizeof(awk::cf) + (sp->stage_in_cap + sp->stage_out_cap) * sizeof(float));   // grow-only device buffers, bytes
         default: return -1;
     }
@@ -459,7 +475,7 @@ int32_t aw_spatializer_kernel_time(aw_spatializer *sp, double *avg_ms, const cha
     }
     sp->pending.clear();
     if (avg_ms) *avg_ms = sp->kernel_launches ? sp->kernel_ms_sum / sp->kernel_launches : 0.0;
-    if (kernel_name) *kernel_name = sp->path == 0 ? (sp->fused2 ? awk::fused_ols2_kernel_name(sp->n_channels) : sp->fusedh ? awk::fused_olsh_kernel_name(sp->n_channels) : awk::fused_ols_kernel_name(sp->n_channels)) : (sp->cmac_group ? "aw_part_forward_kernel + aw_part_cmac_kernel + aw_part_inverse_kernel" : "aw_part_forward_kernel + aw_part_march_kernel + aw_part_inverse_kernel");
+    if (kernel_name) *kernel_name = sp->path == 0 ? (sp->fused2 ? awk::fused_ols2_kernel_name(sp->n_channels) : sp->fusedh ? awk::fused_olsh_kernel_name(sp->n_channels) : awk::fused_ols_kernel_name(sp->n_channels)) : (sp->last_lw_R ? "aw_lw_split_kernel + aw_lw_rows_kernel + aw_lw_merge_kernel" : sp->cmac_group ? "aw_part_forward_kernel + aw_part_cmac_kernel + aw_part_inverse_kernel" : "aw_part_forward_kernel + aw_part_march_kernel + aw_part_inverse_kernel");
     const int n = sp->kernel_launches;
     sp->kernel_ms_sum = 0.0;
     sp->kernel_launches = 0;
@@ -554,7 +570,9 @@ static aw_status sp_process_fused(aw_spatializer *sp, const float *in, float *ou
 // Grow-only; aw_spatializer_reserve() sizes it ahead of time so that process never allocates.
 struct PartPlan { int n_blocks; long long n_windows; size_t per_stream, per_stream_w; long long chunk; size_t need; };
 
-static PartPlan part_plan(const aw_spatializer *sp, int64_t frames, size_t budget_bytes) {
+// held_elems > 0 (a call inside what aw_spatializer_reserve() sized): the stream chunk is clamped to the buffer that is already
+// there, so that process never reallocates — a short call would otherwise pick a larger chunk whose rounding can exceed it.
+static PartPlan part_plan(const aw_spatializer *sp, int64_t frames, size_t budget_bytes, size_t held_elems = 0) {
     PartPlan pl{};
     const int N = awk::kN, B = sp->hop, P = sp->partitions;
     pl.n_blocks = (int)((frames + B - 1) / B);
@@ -562,6 +580,8 @@ static PartPlan part_plan(const aw_spatializer *sp, int64_t frames, size_t budge
     pl.per_stream = (size_t)pl.n_windows * sp->n_pairs * N;          // complex elements of window spectra
     pl.per_stream_w = (size_t)pl.n_blocks * N;                       // complex elements of accumulated W
     pl.chunk = (long long)(budget_bytes / ((pl.per_stream + pl.per_stream_w) * sizeof(awk::cf)));
+    const long long held_chunk = (long long)(held_elems / (pl.per_stream + pl.per_stream_w));
+    if (held_chunk >= 1 && pl.chunk > held_chunk) pl.chunk = held_chunk;
     if (pl.chunk < 1) pl.chunk = 1;
     if (pl.chunk > sp->n_streams) pl.chunk = sp->n_streams;
     if (pl.chunk > 65535) pl.chunk = 65535;                          // grid.y / grid.z of the CMAC launches
@@ -592,7 +612,7 @@ static aw_status part_ensure_scratch(aw_spatializer *sp, size_t need) {
 
 static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, float *out, int64_t frames) {
     const int N = awk::kN, B = sp->hop, P = sp->partitions;
-    const PartPlan pl = part_plan(sp, frames, part_budget(sp));
+    const PartPlan pl = part_plan(sp, frames, part_budget(sp), frames <= sp->reserved_frames ? sp->spec_capacity : 0);
     const int n_blocks = pl.n_blocks;
     const long long chunk = pl.chunk;
     aw_status st = part_ensure_scratch(sp, pl.need);
@@ -634,6 +654,121 @@ static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, flo
     return AW_OK;
 }
 
+
+/* ---- long-window path (device/tile_lw.hpp) ---------------------------------------------------- */
+// Per call: windows of N = R x 4096 frames, R in {32, 64, 128}, hop = N - hist_len (hist_len = P x 4096 >= taps, the history the
+// partitioned kernels keep too, so both kernel sets serve the same spatializer and the choice is free per call).
+// Cost model (fabric bytes): the long-window kernels move 12 C + 24 bytes per WINDOW frame (input + rows
+// written, rows read + s1/s2 written, s1/s2 read + stereo out), the partitioned ones ~29 C bytes per OUTPUT frame.
+static int lw_choose(const aw_spatializer *sp, int64_t frames, bool for_reserve = false) {
+    if (sp->path != 1 || sp->lw_mode == 0 || sp->n_channels > 8) return 0;
+    // calls inside what aw_spatializer_reserve() sized never build tables: only window lengths whose tables exist are candidates
+    const bool existing_only = !for_reserve && frames <= sp->reserved_frames;
+    auto have = [&](int R) { for (const auto &pl : sp->lw_plans) if (pl.R == R) return true; return false; };
+    const int C = sp->n_channels;
+    int best = 0;
+    double best_cost = 0.0;
+    for (int R : {32, 64, 128}) {
+        const long long N = (long long)R * awk::kLwM, hop = N - sp->hist_len;
+        if (hop < N / 4) continue;                                      // the window must be mostly new frames
+        if (sp->lw_mode > 0 && sp->lw_mode != R) continue;
+        if (existing_only && !have(R)) continue;
+        const long long windows = (frames + hop - 1) / hop;
+        const double cost = (double)windows * (double)N * (12.0 * C + 24.0);
+        if (!best || cost < best_cost) { best = R; best_cost = cost; }
+    }
+    if (!best || sp->lw_mode > 0) return best;
+    const double part_cost = (double)frames * 29.0 * C;
+    const long long N = (long long)best * awk::kLwM, hop = N - sp->hist_len;
+    const long long row_tiles = (long long)sp->n_streams * ((frames + hop - 1) / hop) * (best / 2);
+    if (row_tiles < 128) return 0;                                       // too few tiles to fill the chip: the partitioned kernels' 4096-frame blocks
+    return best_cost < part_cost ? best : 0;
+}
+
+static aw_status lw_get_plan(aw_spatializer *sp, int R, const aw_spatializer::LwPlan **out) {
+    for (const auto &pl : sp->lw_plans)
+        if (pl.R == R) { *out = &pl; return AW_OK; }
+    awh::LwTables t;
+    awh::build_lw_tables(sp->lw_tracks.data(), sp->lw_n_tracks, sp->taps, sp->n_channels, sp->lw_left.data(), sp->lw_right.data(), R, t);
+    aw_spatializer::LwPlan pl;
+    pl.R = R;
+    auto up = [&](const void *src, size_t bytes, void **d) -> hipError_t {
+        hipError_t r = hipMalloc(d, bytes);
+        if (r != hipSuccess) return r;
+        return hipMemcpy(*d, src, bytes, hipMemcpyHostToDevice);
+    };
+    hipError_t e = up(t.tab.data(), t.tab.size() * sizeof(awk::LwTab), reinterpret_cast<void **>(&pl.d_tab));
+    if (e == hipSuccess) e = up(t.coarse.data(), t.coarse.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_coarse));
+    if (e == hipSuccess) e = up(t.fine.data(), t.fine.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_fine));
+    if (e == hipSuccess) e = up(t.tw_r.data(), t.tw_r.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_tw_r));
+    if (e == hipSuccess) e = up(t.tw1m.data(), t.tw1m.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_tw1m));
+    sp->lw_plans.push_back(pl);             // owned (and freed) by the spatializer even when an upload failed half way
+    if (e != hipSuccess) return awr::hip_fail(e, "long-window tables");
+    *out = &sp->lw_plans.back();
+    return AW_OK;
+}
+
+// scratch of one stream chunk: rows of every (stream, window) + s1/s2
+struct LwScratch { long long n_windows; size_t per_stream; long long chunk; size_t need; long long spec_per_sw; };
+static LwScratch lw_scratch(const aw_spatializer *sp, int R, int64_t frames, size_t budget_bytes, size_t held_elems) {
+    LwScratch r{};
+    const long long N = (long long)R * awk::kLwM, hop = N - sp->hist_len;
+    const int real_last = sp->n_channels & 1;
+    r.n_windows = (frames + hop - 1) / hop;
+    r.spec_per_sw = (long long)(sp->n_pairs - real_last) * N + (real_last ? N / 2 : 0);
+    r.per_stream = (size_t)r.n_windows * (size_t)(r.spec_per_sw + N);
+    r.chunk = (long long)(budget_bytes / sizeof(awk::cf) / r.per_stream);
+    const long long held_chunk = (long long)(held_elems / r.per_stream);       // see part_plan
+    if (held_chunk >= 1 && r.chunk > held_chunk) r.chunk = held_chunk;
+    if (r.chunk < 1) r.chunk = 1;
+    if (r.chunk > sp->n_streams) r.chunk = sp->n_streams;
+    r.need = r.per_stream * (size_t)r.chunk;
+    return r;
+}
+
+static aw_status sp_process_longwin(aw_spatializer *sp, int R, const float *in, float *out, int64_t frames) {
+    const aw_spatializer::LwPlan *plan = nullptr;
+    aw_status st = lw_get_plan(sp, R, &plan);
+    if (st != AW_OK) return st;
+    const LwScratch sc = lw_scratch(sp, R, frames, part_budget(sp), frames <= sp->reserved_frames ? sp->spec_capacity : 0);
+    st = part_ensure_scratch(sp, sc.need);
+    if (st != AW_OK) return st;
+    const long long N = (long long)R * awk::kLwM;
+    sp->dominant_frames = 0;
+    for (long long s0 = 0; s0 < sp->n_streams; s0 += sc.chunk) {
+        const int ns = (int)std::min<long long>(sc.chunk, sp->n_streams - s0);
+        awk::LwParams p{};
+        p.in = in + (size_t)s0 * frames * sp->n_channels;
+        p.out = out + (size_t)s0 * frames * 2;
+        p.hist = sp->d_hist[sp->hist_cur] + (size_t)s0 * sp->hist_len * sp->n_channels;
+        p.zeros = sp->ctx->d_zeros;
+        p.frames = frames; p.n_channels = sp->n_channels; p.n_pairs = sp->n_pairs; p.real_last = sp->n_channels & 1;
+        p.hist_len = sp->hist_len; p.hop = (int)(N - sp->hist_len); p.n_windows = (int)sc.n_windows;
+        p.R = R; p.N = (int)N;
+        p.spec = sp->d_spec; p.spec_per_sw = sc.spec_per_sw;
+        p.wrows = sp->d_spec + (size_t)sc.chunk * sc.n_windows * sc.spec_per_sw;
+        p.tab = plan->d_tab; p.tw_coarse = plan->d_coarse; p.tw_fine = plan->d_fine; p.tw_r = plan->d_tw_r; p.tw1m = plan->d_tw1m;
+        p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb;
+        p.persistent_wgs = sp->ctx->cfg.persistent_wgs;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (sp->profiling) {
+            e0 = sp_get_event(sp); e1 = sp_get_event(sp);
+            AW_HIP_TRY(hipEventRecord(e0, sp->ctx->stream));
+        }
+        SpStageTimer tm(sp);
+        awk::StageTimer *tmp = sp->profiling ? &tm : nullptr;
+        AW_HIP_TRY(awk::launch_lw_split(p, ns, sp->ctx->stream, tmp));
+        AW_HIP_TRY(awk::launch_lw_rows(p, ns, sp->ctx->stream, tmp));
+        AW_HIP_TRY(awk::launch_lw_merge(p, ns, sp->ctx->stream, tmp));
+        if (sp->profiling) {
+            AW_HIP_TRY(hipEventRecord(e1, sp->ctx->stream));
+            sp->pending.emplace_back(e0, e1);
+        }
+        sp->dominant_frames = (long long)ns * frames;
+    }
+    return AW_OK;
+}
+
 static aw_status sp_grow(float **buf, size_t *cap, size_t need);
 
 // Sizes every grow-only device buffer for calls of up to max_frames frames, so that the process entries never
@@ -643,8 +778,17 @@ aw_status aw_spatializer_reserve(aw_spatializer *sp, int64_t max_frames) {
     if (max_frames <= 0) return fail(AW_ERR_INVALID_ARGUMENT, "max_frames must be positive");
     AW_HIP_TRY(hipSetDevice(sp->ctx->device));
     if (sp->path == 1) {
+        // shorter calls than max_frames may run on the partitioned kernels or on a smaller window: size for both kernel sets
         const PartPlan pl = part_plan(sp, max_frames, part_budget(sp));
-        aw_status st = part_ensure_scratch(sp, pl.need);
+        size_t need = pl.need;
+        const int lw_R = lw_choose(sp, max_frames, true);
+        if (lw_R) {
+            const aw_spatializer::LwPlan *plan = nullptr;
+            aw_status st = lw_get_plan(sp, lw_R, &plan);
+            if (st != AW_OK) return st;
+            need = std::max(need, lw_scratch(sp, lw_R, max_frames, part_budget(sp), 0).need);
+        }
+        aw_status st = part_ensure_scratch(sp, need);
         if (st != AW_OK) return st;
     }
     if (sp->n_streams == 1) {       // plug-in shaped use (host / planar entries): their staging buffers too
@@ -662,7 +806,10 @@ aw_status aw_spatializer_process(aw_spatializer *sp, const float *in, float *out
     if (frames <= 0) return frames == 0 ? AW_OK : fail(AW_ERR_INVALID_ARGUMENT, "frames must be >= 0");
     AW_HIP_TRY(hipSetDevice(sp->ctx->device));
     aw_status st = AW_OK;
+    const int lw_R = lw_choose(sp, frames);
+    sp->last_lw_R = lw_R;
     if (sp->path == 0) st = sp_process_fused(sp, in, out, frames);
+    else if (lw_R) st = sp_process_longwin(sp, lw_R, in, out, frames);
     else st = sp_process_partitioned(sp, in, out, frames);
     if (st != AW_OK) return st;
     // carry the convolution tail: next call's history = last hist_len frames of (history ++ input)

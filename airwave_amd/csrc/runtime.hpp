@@ -62,6 +62,15 @@ struct aw_spatializer {
     bool cmac_group = false;            // partitioned path: block-group CMAC kernel instead of the marched one (> 8 pairs; AW_PART_CMAC=group)
     bool fwd_one_pair = false;          // partitioned path: forward kernel with one channel pair per workgroup (default for more than 4 pairs; AW_PART_FWD=1|2 forces either form)
     bool herm_ok = true;                // partitioned path, odd channel count: store/read only the non-redundant half of the last pair's spectrum
+    // long-window path (device/tile_lw.hpp): chosen per call for long calls of a path-1 spatializer; tables per window length, built on first use
+    // (aw_spatializer_reserve builds the one its max_frames implies)
+    struct LwPlan { int R = 0; awk::LwTab *d_tab = nullptr; awk::cf *d_coarse = nullptr, *d_fine = nullptr, *d_tw_r = nullptr, *d_tw1m = nullptr; };
+    std::vector<LwPlan> lw_plans;
+    int lw_mode = -1;                   // AW_LW at create: -1 automatic (cost model), 0 never, 32/64/128 force that R where it fits
+    std::vector<float> lw_tracks;       // the HRIR and channel map, kept for the lazily built tables
+    std::vector<int32_t> lw_left, lw_right;
+    int lw_n_tracks = 0;
+    int last_lw_R = 0;                  // R of the last call (0: the partitioned kernels ran)
     int64_t reserved_frames = 0;        // aw_spatializer_reserve(): buffers are sized for calls up to this many frames
     // host-entry staging (grow-only)
     float *d_stage_in = nullptr, *d_stage_out = nullptr;

@@ -11,7 +11,7 @@ _DEFS = os.environ.get("AW_EMU_DEFINES", "").split()          # e.g. "-DAW_SUBFF
 _LIB = os.path.join(_HERE, "libemu.so" if not _DEFS else "libemu_variant.so")
 _SRCS = [os.path.join(_HERE, "emu_harness.cpp"), os.path.join(_ROOT, "airwave_amd/csrc/host/tables.cpp"),
          os.path.join(_ROOT, "airwave_amd/csrc/host/eq.cpp")]
-_DEPS = _SRCS + [os.path.join(_ROOT, "airwave_amd/csrc/device", f) for f in ("tile_ols.hpp", "tile_ols2.hpp", "tile_olsh.hpp", "tile_march.hpp", "cplx.hpp", "eq_cascade.hpp")] + [
+_DEPS = _SRCS + [os.path.join(_ROOT, "airwave_amd/csrc/device", f) for f in ("tile_ols.hpp", "tile_ols2.hpp", "tile_olsh.hpp", "tile_march.hpp", "tile_lw.hpp", "cplx.hpp", "eq_cascade.hpp")] + [
     os.path.join(_ROOT, "airwave_amd/csrc/host/tables.hpp"), os.path.join(_ROOT, "airwave_amd/csrc/host/eq.hpp")]
 _lib = None
 
@@ -29,6 +29,8 @@ def lib():
                                        ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _lib.emu_partitioned.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
                                          ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
+        _lib.emu_longwin.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
+                                     ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _lib.emu_fft_small.argtypes = [fp, ctypes.c_int, ctypes.c_int]
         _lib.emu_eq_process.argtypes = [fp, fp, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_longlong, ctypes.c_double,
                                         ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int]
@@ -70,6 +72,28 @@ def partitioned(x, tracks, left_track, right_track, hist=None, cmac="march"):
                                tr.ctypes.data_as(fp), tr.shape[0], tr.shape[1], C, lt.ctypes.data_as(ip),
                                rt.ctypes.data_as(ip), F, S, 1 if cmac == "group" else 0)
     assert rc == 0
+    return out
+
+
+def longwin(x, tracks, left_track, right_track, R=32, hop=None, hist=None):
+    """Long-window path (tile_lw.hpp): windows of R x 4096 frames; x: [streams][frames][C] -> [streams][frames][2]."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    S, F, C = x.shape
+    tr = np.ascontiguousarray(tracks, dtype=np.float32)
+    lt = np.ascontiguousarray(left_track, dtype=np.int32)
+    rt = np.ascontiguousarray(right_track, dtype=np.int32)
+    N = R * 4096
+    if hop is None:
+        hop = N - (tr.shape[1] - 1)
+    out = np.full((S, F, 2), np.nan, dtype=np.float32)
+    h = None
+    if hist is not None:
+        h = np.ascontiguousarray(hist, dtype=np.float32)
+        assert h.shape == (S, N - hop, C)
+    rc = lib().emu_longwin(x.ctypes.data_as(fp), out.ctypes.data_as(fp), None if h is None else h.ctypes.data_as(fp),
+                           tr.ctypes.data_as(fp), tr.shape[0], tr.shape[1], C, lt.ctypes.data_as(ip), rt.ctypes.data_as(ip),
+                           F, S, R, hop)
+    assert rc == 0, rc
     return out
 
 

@@ -17,6 +17,7 @@
 #include "../../airwave_amd/csrc/device/tile_ols.hpp"
 #include "../../airwave_amd/csrc/device/tile_olsh.hpp"
 #include "../../airwave_amd/csrc/device/tile_march.hpp"
+#include "../../airwave_amd/csrc/device/tile_lw.hpp"
 #include "../../airwave_amd/csrc/device/eq_cascade.hpp"
 #include "../../airwave_amd/csrc/host/eq.hpp"
 #include "../../airwave_amd/csrc/host/tables.hpp"
@@ -64,6 +65,7 @@ struct EmuCtx {
         for (int i = 0; i < 8; ++i) { a[i] = p0[i * STRIDE]; b[i] = p1[i * STRIDE]; }
     }
     void st_stream(awk::cf *q, awk::cf v) const { *q = v; }
+    awk::cf ld_stream(const awk::cf *q) const { return *q; }
     void st_stream4(float *q, float a, float b, float c, float d) const { q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
     awk::cf xchg1(awk::cf v) const {          // value of lane ^ 1
         sh->xs[(size_t)tid_ * 2] = v;
@@ -390,6 +392,77 @@ int emu_partitioned(const float *in, float *out, const float *hist, const float 
                     }
     }
     run([&](EmuCtx &ctx, int s, int b) { tile_part_inverse<EmuCtx>(ctx, p, s, b); }, p.n_blocks);
+    return 0;
+}
+
+// The long-window path (tile_lw.hpp): split -> rows -> merge on windows of N = R x 4096 frames, R in {32, 64, 128}.
+// hist: [stream][hist_len][C] or NULL; hist_len = N - hop must be >= taps - 1 (hop given by the caller).
+int emu_longwin(const float *in, float *out, const float *hist, const float *tracks, int n_tracks, int taps, int n_channels,
+                const int32_t *left_track, const int32_t *right_track, long long frames, int n_streams, int R, int hop) {
+    using namespace awk;
+    if (R != 32 && R != 64 && R != 128) return -1;
+    const long long N = (long long)R * kLwM;
+    if (hop <= 0 || N - hop < taps - 1 || n_channels < 1 || n_channels > 8) return -2;
+    awh::Twiddles tw;
+    awh::build_twiddles(tw);
+    awh::LwTables lt;
+    awh::build_lw_tables(tracks, n_tracks, taps, n_channels, left_track, right_track, R, lt);
+    LwParams p{};
+    p.in = in; p.out = out; p.zeros = g_zeros; p.frames = frames;
+    p.n_channels = n_channels; p.n_pairs = (n_channels + 1) / 2; p.real_last = n_channels & 1;
+    p.hop = hop; p.hist_len = (int)(N - hop); p.n_windows = (int)((frames + hop - 1) / hop);
+    p.R = R; p.N = (int)N;
+    std::vector<float> hist_pad((size_t)n_streams * p.hist_len * n_channels + 4, 0.f);
+    if (hist) std::memcpy(hist_pad.data(), hist, ((size_t)n_streams * p.hist_len * n_channels) * sizeof(float));
+    p.hist = hist_pad.data();
+    p.spec_per_sw = (long long)(p.n_pairs - p.real_last) * N + (p.real_last ? N / 2 : 0);
+    const long long n_sw = (long long)n_streams * p.n_windows;
+    std::vector<cf> spec((size_t)(n_sw * p.spec_per_sw), mk(NAN, NAN)), wrows((size_t)(n_sw * N), mk(NAN, NAN));
+    p.spec = spec.data(); p.wrows = wrows.data();
+    p.tab = lt.tab.data(); p.tw_coarse = lt.coarse.data(); p.tw_fine = lt.fine.data(); p.tw_r = lt.tw_r.data(); p.tw1m = lt.tw1m.data();
+    p.twa = tw.twa.data(); p.twb = tw.twb.data();
+    EmuShared sh;
+    auto run = [&](auto fn) {            // one emulated persistent workgroup walks every tile
+        std::vector<std::thread> th;
+        th.reserve(kThreads);
+        for (int t = 0; t < kThreads; ++t) th.emplace_back([&, t]() { EmuCtx ctx{t, &sh}; fn(ctx); });
+        for (auto &x : th) x.join();
+    };
+    const long long n_st = n_sw * kLwChunks;
+    auto split = [&](auto RA) {
+        constexpr int ra = decltype(RA)::value;
+        run([&](EmuCtx &ctx) {
+            switch (n_channels) {
+                case 1: lw_split_tiles<EmuCtx, ra, 1>(ctx, p, 0, 1, n_st); break;
+                case 2: lw_split_tiles<EmuCtx, ra, 2>(ctx, p, 0, 1, n_st); break;
+                case 3: lw_split_tiles<EmuCtx, ra, 3>(ctx, p, 0, 1, n_st); break;
+                case 4: lw_split_tiles<EmuCtx, ra, 4>(ctx, p, 0, 1, n_st); break;
+                case 5: lw_split_tiles<EmuCtx, ra, 5>(ctx, p, 0, 1, n_st); break;
+                case 6: lw_split_tiles<EmuCtx, ra, 6>(ctx, p, 0, 1, n_st); break;
+                case 7: lw_split_tiles<EmuCtx, ra, 7>(ctx, p, 0, 1, n_st); break;
+                default: lw_split_tiles<EmuCtx, ra, 8>(ctx, p, 0, 1, n_st); break;
+            }
+        });
+    };
+    if (R == 32) split(LwIdx<4>{}); else if (R == 64) split(LwIdx<8>{}); else split(LwIdx<16>{});
+    const long long n_rt = n_sw * (R / 2);
+    run([&](EmuCtx &ctx) {
+        switch (n_channels) {
+            case 1: lw_rows_tiles<EmuCtx, 1, true>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
+            case 2: lw_rows_tiles<EmuCtx, 1, false>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
+            case 3: lw_rows_tiles<EmuCtx, 2, true>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
+            case 4: lw_rows_tiles<EmuCtx, 2, false>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
+            case 5: lw_rows_tiles<EmuCtx, 3, true>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
+            case 6: lw_rows_tiles<EmuCtx, 3, false>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
+            case 7: lw_rows_tiles<EmuCtx, 4, true>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
+            default: lw_rows_tiles<EmuCtx, 4, false>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
+        }
+    });
+    run([&](EmuCtx &ctx) {
+        if (R == 32) lw_merge_tiles<EmuCtx, 4>(ctx, p, 0, 1, n_st);
+        else if (R == 64) lw_merge_tiles<EmuCtx, 8>(ctx, p, 0, 1, n_st);
+        else lw_merge_tiles<EmuCtx, 16>(ctx, p, 0, 1, n_st);
+    });
     return 0;
 }
 
