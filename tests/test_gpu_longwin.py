@@ -7,6 +7,12 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+@pytest.fixture(scope="module")
+def aw():
+    import airwave_amd
+    return airwave_amd
+
+
 TOL = 1e-5          # north_star: <= 1e-5 max rel error (peak-relative per stream and ear)
 
 
@@ -76,23 +82,33 @@ def test_long_window_stream_chunks(aw, oracle, monkeypatch):
         assert oracle.peak_rel_error(y[s], oracle.spatialize_f64(x[s], h, lt, rt)) < TOL
 
 
-def test_reserved_spatializer_never_reallocates(aw, oracle, monkeypatch):
-    """aw_spatializer_reserve(max) then shorter calls: the scratch stays as allocated whichever kernel set runs (the stream
-    chunk is clamped to the held buffer), also when the budget forces several chunks."""
+def test_reserved_spatializer_never_reallocates(oracle, monkeypatch):
+    """aw_spatializer_reserve(max) then shorter calls: the scratch stays as allocated whichever kernel set runs — the stream
+    chunk is clamped to the held buffer (a 1-block call would otherwise pick a larger chunk whose rounding exceeds what a
+    10-block reserve allocated: 64 MiB budget, 1 pair, 2 partitions, 400 streams: 65 472 KiB against 64 512 KiB)."""
+    import torch
+    import airwave_amd as aw
     monkeypatch.setenv("AW_SPEC_SCRATCH_MB", "64")
-    taps, S, C = 16385, 40, 2
+    monkeypatch.setenv("AW_WINDOW", "4096")                  # the partitioned kernels for an HRIR one fused window could hold
+    ctx = aw.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    taps, S, C, F = 8000, 400, 2, 10 * 4096
     h = oracle.synth_hrir(14, taps, seed=4)
     lt, rt = _maps(C)
-    sp = aw.Spatializer(aw.HRIR(h), lt, rt, n_streams=S)
-    sp.reserve(10 * 4096)
+    sp = aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=S, ctx=ctx)
+    assert sp.info()["path"] == 1 and sp.info()["partitions"] == 2
+    x = torch.empty((S, F, C), dtype=torch.float32, device="cuda")
+    y = torch.empty((S, F, 2), dtype=torch.float32, device="cuda")
+    ctx.synth_fill(x.data_ptr(), S, F, C)
+    sp.reserve(F)
     held = sp.info()["scratch_bytes"]
     assert held > 0
-    for n in (4096, 10 * 4096, 100, 3 * 4096 + 5):
-        x = oracle.synth_input(S, n, C, seed=n)
-        y = sp.process(x)
-        assert sp.info()["scratch_bytes"] == held
-    sp.reset()
-    x = oracle.synth_input(S, 10 * 4096, C, seed=8)
-    y = sp.process(x)
-    assert sp.info()["scratch_bytes"] == held
-    assert oracle.peak_rel_error(y[1], oracle.spatialize_f64(x[1], h, lt, rt)) < TOL
+    sizes = (4096, F, 100, 3 * 4096 + 5)
+    for n in sizes:
+        sp.process_device(x.data_ptr(), y.data_ptr(), n)
+        assert sp.info()["scratch_bytes"] == held, n
+    torch.cuda.synchronize()
+    flat = x.view(-1, C)                                     # a call of n frames reads streams packed with stride n
+    s = 399
+    ref = oracle.spatialize_f64(np.concatenate([flat[s * n:(s + 1) * n].cpu().numpy() for n in sizes]), h, lt, rt)
+    n = sizes[-1]
+    assert oracle.peak_rel_error(y.view(-1, 2)[s * n:(s + 1) * n].cpu().numpy(), ref[-n:]) < TOL
