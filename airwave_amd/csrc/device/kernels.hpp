@@ -71,6 +71,8 @@ struct LaunchCfg {
     int debug_occupancy = 0;      // AW_DEBUG_OCCUPANCY
     int stamp_thread = 0;         // AW_STAMP_THREAD (diagnostic builds)
     int eq_ear_split = -1;        // AW_EQ_EAR_SPLIT: -1 automatic, 0 / 1 forced
+    int lw_rows_pb = 1;           // long-window rows kernel: channel pairs per batch (AW_LW_ROWS_PB; 1 = one exchange buffer, two workgroups per CU)
+    int hop_align = 64;           // fused windows start on multiples of this many frames (AW_HOP_ALIGN; 1 = off)
 };
 hipError_t prepare_kernels(LaunchCfg *cfg);   // fills cfg from the current device + environment; sets the dynamic-LDS attribute on every tile kernel
 

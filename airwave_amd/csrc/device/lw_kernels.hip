@@ -29,6 +29,19 @@ __global__ void __launch_bounds__(kThreads) aw_lw_rows_kernel(LwParams p, long l
     lw_rows_tiles<GpuCtx, NP, REAL_LAST>(ctx, p, (long long)slot, (long long)per_xcd_wg, (long long)n_rp_x * n_sw, n_sw, xcd, 8);
 }
 
+// PB = 1: one exchange buffer, two workgroups per CU
+template <int NP, bool REAL_LAST>
+__global__ void __launch_bounds__(kThreads, 4) aw_lw_rows1_kernel(LwParams p, long long n_sw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
+    const int g = (int)gridDim.x, b = (int)blockIdx.x;
+    const int xcd = b % 8, slot = b / 8;
+    const int per_xcd_wg = (g - xcd + 7) / 8;
+    const int n_rp = p.R / 2;
+    const int n_rp_x = (n_rp - xcd + 7) / 8;
+    lw_rows_tiles<GpuCtx, NP, REAL_LAST, 1>(ctx, p, (long long)slot, (long long)per_xcd_wg, (long long)n_rp_x * n_sw, n_sw, xcd, 8);
+}
+
 template <int RA>
 __global__ void __launch_bounds__(kThreads, 4) aw_lw_merge_kernel(LwParams p, long long n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -41,6 +54,8 @@ __global__ void __launch_bounds__(kThreads, 4) aw_lw_merge_kernel(LwParams p, lo
 
 template <int RA> constexpr int lw_split_lds_bytes() { return lw_split_lds_elems<RA>() * (int)sizeof(cf); }
 template <int RA> constexpr int lw_merge_lds_bytes() { return lw_merge_lds_elems<RA>() * (int)sizeof(cf); }
+
+constexpr int kLwRows1LdsBytes = lw_rows_lds_elems<1>() * (int)sizeof(cf);
 
 hipError_t prepare_lw_kernels() {
     hipError_t e = hipSuccess;
@@ -57,6 +72,15 @@ hipError_t prepare_lw_kernels() {
     if (e == hipSuccess)                                                                               \
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_rows_kernel<NP, true>),          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    AW_SET(1) AW_SET(2) AW_SET(3) AW_SET(4)
+#undef AW_SET
+#define AW_SET(NP)                                                                                     \
+    if (e == hipSuccess)                                                                               \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_rows1_kernel<NP, false>),        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLwRows1LdsBytes);         \
+    if (e == hipSuccess)                                                                               \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_rows1_kernel<NP, true>),         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLwRows1LdsBytes);
     AW_SET(1) AW_SET(2) AW_SET(3) AW_SET(4)
 #undef AW_SET
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_merge_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lw_merge_lds_bytes<4>());
@@ -95,11 +119,22 @@ hipError_t launch_lw_rows(const LwParams &p, int n_streams, hipStream_t stream, 
     if (n_tiles <= 0) return hipSuccess;
     if (n_tiles > 0x7fffffffLL) return hipErrorInvalidValue;
     // 8 XCD groups: a grid that is a multiple of 8 (every group has the same number of workgroups), at least 8
-    unsigned grid = lw_grid((n_tiles + 7) / 8 * 8, p, 1) / 8 * 8;
+    const bool one = p.rows_pairs_per_batch == 1;
+    unsigned grid = lw_grid((n_tiles + 7) / 8 * 8, p, one ? 2 : 1) / 8 * 8;
     if (grid < 8) grid = 8;
     if (tm) tm->begin();
     const bool real = p.real_last != 0;
-    switch (p.n_pairs) {
+    if (one) switch (p.n_pairs) {
+#define AW_CASE(NP)                                                                                                       \
+        case NP:                                                                                                          \
+            if (real) hipLaunchKernelGGL((aw_lw_rows1_kernel<NP, true>), dim3(grid), dim3(kThreads), kLwRows1LdsBytes, stream, p, n_sw);   \
+            else hipLaunchKernelGGL((aw_lw_rows1_kernel<NP, false>), dim3(grid), dim3(kThreads), kLwRows1LdsBytes, stream, p, n_sw);       \
+            break;
+        AW_CASE(1) AW_CASE(2) AW_CASE(3) AW_CASE(4)
+#undef AW_CASE
+        default: return hipErrorInvalidValue;
+    }
+    else switch (p.n_pairs) {
 #define AW_CASE(NP)                                                                                                       \
         case NP:                                                                                                          \
             if (real) hipLaunchKernelGGL((aw_lw_rows_kernel<NP, true>), dim3(grid), dim3(kThreads), kLdsBytes, stream, p, n_sw);   \

@@ -43,12 +43,18 @@ constexpr int kLwInner = kLwM / kSub;       // 8 inner rows of 512 per row: radi
 constexpr int kLwTw = 64;                   // frames t per split / merge tile: one wave wide
 constexpr int kLwChunks = kLwM / kLwTw;     // 64 tiles per (stream, window)
 
+#ifndef AW_LW_PREFETCH_EARLY
+#define AW_LW_PREFETCH_EARLY 0      // rows kernel, fetch of the next tile's first batch: 0 under the final pass, 1 right after the last pass 1, 2 before the inverse sub-FFTs
+#endif
+
 struct alignas(16) LwTab { cf t0, t1, t2, t3; };
 
 struct LwParams {
     const float *in;        // [stream][frames][C] interleaved
     float *out;             // [stream][frames][2]
     const float *hist;      // [stream][hist_len][C]: the frames preceding in[...][0]
+    float *hist_out;        // [stream][hist_len][C] or NULL: the split kernel also carries the convolution tail — the last hist_len
+                            // frames of (history ++ input) — into the other history buffer (every such frame passes through it anyway)
     const float *zeros;     // >= 64 bytes of zeros
     long long frames;       // frames per stream in this call
     int n_channels, n_pairs;
@@ -67,6 +73,7 @@ struct LwParams {
     const cf *tw1m;         // [512]: w_4096^{t}
     const cf *twa, *twb;    // sub-FFT twiddles of the context (tile_ols.hpp)
     int persistent_wgs;
+    int rows_pairs_per_batch;   // rows kernel form: 2 = two pairs per batch, one workgroup per CU; 1 = one pair per batch, two workgroups per CU
 };
 
 // ---- compile-time constants: w_32^m = cos(pi m/16) - i sin(pi m/16) ---------------------------------------------
@@ -140,6 +147,20 @@ template <int CS> AW_HD void lw_load_frame(const float *src, float (&d)[CS]) {
     }
 }
 
+template <int CS> AW_HD void lw_store_frame(float *dst, const float (&d)[CS]) {
+    constexpr int n4 = CS / 4, rem = CS % 4;
+#pragma unroll
+    for (int g = 0; g < n4; ++g) {
+        if constexpr (CS % 4 == 0) { f4 v; v.x = d[4 * g]; v.y = d[4 * g + 1]; v.z = d[4 * g + 2]; v.w = d[4 * g + 3]; *reinterpret_cast<f4 *>(dst + 4 * g) = v; }
+        else { f4u v; v.x = d[4 * g]; v.y = d[4 * g + 1]; v.z = d[4 * g + 2]; v.w = d[4 * g + 3]; *reinterpret_cast<f4u *>(dst + 4 * g) = v; }
+    }
+    if constexpr (rem == 3) { f3u v; v.x = d[4 * n4]; v.y = d[4 * n4 + 1]; v.z = d[4 * n4 + 2]; *reinterpret_cast<f3u *>(dst + 4 * n4) = v; }
+    else if constexpr (rem == 2) {
+        if constexpr (CS % 2 == 0) { f2 v; v.x = d[4 * n4]; v.y = d[4 * n4 + 1]; *reinterpret_cast<f2 *>(dst + 4 * n4) = v; }
+        else { f2u v; v.x = d[4 * n4]; v.y = d[4 * n4 + 1]; *reinterpret_cast<f2u *>(dst + 4 * n4) = v; }
+    } else if constexpr (rem == 1) dst[4 * n4] = d[4 * n4];
+}
+
 // w_N^{t (k1 + 1/2)} for t = 64 tc + lane, k1 < R/2: one wave-uniform (scalar) and one lane-contiguous table read
 AW_HD cf lw_tau(const LwParams &p, int tc, int lane, int k1) {
     const cf c = p.tw_coarse[(tc * (2 * k1 + 1)) & (p.N / 32 - 1)];
@@ -182,6 +203,17 @@ AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
         const int tc = (int)(id - sw * kLwChunks);
         const int t = tc * kLwTw + lane;
         cf *spec_sw = p.spec + sw * p.spec_per_sw;
+        if (p.hist_out) {             // uniform.  The next call's history: frames [frames - hist_len, frames) of (history ++ input)
+            const long long stream = sw / p.n_windows;
+            const int win = (int)(sw - stream * p.n_windows);
+            const long long fb = (long long)win * p.hop - p.hist_len + (long long)kLwM * wave + t;
+            float *ho = p.hist_out + stream * (long long)p.hist_len * CS;
+#pragma unroll
+            for (int j2 = 0; j2 < RA; ++j2) {
+                const long long i = fb + (long long)kLwM * 8 * j2 - (p.frames - p.hist_len);
+                if (i >= 0 && i < p.hist_len) lw_store_frame<CS>(ho + i * CS, raw[j2]);
+            }
+        }
         lw_unroll<NPASS>([&](auto PP) {
             constexpr int pp = PP.value;
             if (pp > 0 || id != first) ctx.barrier();                 // every wave is done reading the exchange buffer
@@ -277,30 +309,35 @@ AW_HD LwRowTile lw_row_tile(long long vid, long long n_sw, int rp0, int rp_step)
     return r;
 }
 
-template <class Ctx, int NP, bool REAL_LAST>
+// PB = channel pairs per batch: 2 = two exchange buffers (152 KB of LDS, one workgroup per CU); 1 = one buffer (78 KB) and
+// half the register batch, so that two workgroups share a CU and one's barriers and exposed latencies meet the other's work.
+template <int PB> constexpr int lw_rows_lds_elems() { return PB * kBufElems + kTwaElems + kTwbElems; }
+
+template <class Ctx, int NP, bool REAL_LAST, int PB = 2>
 AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long step, long long end, long long n_sw, int rp0, int rp_step) {
     static_assert(NP >= 1 && NP <= 8, "channel pairs");
-    constexpr int NB = (NP + 1) / 2;
+    static_assert(PB == 1 || PB == 2, "pairs per batch");
+    constexpr int NB = (NP + PB - 1) / PB;
     if (first >= end) return;
     const int t0 = ctx.tid();
     int t = t0, lane = ctx.lane();
     const int wave = ctx.wave();
     cf *buf0 = ctx.lds();
-    cf *buf1 = buf0 + kBufElems;
-    cf *twa = buf1 + kBufElems;
+    cf *buf1 = buf0 + (PB - 1) * kBufElems;
+    cf *twa = buf0 + PB * kBufElems;
     cf *twb = twa + kTwaElems;
     const cf w1 = p.tw1m[t];
     twa[t] = p.twa[t];
     if (t < kTwbElems) twb[t] = p.twb[t];
     const int R = p.R;
 
-    cf raw[2][2][8];          // [pair of the batch][row ra / rb][j2]: row samples t + 512 j2
+    cf raw[PB][2][8];         // [pair of the batch][row ra / rb][j2]: row samples t + 512 j2
     auto load_batch = [&](long long vid, int b) {
         const LwRowTile tl = lw_row_tile(vid, n_sw, rp0, rp_step);
         const cf *spec_sw = p.spec + tl.sw * p.spec_per_sw;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int pair = 2 * b + h;
+        for (int h = 0; h < PB; ++h) {
+            const int pair = PB * b + h;
             if (pair >= NP) break;                                     // compile-time after unrolling
             const cf *base = spec_sw + (long long)pair * p.N + t;
 #pragma unroll
@@ -329,8 +366,8 @@ AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long
                 cf pw[8];
                 lw_powers8(ctx.opaque(w1), pw);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    constexpr int pair0 = 2 * b;
+                for (int h = 0; h < PB; ++h) {
+                    constexpr int pair0 = PB * b;
                     if (pair0 + h >= NP) break;
                     cf *buf = h == 0 ? buf0 : buf1;
 #pragma unroll
@@ -347,11 +384,14 @@ AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long
                     }
                 }
             }
-            if constexpr (b + 1 < NB) load_batch(vid, b + 1);          // the next batch's rows travel under this batch's sub-FFTs
+            // the next batch's rows — of this tile or, after the last batch, of the workgroup's next tile (the last tile re-reads
+            // its own) — travel under this batch's sub-FFTs (and, for the next tile, under the whole inverse transform)
+            if constexpr (b + 1 < NB) load_batch(vid, b + 1);
+            else if constexpr (AW_LW_PREFETCH_EARLY == 1) load_batch(vid + step < end ? vid + step : vid, 0);
             ctx.barrier();
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                constexpr int pair0 = 2 * b;
+            for (int h = 0; h < PB; ++h) {
+                constexpr int pair0 = PB * b;
                 const int pair = pair0 + h;
                 if (pair >= NP) break;
                 cf *buf = h == 0 ? buf0 : buf1;
@@ -391,11 +431,12 @@ AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long
         {
             cf *row0 = buf0 + wave * kRowStride, *row1 = buf0 + (8 + wave) * kRowStride;
             ctx.wave_sync();                                  // this wave's forward reads of its rows are complete
+            if constexpr (AW_LW_PREFETCH_EARLY == 2) load_batch(vid + step < end ? vid + step : vid, 0);      // under the whole inverse transform
             sub_fft512x2<true>(ctx, wacc, row0, row1, twa, twb, lane);
 #pragma unroll
             for (int kc = 0; kc < 8; ++kc) { row0[lane + 64 * kc] = wacc[0][kc]; row1[lane + 64 * kc] = wacc[1][kc]; }
         }
-        load_batch(vid + step < end ? vid + step : vid, 0);      // the next tile's first batch, under the final pass (the last tile re-reads its own)
+        if constexpr (AW_LW_PREFETCH_EARLY == 0) load_batch(vid + step < end ? vid + step : vid, 0);      // the next tile's first batch under the final pass only
         ctx.barrier();
         {
             cf pw[8];

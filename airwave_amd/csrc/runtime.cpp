@@ -214,9 +214,9 @@ static aw_status sp_alloc_hist(aw_spatializer *sp) {
 }
 
 // Tiles start on 64-frame boundaries of the timeline: a shorter hop costs < 2 % more tiles and makes every tile's
-// loads and stores start line-aligned (measured cfg 2: 1.555 -> 1.530 ms per call).  AW_HOP_ALIGN overrides (1 = off).
-static int align_hop(int hop) {
-    static const int al = [] { const char *e = getenv("AW_HOP_ALIGN"); return e ? atoi(e) : 64; }();
+// loads and stores start line-aligned (measured cfg 2: 1.555 -> 1.530 ms per call).  AW_HOP_ALIGN (read at aw_context_create) overrides (1 = off).
+static int align_hop(const aw_context *ctx, int hop) {
+    const int al = ctx->cfg.hop_align;          // read once at aw_context_create (LaunchCfg), like every other knob
     return (al > 1 && hop > 16 * al) ? hop - hop % al : hop;
 }
 
@@ -287,7 +287,7 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
     const bool force_partitioned = window == 4096 || prefer_partitioned;       // AW_WINDOW=4096: the partitioned path (A/B)
     if (!force_partitioned && ((window == awk::kN2 && fits2) || (!fits1 && fused2_ok))) {
         sp->path = 0; sp->fused2 = true;
-        sp->hop = align_hop(awk::kN2 - hist2);
+        sp->hop = align_hop(ctx, awk::kN2 - hist2);
         sp->hist_len = awk::kN2 - sp->hop;                           // even, >= 2 * floor(taps / 2)
         sp->partitions = 1;
         sp->n_pairs = (2 * n_in + 1) / 2;                            // pseudo-pairs of the half-rate 2C-channel view
@@ -298,7 +298,7 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
             bool ok = false;
             if (awk::probe_sibling_placement(ctx->stream, ctx->cfg.persistent_wgs, &ok) != hipSuccess || !ok) sp->fusedh = 0;
         }
-        sp->hop = align_hop(N - (hrir->taps - 1));
+        sp->hop = align_hop(ctx, N - (hrir->taps - 1));
         sp->hist_len = N - sp->hop;
         sp->partitions = 1;
     } else {
@@ -741,6 +741,7 @@ static aw_status sp_process_longwin(aw_spatializer *sp, int R, const float *in, 
         p.in = in + (size_t)s0 * frames * sp->n_channels;
         p.out = out + (size_t)s0 * frames * 2;
         p.hist = sp->d_hist[sp->hist_cur] + (size_t)s0 * sp->hist_len * sp->n_channels;
+        p.hist_out = sp->d_hist[sp->hist_cur ^ 1] + (size_t)s0 * sp->hist_len * sp->n_channels;      // the tail carry rides along in the split kernel
         p.zeros = sp->ctx->d_zeros;
         p.frames = frames; p.n_channels = sp->n_channels; p.n_pairs = sp->n_pairs; p.real_last = sp->n_channels & 1;
         p.hist_len = sp->hist_len; p.hop = (int)(N - sp->hist_len); p.n_windows = (int)sc.n_windows;
@@ -750,6 +751,7 @@ static aw_status sp_process_longwin(aw_spatializer *sp, int R, const float *in, 
         p.tab = plan->d_tab; p.tw_coarse = plan->d_coarse; p.tw_fine = plan->d_fine; p.tw_r = plan->d_tw_r; p.tw1m = plan->d_tw1m;
         p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb;
         p.persistent_wgs = sp->ctx->cfg.persistent_wgs;
+        p.rows_pairs_per_batch = sp->ctx->cfg.lw_rows_pb;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (sp->profiling) {
             e0 = sp_get_event(sp); e1 = sp_get_event(sp);
@@ -813,12 +815,14 @@ aw_status aw_spatializer_process(aw_spatializer *sp, const float *in, float *out
     else st = sp_process_partitioned(sp, in, out, frames);
     if (st != AW_OK) return st;
     // carry the convolution tail: next call's history = last hist_len frames of (history ++ input)
-    float *h_old = sp->d_hist[sp->hist_cur], *h_new = sp->d_hist[sp->hist_cur ^ 1];
-    SpStageTimer tm(sp);
-    if (sp->profiling) tm.begin();
-    AW_HIP_TRY(awk::launch_hist_update(in, h_old, h_new, frames, sp->n_channels, sp->hist_len, sp->n_streams,
-                                       sp->ctx->stream));
-    if (sp->profiling) tm.end("aw_hist_update_kernel");
+    if (!(sp->path == 1 && lw_R)) {      // (the long-window split kernel has written it on the way)
+        float *h_old = sp->d_hist[sp->hist_cur], *h_new = sp->d_hist[sp->hist_cur ^ 1];
+        SpStageTimer tm(sp);
+        if (sp->profiling) tm.begin();
+        AW_HIP_TRY(awk::launch_hist_update(in, h_old, h_new, frames, sp->n_channels, sp->hist_len, sp->n_streams,
+                                           sp->ctx->stream));
+        if (sp->profiling) tm.end("aw_hist_update_kernel");
+    }
     sp->hist_cur ^= 1;
     return AW_OK;
 }

@@ -398,7 +398,7 @@ int emu_partitioned(const float *in, float *out, const float *hist, const float 
 // The long-window path (tile_lw.hpp): split -> rows -> merge on windows of N = R x 4096 frames, R in {32, 64, 128}.
 // hist: [stream][hist_len][C] or NULL; hist_len = N - hop must be >= taps - 1 (hop given by the caller).
 int emu_longwin(const float *in, float *out, const float *hist, const float *tracks, int n_tracks, int taps, int n_channels,
-                const int32_t *left_track, const int32_t *right_track, long long frames, int n_streams, int R, int hop) {
+                const int32_t *left_track, const int32_t *right_track, long long frames, int n_streams, int R, int hop, int rows_pb, float *hist_out) {
     using namespace awk;
     if (R != 32 && R != 64 && R != 128) return -1;
     const long long N = (long long)R * kLwM;
@@ -415,6 +415,7 @@ int emu_longwin(const float *in, float *out, const float *hist, const float *tra
     std::vector<float> hist_pad((size_t)n_streams * p.hist_len * n_channels + 4, 0.f);
     if (hist) std::memcpy(hist_pad.data(), hist, ((size_t)n_streams * p.hist_len * n_channels) * sizeof(float));
     p.hist = hist_pad.data();
+    p.hist_out = hist_out;
     p.spec_per_sw = (long long)(p.n_pairs - p.real_last) * N + (p.real_last ? N / 2 : 0);
     const long long n_sw = (long long)n_streams * p.n_windows;
     std::vector<cf> spec((size_t)(n_sw * p.spec_per_sw), mk(NAN, NAN)), wrows((size_t)(n_sw * N), mk(NAN, NAN));
@@ -446,18 +447,22 @@ int emu_longwin(const float *in, float *out, const float *hist, const float *tra
     };
     if (R == 32) split(LwIdx<4>{}); else if (R == 64) split(LwIdx<8>{}); else split(LwIdx<16>{});
     const long long n_rt = n_sw * (R / 2);
-    run([&](EmuCtx &ctx) {
-        switch (n_channels) {
-            case 1: lw_rows_tiles<EmuCtx, 1, true>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
-            case 2: lw_rows_tiles<EmuCtx, 1, false>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
-            case 3: lw_rows_tiles<EmuCtx, 2, true>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
-            case 4: lw_rows_tiles<EmuCtx, 2, false>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
-            case 5: lw_rows_tiles<EmuCtx, 3, true>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
-            case 6: lw_rows_tiles<EmuCtx, 3, false>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
-            case 7: lw_rows_tiles<EmuCtx, 4, true>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
-            default: lw_rows_tiles<EmuCtx, 4, false>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
-        }
-    });
+    auto rows = [&](auto PBB) {
+        constexpr int pb = decltype(PBB)::value;
+        run([&](EmuCtx &ctx) {
+            switch (n_channels) {
+                case 1: lw_rows_tiles<EmuCtx, 1, true, pb>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
+                case 2: lw_rows_tiles<EmuCtx, 1, false, pb>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
+                case 3: lw_rows_tiles<EmuCtx, 2, true, pb>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
+                case 4: lw_rows_tiles<EmuCtx, 2, false, pb>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
+                case 5: lw_rows_tiles<EmuCtx, 3, true, pb>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
+                case 6: lw_rows_tiles<EmuCtx, 3, false, pb>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
+                case 7: lw_rows_tiles<EmuCtx, 4, true, pb>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
+                default: lw_rows_tiles<EmuCtx, 4, false, pb>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
+            }
+        });
+    };
+    if (rows_pb == 1) rows(LwIdx<1>{}); else rows(LwIdx<2>{});
     run([&](EmuCtx &ctx) {
         if (R == 32) lw_merge_tiles<EmuCtx, 4>(ctx, p, 0, 1, n_st);
         else if (R == 64) lw_merge_tiles<EmuCtx, 8>(ctx, p, 0, 1, n_st);

@@ -22,12 +22,13 @@ def _case(oracle, channels, taps, frames, R, seed=5, hop=None, hist_frames=0):
     return h, lt, rt, x, ref
 
 
-@pytest.mark.parametrize("channels", [7, 8, 1, 2, 5])
-def test_emulated_long_window_matches_truth(oracle, channels):
-    # one window of 32 x 4096 frames holds the whole call: history (zeros), input, zero fill past the end
+@pytest.mark.parametrize("channels,rows_pb", [(7, 2), (8, 2), (1, 2), (2, 2), (5, 2), (7, 1), (6, 1), (1, 1)])
+def test_emulated_long_window_matches_truth(oracle, channels, rows_pb):
+    # one window of 32 x 4096 frames holds the whole call: history (zeros), input, zero fill past the end;
+    # rows_pb = channel pairs per batch of the rows kernel (1: the two-workgroups-per-CU form)
     taps, frames = 9000, 100000
     h, lt, rt, x, ref = _case(oracle, channels, taps, frames, 32)
-    y = emu.longwin(x, h, lt, rt, R=32)
+    y = emu.longwin(x, h, lt, rt, R=32, rows_pb=rows_pb)
     assert not np.isnan(y).any()
     for ear in range(2):
         assert oracle.peak_rel_error(y[0, :, ear], ref[:, ear]) < TOL
@@ -44,8 +45,10 @@ def test_emulated_long_window_two_windows_and_history(oracle):
     lt[3] = -1
     ref = oracle.spatialize_f64(x[0], h, lt, rt)
     hist = x[:, :hist_len].copy()
-    y = emu.longwin(x[:, hist_len:], h, lt, rt, R=R, hop=hop, hist=hist)
+    hist_out = np.full((1, hist_len, 6), np.nan, dtype=np.float32)
+    y = emu.longwin(x[:, hist_len:], h, lt, rt, R=R, hop=hop, hist=hist, hist_out=hist_out)
     assert not np.isnan(y).any()
+    assert np.array_equal(hist_out, x[:, -hist_len:])          # the split kernel carried the convolution tail
     for ear in range(2):
         assert oracle.peak_rel_error(y[0, :, ear], ref[hist_len:, ear]) < TOL
 
@@ -59,3 +62,19 @@ def test_emulated_long_window_larger_radix(oracle, R):
     assert not np.isnan(y).any()
     for ear in range(2):
         assert oracle.peak_rel_error(y[0, :, ear], ref[:, ear]) < TOL
+
+
+def test_emulated_split_kernel_carries_a_short_calls_tail(oracle):
+    # a call shorter than the history: the new history is part old history, part input
+    taps, R = 33000, 32
+    N = R * 4096
+    hist_len = 36864
+    hop = N - hist_len
+    frames = 5000
+    h, lt, rt, x, ref = _case(oracle, 3, taps, frames, R, hist_frames=hist_len)
+    hist = x[:, :hist_len].copy()
+    hist_out = np.full((1, hist_len, 3), np.nan, dtype=np.float32)
+    y = emu.longwin(x[:, hist_len:], h, lt, rt, R=R, hop=hop, hist=hist, hist_out=hist_out)
+    assert np.array_equal(hist_out, x[:, -hist_len:])
+    for ear in range(2):
+        assert oracle.peak_rel_error(y[0, :, ear], ref[hist_len:, ear]) < TOL
