@@ -67,9 +67,11 @@ struct LwParams {
     long long spec_per_sw;  // complex elements of spec per (stream, window)
     cf *wrows;              // [stream][window][row pair][2][4096]: s1, s2
     const LwTab *tab;       // [row pair][pair][8][512]: bin k2 = q1 + 8 q2 of the row pair at [q1][q2]
-    const cf *tw_coarse;    // [2N/64]: w_{2N}^{64 e}
-    const cf *tw_fine;      // [R/2][64]: w_{2N}^{lane (2 k1 + 1)}
-    const cf *tw_r;         // [8][RA]: w_{2R}^{j1 (2 ka + 1)}
+    // row twiddles w_N^{t (k1 + 1/2)}, t = 64 tc + lane, k1 = RA m + ka:  base(ka) = coarse[ka][tc] * fine[ka][lane], times step[m][t]
+    const cf *tw_coarse;    // [RA][64]: w_{2N}^{64 tc (2 ka + 1)}
+    const cf *tw_fine;      // [RA][64]: w_{2N}^{lane (2 ka + 1)}
+    const cf *tw_step;      // [3][4096]: w_{2N}^{2 RA m t}, m = 1, 2, 3
+    const cf *tw_r;         // [RA][8]: w_{2R}^{j1 (2 ka + 1)}
     const cf *tw1m;         // [512]: w_4096^{t}
     const cf *twa, *twb;    // sub-FFT twiddles of the context (tile_ols.hpp)
     int persistent_wgs;
@@ -161,25 +163,36 @@ template <int CS> AW_HD void lw_store_frame(float *dst, const float (&d)[CS]) {
     } else if constexpr (rem == 1) dst[4 * n4] = d[4 * n4];
 }
 
-// w_N^{t (k1 + 1/2)} for t = 64 tc + lane, k1 < R/2: one wave-uniform (scalar) and one lane-contiguous table read
-AW_HD cf lw_tau(const LwParams &p, int tc, int lane, int k1) {
-    const cf c = p.tw_coarse[(tc * (2 * k1 + 1)) & (p.N / 32 - 1)];
-    const cf f = p.tw_fine[k1 * 64 + lane];
-    return cmul(c, f);
+// The small twiddle tables of the split / merge kernels live in LDS behind the exchange buffer (global loads of them — two
+// per output value — were most of the kernels' vector-memory instructions and their exposed latency: 174 of 330 per tile).
+template <int RA> constexpr int lw_small_elems() { return RA * 8 + 2 * RA * 64; }
+template <int RA, class Ctx>
+AW_HD void lw_small_tables(Ctx &ctx, const LwParams &p, cf *sm) {            // [twr RA x 8][coarse RA x 64][fine RA x 64]; visible after the next barrier
+    for (int i = ctx.tid(); i < RA * 8; i += kThreads) sm[i] = p.tw_r[i];
+    for (int i = ctx.tid(); i < RA * 64; i += kThreads) { sm[RA * 8 + i] = p.tw_coarse[i]; sm[RA * 8 + RA * 64 + i] = p.tw_fine[i]; }
+}
+// the four row twiddles base(ka) * {1, S1, S2, S3} of one ka
+template <int RA, class Ctx>
+AW_HD void lw_row_twiddles(Ctx &ctx, const cf *sm, int ka, int tc, int lane, const cf (&S)[3], cf (&tau)[4]) {
+    tau[0] = cmul(ctx.ld(sm + RA * 8 + ka * 64 + tc), ctx.ld(sm + RA * 8 + RA * 64 + ka * 64 + lane));
+#pragma unroll
+    for (int m = 1; m < 4; ++m) tau[m] = cmul(tau[0], S[m - 1]);
 }
 
 // ---- kernel 1: split ---------------------------------------------------------------------------------------------
 // Tile id = (stream, window) * 64 + tc.  512 threads: wave = j1, lane = t - 64 tc.  LDS: [2][RA][8][64] complex.
-template <int RA> constexpr int lw_split_lds_elems() { return 2 * RA * 8 * 64; }
+template <int RA> constexpr int lw_split_lds_elems() { return 2 * RA * 8 * 64 + lw_small_elems<RA>(); }
 
 template <class Ctx, int RA, int CS>
 AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long long step, long long end) {
     static_assert(RA == 4 || RA == 8 || RA == 16, "R = 32, 64 or 128 rows");
     static_assert(CS >= 1 && CS <= 8, "up to eight channels per group");
-    constexpr int R = 8 * RA, NP = (CS + 1) / 2, NPASS = (NP + 1) / 2, NCOMBO = RA / 4, G = RA >= 8 ? RA / 8 : 1;
+    constexpr int NP = (CS + 1) / 2, NPASS = (NP + 1) / 2, NCOMBO = RA / 4, G = RA >= 8 ? RA / 8 : 1;
     if (first >= end) return;
     const int lane = ctx.lane(), wave = ctx.wave();
     cf *lds = ctx.lds();
+    cf *sm = lds + 2 * RA * 8 * 64;
+    lw_small_tables<RA>(ctx, p, sm);
     float raw[RA][CS];
     auto load_tile = [&](long long id) {
         const long long sw = (long long)((unsigned long long)id / (unsigned)kLwChunks);
@@ -194,6 +207,11 @@ AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
             const long long f = fb + (long long)kLwM * 8 * j2;
             // frames before the call: the history buffer; past its end: a page of zeros (a pointer select, never a select on data)
             const float *src = f < 0 ? hist_s + ((long long)p.hist_len + f) * CS : (f >= p.frames ? p.zeros : in_s + f * CS);
+#ifdef AW_LW_ABL_SPLIT_NOLOAD     // timing ablation only (wrong results)
+#pragma unroll
+            for (int c = 0; c < CS; ++c) raw[j2][c] = 0.001f * lane + (float)(src == nullptr);
+            continue;
+#endif
             lw_load_frame<CS>(src, raw[j2]);
         }
     };
@@ -203,6 +221,9 @@ AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
         const int tc = (int)(id - sw * kLwChunks);
         const int t = tc * kLwTw + lane;
         cf *spec_sw = p.spec + sw * p.spec_per_sw;
+        cf S[3];                      // issued here: they travel under step 1
+#pragma unroll
+        for (int m = 0; m < 3; ++m) S[m] = p.tw_step[m * kLwM + t];
         if (p.hist_out) {             // uniform.  The next call's history: frames [frames - hist_len, frames) of (history ++ input)
             const long long stream = sw / p.n_windows;
             const int win = (int)(sw - stream * p.n_windows);
@@ -217,7 +238,7 @@ AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
         lw_unroll<NPASS>([&](auto PP) {
             constexpr int pp = PP.value;
             if (pp > 0 || id != first) ctx.barrier();                 // every wave is done reading the exchange buffer
-            // step 1: odd DFT over j2 (this thread's RA frames), twiddle w_R^{j1 (ka + 1/2)}, to LDS [q][ka][j1][lane]
+            // step 1: odd DFT over j2 (this thread's RA frames) to LDS [q][ka][j1][lane]
             lw_unroll<2>([&](auto Q) {
                 constexpr int q = Q.value, pair = 2 * pp + q;
                 if constexpr (pair < NP) {
@@ -227,12 +248,14 @@ AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
                     lw_odd_dft<false, RA>(x);
 #pragma unroll
                     for (int ka = 0; ka < RA; ++ka)
-                        lds[((q * RA + ka) * 8 + wave) * 64 + lane] = cmul(x[ka], p.tw_r[wave * RA + ka]);
+                        lds[((q * RA + ka) * 8 + wave) * 64 + lane] = x[ka];
                 }
             });
             if constexpr (pp == NPASS - 1) load_tile(id + step < end ? id + step : id);     // the frames are consumed: fetch the next tile's (the last one re-reads its own)
             ctx.barrier();
-            // step 3: DFT-8 over j1 -> kb, row k1 = RA kb + ka; twiddle; rows to scratch (512 contiguous bytes per wave and row)
+            // step 3: twiddle w_R^{j1 (ka + 1/2)}, DFT-8 over j1 -> kb, row k1 = RA kb + ka; row twiddle; rows to scratch (512
+            // contiguous bytes per wave and row).  Row twiddles: lower rows (kb < 4) base(ka) S^kb, upper rows — conj-reversed,
+            // the partner row R-1-k1 = RA (7 - kb) + (RA-1-ka) — base(RA-1-ka) S^(7-kb).
 #pragma unroll
             for (int i = 0; i < NCOMBO; ++i) {
                 const int q = RA >= 8 ? i / G : wave / RA;                      // uniform
@@ -242,16 +265,24 @@ AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
                 cf v[8];
 #pragma unroll
                 for (int j1 = 0; j1 < 8; ++j1) v[j1] = ctx.ld(lds + ((q * RA + ka) * 8 + j1) * 64 + lane);
+#pragma unroll
+                for (int j1 = 1; j1 < 8; ++j1) v[j1] = cmul(v[j1], ctx.ld(sm + ka * 8 + j1));
                 fft8<false>(v);
+                cf tlo[4], tup[4];
+                lw_row_twiddles<RA>(ctx, sm, ka, tc, lane, S, tlo);
+                lw_row_twiddles<RA>(ctx, sm, RA - 1 - ka, tc, lane, S, tup);
                 const bool real_pair = (CS & 1) && pair == NP - 1;
                 cf *dst = spec_sw + (long long)pair * p.N + t;
 #pragma unroll
                 for (int kb = 0; kb < 8; ++kb) {
                     const int k1 = RA * kb + ka;
+#ifdef AW_LW_ABL_SPLIT_NOSTORE    // timing ablation only (wrong results)
+                    if (v[kb].x != 1.2345e-30f) continue;
+#endif
                     if (kb < 4) {
-                        ctx.st_stream(dst + (long long)k1 * kLwM, cmul(v[kb], lw_tau(p, tc, lane, k1)));
+                        ctx.st_stream(dst + (long long)k1 * kLwM, cmul(v[kb], tlo[kb & 3]));
                     } else if (!real_pair) {
-                        ctx.st_stream(dst + (long long)k1 * kLwM, cmul(conj(v[kb]), lw_tau(p, tc, lane, R - 1 - k1)));
+                        ctx.st_stream(dst + (long long)k1 * kLwM, cmul(conj(v[kb]), tup[(7 - kb) & 3]));
                     }
                 }
             }
@@ -341,6 +372,10 @@ AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long
             if (pair >= NP) break;                                     // compile-time after unrolling
             const cf *base = spec_sw + (long long)pair * p.N + t;
 #pragma unroll
+#ifdef AW_LW_ABL_ROWS_NOLOAD      // timing ablation only (wrong results)
+            for (int j2 = 0; j2 < 8; ++j2) { raw[h][0][j2] = mk(0.001f * t, (float)(base == nullptr)); raw[h][1][j2] = mk(0.002f * j2, 1.f); }
+            continue;
+#endif
             for (int j2 = 0; j2 < 8; ++j2) raw[h][0][j2] = ctx.ld_stream(base + (long long)tl.rp * kLwM + 512 * j2);
             if (!(REAL_LAST && pair == NP - 1)) {
 #pragma unroll
@@ -406,7 +441,11 @@ AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long
                     lw_sub_fft512<false>(ctx, z, row0, twa, twb, lane);
 #pragma unroll
                     for (int kc = 0; kc < 8; ++kc) {
+#ifdef AW_LW_ABL_ROWS_NOTAB       // timing ablation only (wrong results)
+                        const LwTab T{mk(1.f, 0.5f * lane), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.25f * kc, 1.f * wave)};
+#else
                         const LwTab T = tb[64 * kc];
+#endif
                         wacc[0][kc] = cfma(z[kc], T.t0, wacc[0][kc]);
                         wacc[1][kc] = cfma(z[kc], T.t3, wacc[1][kc]);
                     }
@@ -417,7 +456,11 @@ AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long
                     sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
 #pragma unroll
                     for (int kc = 0; kc < 8; ++kc) {
+#ifdef AW_LW_ABL_ROWS_NOTAB       // timing ablation only (wrong results)
+                        const LwTab T{mk(1.f, 0.5f * lane), mk(0.3f, 0.1f), mk(0.2f * pair, 0.7f), mk(0.25f * kc, 1.f * wave)};
+#else
                         const LwTab T = tb[64 * kc];
+#endif
                         wacc[0][kc] = cfma(z[0][kc], T.t0, wacc[0][kc]);
                         wacc[0][kc] = cfma(z[1][kc], T.t1, wacc[0][kc]);
                         wacc[1][kc] = cfma(z[1][kc], T.t2, wacc[1][kc]);
@@ -451,7 +494,12 @@ AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long
                 for (int q1 = 1; q1 < 8; ++q1) y[q1] = cmulc(y[q1], pw[q1]);
                 fft8<true>(y);
 #pragma unroll
-                for (int j2 = 0; j2 < 8; ++j2) ctx.st_stream(dst + r * kLwM + 512 * j2, y[j2]);
+                for (int j2 = 0; j2 < 8; ++j2) {
+#ifdef AW_LW_ABL_ROWS_NOSTORE     // timing ablation only (wrong results)
+                    if (y[j2].x != 1.2345e-30f) continue;
+#endif
+                    ctx.st_stream(dst + r * kLwM + 512 * j2, y[j2]);
+                }
             }
         }
         ctx.barrier();                                        // the final exchange has been read before buf0 is rewritten
@@ -460,7 +508,7 @@ AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long
 
 // ---- kernel 3: merge -------------------------------------------------------------------------------------------------
 // Tile id = (stream, window) * 64 + tc.  512 threads.  LDS: [RA][8][64] complex.
-template <int RA> constexpr int lw_merge_lds_elems() { return RA * 8 * 64; }
+template <int RA> constexpr int lw_merge_lds_elems() { return RA * 8 * 64 + lw_small_elems<RA>(); }
 
 template <class Ctx, int RA>
 AW_HD void lw_merge_tiles(Ctx &ctx, const LwParams &p, long long first, long long step, long long end) {
@@ -468,6 +516,9 @@ AW_HD void lw_merge_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
     constexpr int R = 8 * RA, NKA = RA >= 8 ? RA / 8 : 1;
     const int lane = ctx.lane(), wave = ctx.wave();
     cf *lds = ctx.lds();
+    cf *sm = lds + RA * 8 * 64;
+    lw_small_tables<RA>(ctx, p, sm);
+    if (first < end) ctx.barrier();
     for (long long id = first; id < end; id += step) {
         const long long sw = (long long)((unsigned long long)id / (unsigned)kLwChunks);
         const int tc = (int)(id - sw * kLwChunks);
@@ -488,16 +539,20 @@ AW_HD void lw_merge_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
                 const int rp = kb < 4 ? k1 : R - 1 - k1;
                 g[kb] = ctx.ld_stream(wr + ((long long)rp * 2 + (kb < 4 ? 0 : 1)) * kLwM);
             }
+            cf S[3], tlo[4], tup[4];
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) {
-                const int k1 = RA * kb + ka;
-                const int rp = kb < 4 ? k1 : R - 1 - k1;
-                const cf v = cmulc(g[kb], lw_tau(p, tc, lane, rp));
+            for (int m = 0; m < 3; ++m) S[m] = p.tw_step[m * kLwM + t];
+            lw_row_twiddles<RA>(ctx, sm, ka, tc, lane, S, tlo);
+            lw_row_twiddles<RA>(ctx, sm, RA - 1 - ka, tc, lane, S, tup);
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {          // rows of the lower half: s1 of row pair k1; upper half: s2 of row pair R-1-k1, conj-reversed
+                const cf v = cmulc(g[kb], kb < 4 ? tlo[kb & 3] : tup[(7 - kb) & 3]);
                 g[kb] = kb < 4 ? v : conj(v);
             }
             fft8<true>(g);
+            lds[(ka * 8) * 64 + lane] = g[0];
 #pragma unroll
-            for (int j1 = 0; j1 < 8; ++j1) lds[(ka * 8 + j1) * 64 + lane] = cmulc(g[j1], p.tw_r[j1 * RA + ka]);
+            for (int j1 = 1; j1 < 8; ++j1) lds[(ka * 8 + j1) * 64 + lane] = cmulc(g[j1], ctx.ld(sm + ka * 8 + j1));
         }
         ctx.barrier();
         // step 2: wave = j1; inverse odd DFT over ka -> j2; frame 4096 (j1 + 8 j2) + t of the window

@@ -142,15 +142,20 @@ void build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels
     const int n_pairs = (n_channels + 1) / 2;
     const bool real_last = (n_channels & 1) != 0;
     // twiddles
-    out.coarse.resize(N / 32);
-    for (size_t e = 0; e < N / 32; ++e) out.coarse[e] = unit(64.0 * (double)e, 2.0 * (double)N);
-    out.fine.resize((size_t)(R / 2) * 64);
-    for (int k1 = 0; k1 < R / 2; ++k1)
-        for (int l = 0; l < 64; ++l) out.fine[(size_t)k1 * 64 + l] = unit((double)l * (2 * k1 + 1), 2.0 * (double)N);
     const int RA = R / 8;
-    out.tw_r.resize((size_t)8 * RA);
-    for (int j1 = 0; j1 < 8; ++j1)
-        for (int ka = 0; ka < RA; ++ka) out.tw_r[(size_t)j1 * RA + ka] = unit((double)j1 * (2 * ka + 1), 2.0 * R);
+    out.coarse.resize((size_t)RA * 64);
+    out.fine.resize((size_t)RA * 64);
+    for (int ka = 0; ka < RA; ++ka)
+        for (int i = 0; i < 64; ++i) {
+            out.coarse[(size_t)ka * 64 + i] = unit(64.0 * i * (2 * ka + 1), 2.0 * (double)N);
+            out.fine[(size_t)ka * 64 + i] = unit((double)i * (2 * ka + 1), 2.0 * (double)N);
+        }
+    out.step.resize((size_t)3 * M);
+    for (int m = 1; m <= 3; ++m)
+        for (int t = 0; t < M; ++t) out.step[(size_t)(m - 1) * M + t] = unit(2.0 * RA * m * (double)t, 2.0 * (double)N);
+    out.tw_r.resize((size_t)RA * 8);
+    for (int ka = 0; ka < RA; ++ka)
+        for (int j1 = 0; j1 < 8; ++j1) out.tw_r[(size_t)ka * 8 + j1] = unit((double)j1 * (2 * ka + 1), 2.0 * R);
     out.tw1m.resize(512);
     for (int t = 0; t < 512; ++t) out.tw1m[t] = unit((double)t, (double)M);
     // filter tables

@@ -39,10 +39,12 @@ inline int poly_history_frames(int taps) { return 2 * (taps / 2); }          // 
 //   tab    [R/2][pairs][8][512] {T0, T1, T2, T3}: the odd-frequency spectra (k + 1/2) of the pair filters at bin
 //          k = ra + R k2 (k2 = q1 + 8 q2 stored at [q1][q2]) and at its partner k' = N-1-k, scale 1/(2N) folded in; a real last
 //          channel (odd channel count) has T1 folded into T0 and T2 into T3
-//   coarse [N/32]: w_2N^{64 e};  fine [R/2][64]: w_2N^{lane (2 k1 + 1)};  tw_r [8][R/8]: w_2R^{j1 (2 ka + 1)};  tw1m [512]: w_4096^t
+//   row twiddles w_2N^{t (2 k1 + 1)}, t = 64 tc + lane, k1 = RA m + ka (RA = R/8) as coarse[ka][tc] fine[ka][lane] step[m][t]:
+//   coarse [RA][64]: w_2N^{64 tc (2 ka + 1)};  fine [RA][64]: w_2N^{lane (2 ka + 1)};  step [3][4096]: w_2N^{2 RA m t}, m = 1..3;
+//   tw_r [RA][8]: w_2R^{j1 (2 ka + 1)};  tw1m [512]: w_4096^t
 struct LwTables {
     std::vector<awk::LwTab> tab;
-    std::vector<awk::cf> coarse, fine, tw_r, tw1m;
+    std::vector<awk::cf> coarse, fine, step, tw_r, tw1m;
 };
 void build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
                      const int32_t *right_track, int R, LwTables &out);

@@ -369,6 +369,7 @@ void aw_spatializer_destroy(aw_spatializer *sp) {
         if (pl.d_coarse) (void)hipFree(pl.d_coarse);
         if (pl.d_fine) (void)hipFree(pl.d_fine);
         if (pl.d_tw_r) (void)hipFree(pl.d_tw_r);
+        if (pl.d_step) (void)hipFree(pl.d_step);
         if (pl.d_tw1m) (void)hipFree(pl.d_tw1m);
     }
     if (sp->d_flags) (void)hipFree(sp->d_flags);
@@ -700,6 +701,7 @@ static aw_status lw_get_plan(aw_spatializer *sp, int R, const aw_spatializer::Lw
     hipError_t e = up(t.tab.data(), t.tab.size() * sizeof(awk::LwTab), reinterpret_cast<void **>(&pl.d_tab));
     if (e == hipSuccess) e = up(t.coarse.data(), t.coarse.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_coarse));
     if (e == hipSuccess) e = up(t.fine.data(), t.fine.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_fine));
+    if (e == hipSuccess) e = up(t.step.data(), t.step.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_step));
     if (e == hipSuccess) e = up(t.tw_r.data(), t.tw_r.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_tw_r));
     if (e == hipSuccess) e = up(t.tw1m.data(), t.tw1m.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_tw1m));
     sp->lw_plans.push_back(pl);             // owned (and freed) by the spatializer even when an upload failed half way
@@ -748,7 +750,7 @@ static aw_status sp_process_longwin(aw_spatializer *sp, int R, const float *in, 
         p.R = R; p.N = (int)N;
         p.spec = sp->d_spec; p.spec_per_sw = sc.spec_per_sw;
         p.wrows = sp->d_spec + (size_t)sc.chunk * sc.n_windows * sc.spec_per_sw;
-        p.tab = plan->d_tab; p.tw_coarse = plan->d_coarse; p.tw_fine = plan->d_fine; p.tw_r = plan->d_tw_r; p.tw1m = plan->d_tw1m;
+        p.tab = plan->d_tab; p.tw_coarse = plan->d_coarse; p.tw_fine = plan->d_fine; p.tw_step = plan->d_step; p.tw_r = plan->d_tw_r; p.tw1m = plan->d_tw1m;
         p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb;
         p.persistent_wgs = sp->ctx->cfg.persistent_wgs;
         p.rows_pairs_per_batch = sp->ctx->cfg.lw_rows_pb;

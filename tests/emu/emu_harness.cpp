@@ -420,7 +420,7 @@ int emu_longwin(const float *in, float *out, const float *hist, const float *tra
     const long long n_sw = (long long)n_streams * p.n_windows;
     std::vector<cf> spec((size_t)(n_sw * p.spec_per_sw), mk(NAN, NAN)), wrows((size_t)(n_sw * N), mk(NAN, NAN));
     p.spec = spec.data(); p.wrows = wrows.data();
-    p.tab = lt.tab.data(); p.tw_coarse = lt.coarse.data(); p.tw_fine = lt.fine.data(); p.tw_r = lt.tw_r.data(); p.tw1m = lt.tw1m.data();
+    p.tab = lt.tab.data(); p.tw_coarse = lt.coarse.data(); p.tw_fine = lt.fine.data(); p.tw_step = lt.step.data(); p.tw_r = lt.tw_r.data(); p.tw1m = lt.tw1m.data();
     p.twa = tw.twa.data(); p.twb = tw.twb.data();
     EmuShared sh;
     auto run = [&](auto fn) {            // one emulated persistent workgroup walks every tile
