@@ -8,11 +8,11 @@ namespace awk {
 
 // Tile id = (stream, window) * 64 + t-chunk: workgroups that run at the same time read and write neighbouring 64-frame
 // pieces of the same R strided sub-sequences (whole DRAM pages between them).
-template <int RA, int CS>
+template <int RA, int CS, bool WIDE = false>
 __global__ void __launch_bounds__(kThreads, RA == 16 ? 2 : 4) aw_lw_split_kernel(LwParams p, long long n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
-    lw_split_tiles<GpuCtx, RA, CS>(ctx, p, (long long)blockIdx.x, (long long)gridDim.x, n_tiles);
+    lw_split_tiles<GpuCtx, RA, CS, WIDE>(ctx, p, (long long)blockIdx.x, (long long)gridDim.x, n_tiles);
 }
 
 // Row pairs are pinned to XCDs (blockIdx % 8 labels the XCD): XCD x walks the row pairs x, x + 8, ... one after the other
@@ -65,6 +65,12 @@ hipError_t prepare_lw_kernels() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lw_split_lds_bytes<RA>());
     AW_LW_FOR_RA_CS(AW_SET)
 #undef AW_SET
+#define AW_SET(RA, CS)                                                                                 \
+    if (e == hipSuccess)                                                                               \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_split_kernel<RA, CS, true>),     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lw_split_lds_bytes<RA>());
+    AW_LW_FOR_RA_CS(AW_SET)
+#undef AW_SET
 #define AW_SET(NP)                                                                                     \
     if (e == hipSuccess)                                                                               \
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_rows_kernel<NP, false>),         \
@@ -81,7 +87,7 @@ hipError_t prepare_lw_kernels() {
     if (e == hipSuccess)                                                                               \
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_rows1_kernel<NP, true>),         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLwRows1LdsBytes);
-    AW_SET(1) AW_SET(2) AW_SET(3) AW_SET(4)
+    AW_SET(1) AW_SET(2) AW_SET(3) AW_SET(4) AW_SET(5) AW_SET(6) AW_SET(7) AW_SET(8)
 #undef AW_SET
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_merge_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lw_merge_lds_bytes<4>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_merge_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lw_merge_lds_bytes<8>());
@@ -94,23 +100,31 @@ static unsigned lw_grid(long long n_tiles, const LwParams &p, int wgs_per_cu) {
     return (unsigned)(n_tiles < wgs ? n_tiles : wgs);
 }
 
-hipError_t launch_lw_split(const LwParams &p, int n_streams, hipStream_t stream, StageTimer *tm) {
-    const long long n_tiles = (long long)n_streams * p.n_windows * kLwChunks;
+hipError_t launch_lw_split(const LwParams &p_in, int n_streams, hipStream_t stream, StageTimer *tm) {
+    const long long n_tiles = (long long)n_streams * p_in.n_windows * kLwChunks;
     if (n_tiles <= 0) return hipSuccess;
-    if (n_tiles > 0x7fffffffLL || p.n_channels < 1 || p.n_channels > 8) return hipErrorInvalidValue;
-    const int ra = p.R / 8;
-    if (tm) tm->begin();
-    bool done = false;
-#define AW_CASE(RA, CS)                                                                                                        \
-    if (!done && ra == RA && p.n_channels == CS) {                                                                             \
-        hipLaunchKernelGGL((aw_lw_split_kernel<RA, CS>), dim3(lw_grid(n_tiles, p, RA == 16 ? 1 : 2)), dim3(kThreads),          \
-                           lw_split_lds_bytes<RA>(), stream, p, n_tiles);                                                      \
-        done = true;                                                                                                           \
-    }
-    AW_LW_FOR_RA_CS(AW_CASE)
+    if (n_tiles > 0x7fffffffLL || p_in.n_channels < 1 || p_in.n_channels > 16) return hipErrorInvalidValue;
+    const int ra = p_in.R / 8;
+    const bool wide = p_in.n_channels > 8;           // two launches, one per group of (up to) eight channels
+    for (int c0 = 0; c0 < p_in.n_channels; c0 += 8) {
+        LwParams p = p_in;
+        p.ch0 = c0; p.pair0 = c0 / 2;
+        const int cs = p.n_channels - c0 < 8 ? p.n_channels - c0 : 8;
+        if (tm) tm->begin();
+        bool done = false;
+#define AW_CASE(RA, CS)                                                                                                            \
+        if (!done && ra == RA && cs == CS) {                                                                                       \
+            const dim3 grid(lw_grid(n_tiles, p, RA == 16 ? 1 : 2));                                                                \
+            if (wide) hipLaunchKernelGGL((aw_lw_split_kernel<RA, CS, true>), grid, dim3(kThreads), lw_split_lds_bytes<RA>(), stream, p, n_tiles);   \
+            else hipLaunchKernelGGL((aw_lw_split_kernel<RA, CS, false>), grid, dim3(kThreads), lw_split_lds_bytes<RA>(), stream, p, n_tiles);       \
+            done = true;                                                                                                           \
+        }
+        AW_LW_FOR_RA_CS(AW_CASE)
 #undef AW_CASE
-    if (tm) tm->end("aw_lw_split_kernel");
-    return done ? hipGetLastError() : hipErrorInvalidValue;
+        if (tm) tm->end("aw_lw_split_kernel");
+        if (!done) return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_lw_rows(const LwParams &p, int n_streams, hipStream_t stream, StageTimer *tm) {
@@ -119,7 +133,7 @@ hipError_t launch_lw_rows(const LwParams &p, int n_streams, hipStream_t stream, 
     if (n_tiles <= 0) return hipSuccess;
     if (n_tiles > 0x7fffffffLL) return hipErrorInvalidValue;
     // 8 XCD groups: a grid that is a multiple of 8 (every group has the same number of workgroups), at least 8
-    const bool one = p.rows_pairs_per_batch == 1;
+    const bool one = p.rows_pairs_per_batch == 1 || p.n_pairs > 4;          // the two-pairs-per-batch form exists for up to four pairs
     unsigned grid = lw_grid((n_tiles + 7) / 8 * 8, p, one ? 2 : 1) / 8 * 8;
     if (grid < 8) grid = 8;
     if (tm) tm->begin();
@@ -130,7 +144,7 @@ hipError_t launch_lw_rows(const LwParams &p, int n_streams, hipStream_t stream, 
             if (real) hipLaunchKernelGGL((aw_lw_rows1_kernel<NP, true>), dim3(grid), dim3(kThreads), kLwRows1LdsBytes, stream, p, n_sw);   \
             else hipLaunchKernelGGL((aw_lw_rows1_kernel<NP, false>), dim3(grid), dim3(kThreads), kLwRows1LdsBytes, stream, p, n_sw);       \
             break;
-        AW_CASE(1) AW_CASE(2) AW_CASE(3) AW_CASE(4)
+        AW_CASE(1) AW_CASE(2) AW_CASE(3) AW_CASE(4) AW_CASE(5) AW_CASE(6) AW_CASE(7) AW_CASE(8)
 #undef AW_CASE
         default: return hipErrorInvalidValue;
     }

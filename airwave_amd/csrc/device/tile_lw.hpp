@@ -43,6 +43,9 @@ constexpr int kLwInner = kLwM / kSub;       // 8 inner rows of 512 per row: radi
 constexpr int kLwTw = 64;                   // frames t per split / merge tile: one wave wide
 constexpr int kLwChunks = kLwM / kLwTw;     // 64 tiles per (stream, window)
 
+#ifndef AW_LW_TAB_EARLY
+#define AW_LW_TAB_EARLY 0           // rows kernel: table entries of a pair fetched before its sub-FFTs
+#endif
 #ifndef AW_LW_PREFETCH_EARLY
 #define AW_LW_PREFETCH_EARLY 0      // rows kernel, fetch of the next tile's first batch: 0 under the final pass, 1 right after the last pass 1, 2 before the inverse sub-FFTs
 #endif
@@ -58,6 +61,7 @@ struct LwParams {
     const float *zeros;     // >= 64 bytes of zeros
     long long frames;       // frames per stream in this call
     int n_channels, n_pairs;
+    int ch0, pair0;         // split kernel, layouts of 9-16 channels: this launch's group of up to eight channels starts at channel ch0 = 2 pair0
     int real_last;          // odd channel count: the last pair's second channel is absent (real input)
     int hist_len;           // N - hop >= taps - 1: window positions below it are discarded
     int hop;                // new output frames per window
@@ -126,11 +130,11 @@ template <bool INV, int NN> AW_HD void lw_odd_dft(cf (&v)[NN]) {
 struct __attribute__((packed, aligned(4))) f3u { float x, y, z; };
 
 // One whole interleaved frame of CS channels -> registers (dword-aligned vector loads; exactly CS floats are read).
-template <int CS> AW_HD void lw_load_frame(const float *src, float (&d)[CS]) {
+template <int CS, bool ALIGNED = (CS % 4 == 0)> AW_HD void lw_load_frame(const float *src, float (&d)[CS]) {
     constexpr int n4 = CS / 4, rem = CS % 4;
 #pragma unroll
     for (int g = 0; g < n4; ++g) {
-        if constexpr (CS % 4 == 0) {
+        if constexpr (ALIGNED) {
             const f4 v = *reinterpret_cast<const f4 *>(src + 4 * g);
             d[4 * g] = v.x; d[4 * g + 1] = v.y; d[4 * g + 2] = v.z; d[4 * g + 3] = v.w;
         } else {
@@ -142,23 +146,23 @@ template <int CS> AW_HD void lw_load_frame(const float *src, float (&d)[CS]) {
         const f3u v = *reinterpret_cast<const f3u *>(src + 4 * n4);
         d[4 * n4] = v.x; d[4 * n4 + 1] = v.y; d[4 * n4 + 2] = v.z;
     } else if constexpr (rem == 2) {
-        if constexpr (CS % 2 == 0) { const f2 v = *reinterpret_cast<const f2 *>(src + 4 * n4); d[4 * n4] = v.x; d[4 * n4 + 1] = v.y; }
+        if constexpr (CS % 2 == 0 && ALIGNED == (CS % 4 == 0)) { const f2 v = *reinterpret_cast<const f2 *>(src + 4 * n4); d[4 * n4] = v.x; d[4 * n4 + 1] = v.y; }
         else { const f2u v = *reinterpret_cast<const f2u *>(src + 4 * n4); d[4 * n4] = v.x; d[4 * n4 + 1] = v.y; }
     } else if constexpr (rem == 1) {
         d[4 * n4] = src[4 * n4];
     }
 }
 
-template <int CS> AW_HD void lw_store_frame(float *dst, const float (&d)[CS]) {
+template <int CS, bool ALIGNED = (CS % 4 == 0)> AW_HD void lw_store_frame(float *dst, const float (&d)[CS]) {
     constexpr int n4 = CS / 4, rem = CS % 4;
 #pragma unroll
     for (int g = 0; g < n4; ++g) {
-        if constexpr (CS % 4 == 0) { f4 v; v.x = d[4 * g]; v.y = d[4 * g + 1]; v.z = d[4 * g + 2]; v.w = d[4 * g + 3]; *reinterpret_cast<f4 *>(dst + 4 * g) = v; }
+        if constexpr (ALIGNED) { f4 v; v.x = d[4 * g]; v.y = d[4 * g + 1]; v.z = d[4 * g + 2]; v.w = d[4 * g + 3]; *reinterpret_cast<f4 *>(dst + 4 * g) = v; }
         else { f4u v; v.x = d[4 * g]; v.y = d[4 * g + 1]; v.z = d[4 * g + 2]; v.w = d[4 * g + 3]; *reinterpret_cast<f4u *>(dst + 4 * g) = v; }
     }
     if constexpr (rem == 3) { f3u v; v.x = d[4 * n4]; v.y = d[4 * n4 + 1]; v.z = d[4 * n4 + 2]; *reinterpret_cast<f3u *>(dst + 4 * n4) = v; }
     else if constexpr (rem == 2) {
-        if constexpr (CS % 2 == 0) { f2 v; v.x = d[4 * n4]; v.y = d[4 * n4 + 1]; *reinterpret_cast<f2 *>(dst + 4 * n4) = v; }
+        if constexpr (CS % 2 == 0 && ALIGNED == (CS % 4 == 0)) { f2 v; v.x = d[4 * n4]; v.y = d[4 * n4 + 1]; *reinterpret_cast<f2 *>(dst + 4 * n4) = v; }
         else { f2u v; v.x = d[4 * n4]; v.y = d[4 * n4 + 1]; *reinterpret_cast<f2u *>(dst + 4 * n4) = v; }
     } else if constexpr (rem == 1) dst[4 * n4] = d[4 * n4];
 }
@@ -183,10 +187,15 @@ AW_HD void lw_row_twiddles(Ctx &ctx, const cf *sm, int ka, int tc, int lane, con
 // Tile id = (stream, window) * 64 + tc.  512 threads: wave = j1, lane = t - 64 tc.  LDS: [2][RA][8][64] complex.
 template <int RA> constexpr int lw_split_lds_elems() { return 2 * RA * 8 * 64 + lw_small_elems<RA>(); }
 
-template <class Ctx, int RA, int CS>
+// WIDE (layouts of 9-16 channels): the launch handles the group of CS <= 8 channels starting at p.ch0 of frames that are
+// p.n_channels wide (dword-aligned loads); otherwise the frame IS the group (CS == p.n_channels, compile-time stride).
+template <class Ctx, int RA, int CS, bool WIDE = false>
 AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long long step, long long end) {
     static_assert(RA == 4 || RA == 8 || RA == 16, "R = 32, 64 or 128 rows");
     static_assert(CS >= 1 && CS <= 8, "up to eight channels per group");
+    constexpr bool AL = !WIDE && CS % 4 == 0;
+    const int CF = WIDE ? p.n_channels : CS;              // floats per frame
+    const int c0 = WIDE ? p.ch0 : 0, pair0 = WIDE ? p.pair0 : 0;
     constexpr int NP = (CS + 1) / 2, NPASS = (NP + 1) / 2, NCOMBO = RA / 4, G = RA >= 8 ? RA / 8 : 1;
     if (first >= end) return;
     const int lane = ctx.lane(), wave = ctx.wave();
@@ -199,20 +208,20 @@ AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
         const int tc = (int)(id - sw * kLwChunks);
         const long long stream = sw / p.n_windows;
         const int win = (int)(sw - stream * p.n_windows);
-        const float *in_s = p.in + stream * p.frames * CS;
-        const float *hist_s = p.hist + stream * (long long)p.hist_len * CS;
+        const float *in_s = p.in + stream * p.frames * CF + c0;
+        const float *hist_s = p.hist + stream * (long long)p.hist_len * CF + c0;
         const long long fb = (long long)win * p.hop - p.hist_len + (long long)kLwM * wave + tc * kLwTw + lane;
 #pragma unroll
         for (int j2 = 0; j2 < RA; ++j2) {
             const long long f = fb + (long long)kLwM * 8 * j2;
             // frames before the call: the history buffer; past its end: a page of zeros (a pointer select, never a select on data)
-            const float *src = f < 0 ? hist_s + ((long long)p.hist_len + f) * CS : (f >= p.frames ? p.zeros : in_s + f * CS);
+            const float *src = f < 0 ? hist_s + ((long long)p.hist_len + f) * CF : (f >= p.frames ? p.zeros : in_s + f * CF);
 #ifdef AW_LW_ABL_SPLIT_NOLOAD     // timing ablation only (wrong results)
 #pragma unroll
             for (int c = 0; c < CS; ++c) raw[j2][c] = 0.001f * lane + (float)(src == nullptr);
             continue;
 #endif
-            lw_load_frame<CS>(src, raw[j2]);
+            lw_load_frame<CS, AL>(src, raw[j2]);
         }
     };
     load_tile(first);
@@ -228,11 +237,11 @@ AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
             const long long stream = sw / p.n_windows;
             const int win = (int)(sw - stream * p.n_windows);
             const long long fb = (long long)win * p.hop - p.hist_len + (long long)kLwM * wave + t;
-            float *ho = p.hist_out + stream * (long long)p.hist_len * CS;
+            float *ho = p.hist_out + stream * (long long)p.hist_len * CF + c0;
 #pragma unroll
             for (int j2 = 0; j2 < RA; ++j2) {
                 const long long i = fb + (long long)kLwM * 8 * j2 - (p.frames - p.hist_len);
-                if (i >= 0 && i < p.hist_len) lw_store_frame<CS>(ho + i * CS, raw[j2]);
+                if (i >= 0 && i < p.hist_len) lw_store_frame<CS, AL>(ho + i * CF, raw[j2]);
             }
         }
         lw_unroll<NPASS>([&](auto PP) {
@@ -271,8 +280,8 @@ AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
                 cf tlo[4], tup[4];
                 lw_row_twiddles<RA>(ctx, sm, ka, tc, lane, S, tlo);
                 lw_row_twiddles<RA>(ctx, sm, RA - 1 - ka, tc, lane, S, tup);
-                const bool real_pair = (CS & 1) && pair == NP - 1;
-                cf *dst = spec_sw + (long long)pair * p.N + t;
+                const bool real_pair = (CS & 1) && pair == NP - 1;        // (an odd layout's last group carries its real last channel)
+                cf *dst = spec_sw + (long long)(pair0 + pair) * p.N + t;
 #pragma unroll
                 for (int kb = 0; kb < 8; ++kb) {
                     const int k1 = RA * kb + ka;
@@ -451,6 +460,11 @@ AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long
                     }
                 } else {
                     cf z[2][8];
+#if AW_LW_TAB_EARLY
+                    LwTab Tq[8];          // issued before the sub-FFTs: the L2 round trip hides under them (64 more live registers)
+#pragma unroll
+                    for (int kc = 0; kc < 8; ++kc) Tq[kc] = tb[64 * kc];
+#endif
                     ctx.template ld8x2<64>(z[0], row0 + lane, z[1], row1 + lane);
                     ctx.wave_sync();
                     sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
@@ -458,6 +472,8 @@ AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long
                     for (int kc = 0; kc < 8; ++kc) {
 #ifdef AW_LW_ABL_ROWS_NOTAB       // timing ablation only (wrong results)
                         const LwTab T{mk(1.f, 0.5f * lane), mk(0.3f, 0.1f), mk(0.2f * pair, 0.7f), mk(0.25f * kc, 1.f * wave)};
+#elif AW_LW_TAB_EARLY
+                        const LwTab T = Tq[kc];
 #else
                         const LwTab T = tb[64 * kc];
 #endif

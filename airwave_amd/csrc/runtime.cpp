@@ -318,7 +318,7 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
         if (const char *e = getenv("AW_PART_HERM")) sp->herm_ok = atoi(e) != 0;          // A/B: 0 stores the last pair's redundant half too
         // long calls of this spatializer run on the long-window kernels (device/tile_lw.hpp) — chosen per call, see lw_choose()
         if (const char *e = getenv("AW_LW")) sp->lw_mode = atoi(e);
-        if (n_in > 8) sp->lw_mode = 0;                                                   // up to four channel pairs
+        if (n_in > 16) sp->lw_mode = 0;                                                  // up to eight channel pairs
         if (sp->lw_mode != 0) {
             sp->lw_tracks = hrir->tracks; sp->lw_n_tracks = hrir->n_tracks;
             sp->lw_left.assign(left_track, left_track + n_in); sp->lw_right.assign(right_track, right_track + n_in);
@@ -662,7 +662,7 @@ static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, flo
 // Cost model (fabric bytes): the long-window kernels move 12 C + 24 bytes per WINDOW frame (input + rows
 // written, rows read + s1/s2 written, s1/s2 read + stereo out), the partitioned ones ~29 C bytes per OUTPUT frame.
 static int lw_choose(const aw_spatializer *sp, int64_t frames, bool for_reserve = false) {
-    if (sp->path != 1 || sp->lw_mode == 0 || sp->n_channels > 8) return 0;
+    if (sp->path != 1 || sp->lw_mode == 0 || sp->n_channels > 16) return 0;
     // calls inside what aw_spatializer_reserve() sized never build tables: only window lengths whose tables exist are candidates
     const bool existing_only = !for_reserve && frames <= sp->reserved_frames;
     auto have = [&](int R) { for (const auto &pl : sp->lw_plans) if (pl.R == R) return true; return false; };

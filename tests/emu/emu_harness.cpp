@@ -402,7 +402,7 @@ int emu_longwin(const float *in, float *out, const float *hist, const float *tra
     using namespace awk;
     if (R != 32 && R != 64 && R != 128) return -1;
     const long long N = (long long)R * kLwM;
-    if (hop <= 0 || N - hop < taps - 1 || n_channels < 1 || n_channels > 8) return -2;
+    if (hop <= 0 || N - hop < taps - 1 || n_channels < 1 || n_channels > 16) return -2;
     awh::Twiddles tw;
     awh::build_twiddles(tw);
     awh::LwTables lt;
@@ -432,34 +432,40 @@ int emu_longwin(const float *in, float *out, const float *hist, const float *tra
     const long long n_st = n_sw * kLwChunks;
     auto split = [&](auto RA) {
         constexpr int ra = decltype(RA)::value;
-        run([&](EmuCtx &ctx) {
-            switch (n_channels) {
-                case 1: lw_split_tiles<EmuCtx, ra, 1>(ctx, p, 0, 1, n_st); break;
-                case 2: lw_split_tiles<EmuCtx, ra, 2>(ctx, p, 0, 1, n_st); break;
-                case 3: lw_split_tiles<EmuCtx, ra, 3>(ctx, p, 0, 1, n_st); break;
-                case 4: lw_split_tiles<EmuCtx, ra, 4>(ctx, p, 0, 1, n_st); break;
-                case 5: lw_split_tiles<EmuCtx, ra, 5>(ctx, p, 0, 1, n_st); break;
-                case 6: lw_split_tiles<EmuCtx, ra, 6>(ctx, p, 0, 1, n_st); break;
-                case 7: lw_split_tiles<EmuCtx, ra, 7>(ctx, p, 0, 1, n_st); break;
-                default: lw_split_tiles<EmuCtx, ra, 8>(ctx, p, 0, 1, n_st); break;
-            }
-        });
+        for (int c0 = 0; c0 < n_channels; c0 += 8) {          // layouts of 9-16 channels: one pass per group of eight channels
+            LwParams q = p;
+            q.ch0 = c0; q.pair0 = c0 / 2;
+            const int cs = std::min(8, n_channels - c0);
+            const bool wide = n_channels > 8;
+            run([&](EmuCtx &ctx) {
+                auto go = [&](auto CS) {
+                    constexpr int c = decltype(CS)::value;
+                    if (wide) lw_split_tiles<EmuCtx, ra, c, true>(ctx, q, 0, 1, n_st);
+                    else lw_split_tiles<EmuCtx, ra, c, false>(ctx, q, 0, 1, n_st);
+                };
+                switch (cs) {
+                    case 1: go(LwIdx<1>{}); break; case 2: go(LwIdx<2>{}); break; case 3: go(LwIdx<3>{}); break; case 4: go(LwIdx<4>{}); break;
+                    case 5: go(LwIdx<5>{}); break; case 6: go(LwIdx<6>{}); break; case 7: go(LwIdx<7>{}); break; default: go(LwIdx<8>{}); break;
+                }
+            });
+        }
     };
     if (R == 32) split(LwIdx<4>{}); else if (R == 64) split(LwIdx<8>{}); else split(LwIdx<16>{});
     const long long n_rt = n_sw * (R / 2);
     auto rows = [&](auto PBB) {
         constexpr int pb = decltype(PBB)::value;
         run([&](EmuCtx &ctx) {
-            switch (n_channels) {
-                case 1: lw_rows_tiles<EmuCtx, 1, true, pb>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
-                case 2: lw_rows_tiles<EmuCtx, 1, false, pb>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
-                case 3: lw_rows_tiles<EmuCtx, 2, true, pb>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
-                case 4: lw_rows_tiles<EmuCtx, 2, false, pb>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
-                case 5: lw_rows_tiles<EmuCtx, 3, true, pb>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
-                case 6: lw_rows_tiles<EmuCtx, 3, false, pb>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
-                case 7: lw_rows_tiles<EmuCtx, 4, true, pb>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
-                default: lw_rows_tiles<EmuCtx, 4, false, pb>(ctx, p, 0, 1, n_rt, n_sw, 0, 1); break;
-            }
+            auto go = [&](auto NPP, auto REAL) {
+                lw_rows_tiles<EmuCtx, decltype(NPP)::value, (decltype(REAL)::value != 0), (decltype(NPP)::value > 4 ? 1 : pb)>(ctx, p, 0, 1, n_rt, n_sw, 0, 1);
+            };
+            const int np = p.n_pairs;
+            auto go_np = [&](auto REAL) {
+                switch (np) {
+                    case 1: go(LwIdx<1>{}, REAL); break; case 2: go(LwIdx<2>{}, REAL); break; case 3: go(LwIdx<3>{}, REAL); break; case 4: go(LwIdx<4>{}, REAL); break;
+                    case 5: go(LwIdx<5>{}, REAL); break; case 6: go(LwIdx<6>{}, REAL); break; case 7: go(LwIdx<7>{}, REAL); break; default: go(LwIdx<8>{}, REAL); break;
+                }
+            };
+            if (p.real_last) go_np(LwIdx<1>{}); else go_np(LwIdx<0>{});
         });
     };
     if (rows_pb == 1) rows(LwIdx<1>{}); else rows(LwIdx<2>{});

@@ -22,7 +22,7 @@ def _case(oracle, channels, taps, frames, R, seed=5, hop=None, hist_frames=0):
     return h, lt, rt, x, ref
 
 
-@pytest.mark.parametrize("channels,rows_pb", [(7, 2), (8, 2), (1, 2), (2, 2), (5, 2), (7, 1), (6, 1), (1, 1)])
+@pytest.mark.parametrize("channels,rows_pb", [(7, 2), (8, 2), (1, 2), (2, 2), (5, 2), (7, 1), (6, 1), (1, 1), (14, 1), (9, 1), (13, 2), (16, 1)])
 def test_emulated_long_window_matches_truth(oracle, channels, rows_pb):
     # one window of 32 x 4096 frames holds the whole call: history (zeros), input, zero fill past the end;
     # rows_pb = channel pairs per batch of the rows kernel (1: the two-workgroups-per-CU form)

@@ -23,7 +23,7 @@ def _maps(channels):
 
 
 @pytest.mark.parametrize("rows", [32, 64, 128])
-@pytest.mark.parametrize("channels", [7, 8, 2, 1, 5])
+@pytest.mark.parametrize("channels", [7, 8, 2, 1, 5, 14, 9, 12, 13, 16])
 def test_long_window_kernels_match_truth(aw, oracle, monkeypatch, rows, channels):
     monkeypatch.setenv("AW_LW", str(rows))                   # force the window length (automatic choice: next test)
     taps, S = 32768, 2
