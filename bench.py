@@ -14,7 +14,9 @@ already resident in HBM.  Default workload = the configuration BASELINE.json's m
 (SURVEY.md §8d item 3): 1024 streams x 10 s @ 48 kHz, 14-track 32768-tap HeSuVi HRIR, primary reading C = 7 speakers
 [FL,FR,FC,BL,BR,SL,SR] (all 14 tracks).  The 14-channel-input reading of the same configuration (C = 14 custom channels
 through a parseHeSuViFormat text map) is measured in the same run and reported as `"secondary"` inside the one JSON line.
-`--workload cfg1|cfg2|cfg4|cfg5|cfg3-14ch` benches the other BASELINE configurations on request.
+`--workload cfg1|cfg2|cfg2-14ch|cfg4|cfg5|cfg3-14ch` benches the other BASELINE configurations on request.  After the timed
+region (untimed, in the CPU-baseline leg) two streams' head and tail of the last step are compared with the float64 oracle:
+`parity_spot_err` (primary and secondary); above 1e-5 the exit code is 3.
 
 Streams are independent, so N GPUs = N ranks each owning its own batch (weak scaling, no data-path collective); RCCL
 carries only the final {frames (sum), elapsed (max)} aggregate.  One JSON line on rank 0.
@@ -40,6 +42,9 @@ WORKLOADS = {
                  desc="cfg1: stereo 48 kHz -> NeutralSH1.0, 1 stream (plumbing)"),
     "cfg2": dict(streams=128, channels=8, hrir="RoomSH1.0.wav", taps=4320, seconds=10.0, steps=20, warmup=3,
                  desc="cfg2: 7.1 (8ch) 48 kHz -> RoomSH1.0 14-track HeSuVi HRIR, 128-stream batch x 10 s"),
+    "cfg2-14ch": dict(streams=128, channels=14, hrir="RoomSH1.0.wav", taps=4320, seconds=10.0, steps=20, warmup=3, text_map="hesuvi14_custom_map.txt",
+                      desc="cfg2, 14-ch-input reading (north_star's literal case): InputLayout.detect(14) custom channels through the committed "
+                           "parseHeSuViFormat text map -> RoomSH1.0 14-track HeSuVi HRIR (4320 taps), 128-stream batch x 10 s"),
     "cfg3": dict(streams=1024, channels=7, hrir=None, taps=32768, seconds=10.0, steps=10, warmup=2,
                  desc="cfg3: 7 speakers [FL,FR,FC,BL,BR,SL,SR] 48 kHz -> synthetic 14 x 32768-tap HeSuVi HRIR (seed 1234), 1024-stream batch x 10 s"),
     "cfg3-14ch": dict(streams=1024, channels=14, hrir=None, taps=32768, seconds=10.0, steps=5, warmup=1, text_map="hesuvi14_custom_map.txt",
@@ -136,11 +141,50 @@ def cpu_baseline(x_host, tracks, lt, rt, frames: int, eq_definition=None, rate: 
     }
 
 
+def oracle_spot_check(x_dev, y_dev, tracks, lt, rt, calls: int, streams=(0, -1), head: int = 4096, tail: int = 2048):
+    """Part of the CPU-baseline leg (the oracle as the CHECKER of what was just timed, never the thing measured): the first `head`
+    and last `tail` output frames of two streams of the LAST timed step against the float64 oracle (oracle.spatialize_f64, the
+    mathematical definition the reference's ConvolutionEngine approximates; the reference holds no vector for real HRIRs).
+    The steps continue one stream (no reset between them), so the head is checked with the previous step's tail as history.
+    Returns the worst peak-relative error."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import airwave_oracle as orc
+    L = tracks.shape[1]
+    F = x_dev.shape[1]
+    worst = 0.0
+    for s in streams:
+        if calls >= 2 and F >= L - 1:          # history of the last step = the tail of the same input
+            xin = np.concatenate([x_dev[s, F - (L - 1):].cpu().numpy(), x_dev[s, :head].cpu().numpy()])
+            ref = orc.spatialize_f64(xin, tracks, lt, rt)[L - 1:]
+        else:
+            ref = orc.spatialize_f64(x_dev[s, :head].cpu().numpy(), tracks, lt, rt)
+        worst = max(worst, orc.peak_rel_error(y_dev[s, :head].cpu().numpy(), ref))
+        n0 = max(0, F - tail - (L - 1))
+        xin = x_dev[s, n0:].cpu().numpy()
+        if n0 == 0 and calls >= 2 and F >= L - 1:
+            xin = np.concatenate([x_dev[s, F - (L - 1):].cpu().numpy(), xin])
+            ref = orc.spatialize_f64(xin, tracks, lt, rt)[-tail:]
+        else:
+            ref = orc.spatialize_f64(xin, tracks, lt, rt)[-tail:]
+        worst = max(worst, orc.peak_rel_error(y_dev[s, F - tail:].cpu().numpy(), ref))
+    return worst
+
+
 # ---------------------------------------------------------------------------------------------- one workload
 def flops_per_frame(C: int, path: dict) -> float:
     """Algorithmic flops of the transforms THIS implementation runs per output frame (for the FP32-vector roof)."""
     n8 = 8192
     fft = 5 * n8 * 13
+    if path["path"].startswith("long-window"):
+        # per window of N frames: one complex FFT_N per channel pair (a real last channel: half of one), one inverse, and per bin pair
+        # and channel pair four complex multiply-accumulates (2x2 in-lane CMAC)
+        import math
+        N, hop, frames = path["fft"], path["hop"], path["frames"]
+        windows = -(-frames // hop)
+        pairs_eff = C / 2.0
+        per_window = (pairs_eff + 1) * 5 * N * math.log2(N) + (N / 2) * math.ceil(C / 2) * 4 * 8
+        return windows * per_window / frames
     if path["path"].startswith("fused"):
         long_win = path["fft"] == 16384
         pairs = (2 * C + 1) // 2 if long_win else (C + 1) // 2
@@ -150,7 +194,7 @@ def flops_per_frame(C: int, path: dict) -> float:
     return ((pairs + 1) * fft + path["partitions"] * pairs * n8 * 16) / path["hop"]
 
 
-def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with_cpu: bool):
+def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with_cpu: bool, with_check: bool = None):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -244,11 +288,16 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
             dom_ms += ms * launches_per_step
             dom_frames += info["dominant_frames"] * launches_per_step if info["path"] == 0 else g["n"] * g["F"]
             dom_names.append(kname)
-            paths.append({"rate": g["rate"], "streams": g["n"], "frames": g["F"], "taps": g["taps"], "fft": info["fft"], "hop": info["hop"],
-                          "partitions": info["partitions"], "path": "fused overlap-save" if info["path"] == 0 else "partitioned"})
+            lw = info.get("long_window_rows", 0)
+            if lw:        # the long-window kernels ran (tile_lw.hpp): windows of lw x 4096 frames, hop = window - history
+                paths.append({"rate": g["rate"], "streams": g["n"], "frames": g["F"], "taps": g["taps"], "fft": lw * 4096, "hop": lw * 4096 - info["history"],
+                              "partitions": 1, "path": "long-window overlap-save (four-step FFT: split / rows / merge)"})
+            else:
+                paths.append({"rate": g["rate"], "streams": g["n"], "frames": g["F"], "taps": g["taps"], "fft": info["fft"], "hop": info["hop"],
+                              "partitions": info["partitions"], "path": "fused overlap-save" if info["path"] == 0 else "partitioned"})
         finite = all(bool(torch.isfinite(g["y"][:, -4096:]).all().item()) for g in legs)
         g0 = legs[0]
-        if all(pp["path"] == "partitioned" for pp in paths) and stages:
+        if all(pp["path"] != "fused overlap-save" for pp in paths) and stages:
             # multi-kernel pipeline: every stage's launches cover all frames of the step; the dominant kernel is the longest stage
             kname = max(stages, key=lambda k: stages[k]["ms_per_step"])
             dom_ms, dom_frames, dom_names = stages[kname]["ms_per_step"], frames_step, [kname]
@@ -309,6 +358,15 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
             eq_ms = sum(a.elapsed_time(b) for a, b in eq_events) / steps
             result["roofline"]["eq_kernel_ms_per_step"] = eq_ms
             result["roofline"]["eq_achieved_GBs"] = 16.0 * frames_step / (eq_ms * 1e-3) / 1e9      # 8 B in + 8 B out per frame
+        if with_check is None:
+            with_check = with_cpu
+        if with_check and world == 1 and eq_def is None and len(legs) == 1:
+            # parity of the TIMED configuration (same buffers, same scratch chunking, same kernels): two streams' head and tail
+            tr0 = aw.resample_tracks(tracks, 48000.0, float(g0["rate"]))
+            err = oracle_spot_check(g0["x"], g0["y"], tr0, lt, rt, calls=warmup + steps)
+            result["parity_spot_err"] = err
+            result["parity_spot"] = ("max peak-relative error of streams 0 and n-1, first 4096 and last 2048 output frames of the last timed step, "
+                                     "against the float64 oracle (direct-form linear convolution; the reference pins only delta-HRIR KATs); tolerance 1e-5")
         if with_cpu and world == 1:      # the CPU baseline is reported at N = 1 only
             ns = max(1, min(g0["n"], args.cpu_sample_streams))
             Fc = g0["F"] if name in ("cfg1", "cfg2") else min(g0["F"], int(4 * g0["rate"]))     # long-tap configs: 4 s per stream
@@ -398,19 +456,25 @@ def main() -> int:
             raise SystemExit(f"rendezvous produced {dist.get_world_size()} ranks for --gpus {args.gpus}")
 
     import airwave_amd as aw
+    print(f"[bench rank {rank}/{world}] device {local_rank}: {torch.cuda.get_device_name(local_rank)}, backend {backend if world > 1 else 'none'}", file=sys.stderr, flush=True)
     ctx = aw.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
     result = run_workload(args.workload, args, ctx, world, rank, backend, with_cpu=not args.no_cpu_baseline)
     sec = SECONDARY.get(args.workload)
     if sec and not args.no_secondary and not args.streams and not args.seconds:
-        r2 = run_workload(sec, args, ctx, world, rank, backend, with_cpu=False)
+        r2 = run_workload(sec, args, ctx, world, rank, backend, with_cpu=False, with_check=not args.no_cpu_baseline)
         if rank == 0:
-            result["secondary"] = {k: r2[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "roofline", "fp32_roof") if k in r2}
+            result["secondary"] = {k: r2[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "roofline", "fp32_roof", "parity_spot_err") if k in r2}
             result["secondary"]["note"] = "same configuration read as 14-channel INPUT (north_star: 'synthetic 48 kHz 14-ch input'); value is never the headline"
+    rc = 0
     if rank == 0:
         print(json.dumps(result), flush=True)
+        errs = [e for e in (result.get("parity_spot_err"), result.get("secondary", {}).get("parity_spot_err")) if e is not None]
+        if any(not (e < 1e-5) for e in errs):
+            print(f"bench.py: parity spot check FAILED: {errs} (tolerance 1e-5)", file=sys.stderr)
+            rc = 3
     if world > 1:
         dist.destroy_process_group()
-    return 0
+    return rc
 
 
 if __name__ == "__main__":

@@ -21,14 +21,20 @@ def aw():
 def _energies_distinct(y, S):
     e = (y.double() ** 2).sum(dim=(1, 2))
     assert float(e.min()) > 0.25 * float(e.max())
-    assert len(set(np.round((e / e.max()).cpu().numpy(), 9).tolist())) == S
+    assert len(set(e.cpu().numpy().tolist())) == S          # float64 sums of 10^6 squares: equal only for duplicated streams
 
 
-def test_full_size_properties_cfg3(aw, oracle, monkeypatch):
-    """cfg 3: 1024 streams x 10 s x 7 speakers, 14 x 32768-tap HRIR -> partitioned path (8 partitions), with the
-    scratch budget lowered so that the batch runs as three stream chunks; one sampled stream at each chunk edge."""
+@pytest.mark.parametrize("kernels,scratch_mb", [("long-window", None), ("long-window", "8192"), ("partitioned", None), ("partitioned", "16384")])
+def test_full_size_properties_cfg3(aw, oracle, monkeypatch, kernels, scratch_mb):
+    """cfg 3: 1024 streams x 10 s x 7 speakers, 14 x 32768-tap HRIR, on both kernel sets a path-1 spatializer owns:
+    the long-window kernels (one 524288-frame window per stream; what bench.py times, with the default scratch budget = ONE
+    stream chunk) and the partitioned ones (AW_LW=0: 8 partitions of 4096), each also with a lowered scratch budget so that the
+    batch runs as several stream chunks; sampled streams include every chunk edge."""
     import torch
-    monkeypatch.setenv("AW_SPEC_SCRATCH_MB", "16384")
+    if scratch_mb:
+        monkeypatch.setenv("AW_SPEC_SCRATCH_MB", scratch_mb)
+    if kernels == "partitioned":
+        monkeypatch.setenv("AW_LW", "0")
     S, F, C, L = 1024, 480000, 7, 32768
     ctx = aw.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     h = oracle.synth_hrir(14, L, seed=1234)
@@ -43,13 +49,17 @@ def test_full_size_properties_cfg3(aw, oracle, monkeypatch):
     y = torch.empty((S, F, 2), dtype=torch.float32, device="cuda")
     sp.process_device(x.data_ptr(), y.data_ptr(), F)
     torch.cuda.synchronize()
+    assert sp.info()["long_window_rows"] == (128 if kernels == "long-window" else 0)
     assert torch.isfinite(y).all()
-    # chunk = floor(16 GiB / ((124 windows x 4 pairs + 117 blocks) x 8192 bins x 8 B)) = 427 streams: [0,427) [427,854) [854,1024)
-    per_stream = ((F + 4095) // 4096 + 7) * 4 * 8192 * 8 + ((F + 4095) // 4096) * 8192 * 8
-    chunk = (16384 << 20) // per_stream
-    assert 2 * chunk < S <= 3 * chunk
+    if kernels == "long-window":     # one window of 128 x 4096 frames per stream: rows 3.5 pairs x N + s1/s2 N complex values
+        per_stream = (7 * 524288 // 2 + 524288) * 8
+    else:                            # 124 windows x 4 pairs + 117 blocks of 8192 bins
+        per_stream = ((F + 4095) // 4096 + 7) * 4 * 8192 * 8 + ((F + 4095) // 4096) * 8192 * 8
+    chunk = min(S, ((int(scratch_mb) << 20) // per_stream) if scratch_mb else S)
+    assert (chunk < S) == bool(scratch_mb)
+    edges = sorted({0, S - 1} | {e for k in range(chunk, S, chunk) for e in (k - 1, k)})
     head, tail = 6000, 2000
-    for s in (0, chunk - 1, chunk, 2 * chunk - 1, 2 * chunk, S - 1):
+    for s in edges:
         xs = x[s, :head].cpu().numpy()
         assert np.array_equal(xs, oracle.synth_input(1, head, C, first_stream=s)[0])
         assert oracle.peak_rel_error(y[s, :head].cpu().numpy(), oracle.spatialize_f64(xs, h, lt, rt)) < TOL, s
@@ -64,6 +74,46 @@ def test_full_size_properties_cfg3(aw, oracle, monkeypatch):
     torch.cuda.synchronize()
     assert float((y2 + 0.5 * y).abs().max()) <= 2e-6 * float(y.abs().max())
     _energies_distinct(y, S)
+    del x, y, y2
+    torch.cuda.empty_cache()
+
+
+def test_full_size_properties_cfg3_14_channel_input(aw, oracle, golden_dir):
+    """The 14-channel-input reading of cfg 3 (bench.py's "secondary") at its full batch: InputLayout.detect(14) custom channels
+    through the committed parseHeSuViFormat text map, 28 convolutions per stream; the long-window kernels over two groups of
+    channels (8 + 6)."""
+    import torch
+    S, F, C, L = 1024, 480000, 14, 32768
+    ctx = aw.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    h = oracle.synth_hrir(14, L, seed=1234)
+    layout = aw.InputLayout.detect(C)
+    cmap = aw.HRIRChannelMap.parseHeSuViFormat(open(os.path.join(golden_dir, "hesuvi14_custom_map.txt")).read())
+    lt, rt = cmap.resolve(layout, 14)
+    assert (np.asarray(lt) >= 0).sum() + (np.asarray(rt) >= 0).sum() == 28
+    sp = aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=S, ctx=ctx)
+    sp.reserve(F)
+    x = torch.empty((S, F, C), dtype=torch.float32, device="cuda")
+    ctx.synth_fill(x.data_ptr(), S, F, C, seed=oracle.SYNTH_SEED)
+    y = torch.empty((S, F, 2), dtype=torch.float32, device="cuda")
+    sp.process_device(x.data_ptr(), y.data_ptr(), F)
+    torch.cuda.synchronize()
+    assert sp.info()["long_window_rows"] == 128
+    assert torch.isfinite(y).all()
+    head, tail = 6000, 2000
+    for s in (0, 511, S - 1):
+        xs = x[s, :head].cpu().numpy()
+        assert oracle.peak_rel_error(y[s, :head].cpu().numpy(), oracle.spatialize_f64(xs, h, lt, rt)) < TOL, s
+        tail_in = x[s, F - tail - (L - 1):].cpu().numpy()
+        assert oracle.peak_rel_error(y[s, F - tail:].cpu().numpy(), oracle.spatialize_f64(tail_in, h, lt, rt)[L - 1:]) < TOL, s
+    sp.reset()
+    x.mul_(-0.5)
+    y2 = torch.empty_like(y)
+    sp.process_device(x.data_ptr(), y2.data_ptr(), F)
+    torch.cuda.synchronize()
+    assert float((y2 + 0.5 * y).abs().max()) <= 2e-6 * float(y.abs().max())
+    _energies_distinct(y, S)
+    del x, y, y2
+    torch.cuda.empty_cache()
 
 
 def test_full_size_properties_cfg4(aw, oracle, golden_dir):
