@@ -316,13 +316,14 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
         sp->fwd_one_pair = sp->n_pairs > 4;
         if (const char *e = getenv("AW_PART_FWD")) sp->fwd_one_pair = atoi(e) == 1;
         if (const char *e = getenv("AW_PART_HERM")) sp->herm_ok = atoi(e) != 0;          // A/B: 0 stores the last pair's redundant half too
-        // long calls of this spatializer run on the long-window kernels (device/tile_lw.hpp) — chosen per call, see lw_choose()
-        if (const char *e = getenv("AW_LW")) sp->lw_mode = atoi(e);
-        if (n_in > 16) sp->lw_mode = 0;                                                  // up to eight channel pairs
-        if (sp->lw_mode != 0) {
-            sp->lw_tracks = hrir->tracks; sp->lw_n_tracks = hrir->n_tracks;
-            sp->lw_left.assign(left_track, left_track + n_in); sp->lw_right.assign(right_track, right_track + n_in);
-        }
+    }
+    // Long calls may run on the long-window kernels (device/tile_lw.hpp) whatever the path above — chosen per call, see lw_choose();
+    // they use the same history buffer.  AW_LW: 0 never, 32/64/128 force that window, unset = the measured policy.
+    if (const char *e = getenv("AW_LW")) sp->lw_mode = atoi(e);
+    if (n_in > 16) sp->lw_mode = 0;                                                      // up to eight channel pairs
+    if (sp->lw_mode != 0) {
+        sp->lw_tracks = hrir->tracks; sp->lw_n_tracks = hrir->n_tracks;
+        sp->lw_left.assign(left_track, left_track + n_in); sp->lw_right.assign(right_track, right_track + n_in);
     }
     std::vector<awk::cf2> tab, all;
     if (sp->fused2) {
@@ -476,7 +477,7 @@ int32_t aw_spatializer_kernel_time(aw_spatializer *sp, double *avg_ms, const cha
     }
     sp->pending.clear();
     if (avg_ms) *avg_ms = sp->kernel_launches ? sp->kernel_ms_sum / sp->kernel_launches : 0.0;
-    if (kernel_name) *kernel_name = sp->path == 0 ? (sp->fused2 ? awk::fused_ols2_kernel_name(sp->n_channels) : sp->fusedh ? awk::fused_olsh_kernel_name(sp->n_channels) : awk::fused_ols_kernel_name(sp->n_channels)) : (sp->last_lw_R ? "aw_lw_split_kernel + aw_lw_rows_kernel + aw_lw_merge_kernel" : sp->cmac_group ? "aw_part_forward_kernel + aw_part_cmac_kernel + aw_part_inverse_kernel" : "aw_part_forward_kernel + aw_part_march_kernel + aw_part_inverse_kernel");
+    if (kernel_name) *kernel_name = sp->last_lw_R ? "aw_lw_split_kernel + aw_lw_rows_kernel + aw_lw_merge_kernel" : sp->path == 0 ? (sp->fused2 ? awk::fused_ols2_kernel_name(sp->n_channels) : sp->fusedh ? awk::fused_olsh_kernel_name(sp->n_channels) : awk::fused_ols_kernel_name(sp->n_channels)) : (sp->cmac_group ? "aw_part_forward_kernel + aw_part_cmac_kernel + aw_part_inverse_kernel" : "aw_part_forward_kernel + aw_part_march_kernel + aw_part_inverse_kernel");
     const int n = sp->kernel_launches;
     sp->kernel_ms_sum = 0.0;
     sp->kernel_launches = 0;
@@ -661,8 +662,16 @@ static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, flo
 // partitioned kernels keep too, so both kernel sets serve the same spatializer and the choice is free per call).
 // Cost model (fabric bytes): the long-window kernels move 12 C + 24 bytes per WINDOW frame (input + rows
 // written, rows read + s1/s2 written, s1/s2 read + stereo out), the partitioned ones ~29 C bytes per OUTPUT frame.
+// Path-0 spatializers (HRIRs one fused window can hold): HRIR length from which the long-window kernels measure faster than
+// the fused 8192- / 16384-frame tiles on long calls (tools/lw_sweep.py, 128 streams x 10 s); 1 << 30 = never.
+static int lw_fused_crossover_taps(int channels) {
+    (void)channels;
+    return 1 << 30;
+}
+
 static int lw_choose(const aw_spatializer *sp, int64_t frames, bool for_reserve = false) {
-    if (sp->path != 1 || sp->lw_mode == 0 || sp->n_channels > 16) return 0;
+    if (sp->lw_mode == 0 || sp->n_channels > 16) return 0;
+    if (sp->path == 0 && sp->lw_mode < 0 && sp->taps < lw_fused_crossover_taps(sp->n_channels)) return 0;
     // calls inside what aw_spatializer_reserve() sized never build tables: only window lengths whose tables exist are candidates
     const bool existing_only = !for_reserve && frames <= sp->reserved_frames;
     auto have = [&](int R) { for (const auto &pl : sp->lw_plans) if (pl.R == R) return true; return false; };
@@ -679,7 +688,8 @@ static int lw_choose(const aw_spatializer *sp, int64_t frames, bool for_reserve 
         if (!best || cost < best_cost) { best = R; best_cost = cost; }
     }
     if (!best || sp->lw_mode > 0) return best;
-    const double part_cost = (double)frames * 29.0 * C;
+    // path 0: past the measured crossover (above) the long call only has to fill its windows; path 1: against the partitioned kernels
+    const double part_cost = sp->path == 0 ? 1.25 * (double)frames * (12.0 * C + 24.0) : (double)frames * 29.0 * C;
     const long long N = (long long)best * awk::kLwM, hop = N - sp->hist_len;
     const long long row_tiles = (long long)sp->n_streams * ((frames + hop - 1) / hop) * (best / 2);
     if (row_tiles < 128) return 0;                                       // too few tiles to fill the chip: the partitioned kernels' 4096-frame blocks
@@ -717,7 +727,8 @@ static LwScratch lw_scratch(const aw_spatializer *sp, int R, int64_t frames, siz
     const long long N = (long long)R * awk::kLwM, hop = N - sp->hist_len;
     const int real_last = sp->n_channels & 1;
     r.n_windows = (frames + hop - 1) / hop;
-    r.spec_per_sw = (long long)(sp->n_pairs - real_last) * N + (real_last ? N / 2 : 0);
+    const int n_pairs = (sp->n_channels + 1) / 2;                         // (a fused2 spatializer's n_pairs counts pseudo-pairs)
+    r.spec_per_sw = (long long)(n_pairs - real_last) * N + (real_last ? N / 2 : 0);
     r.per_stream = (size_t)r.n_windows * (size_t)(r.spec_per_sw + N);
     r.chunk = (long long)(budget_bytes / sizeof(awk::cf) / r.per_stream);
     const long long held_chunk = (long long)(held_elems / r.per_stream);       // see part_plan
@@ -745,7 +756,7 @@ static aw_status sp_process_longwin(aw_spatializer *sp, int R, const float *in, 
         p.hist = sp->d_hist[sp->hist_cur] + (size_t)s0 * sp->hist_len * sp->n_channels;
         p.hist_out = sp->d_hist[sp->hist_cur ^ 1] + (size_t)s0 * sp->hist_len * sp->n_channels;      // the tail carry rides along in the split kernel
         p.zeros = sp->ctx->d_zeros;
-        p.frames = frames; p.n_channels = sp->n_channels; p.n_pairs = sp->n_pairs; p.real_last = sp->n_channels & 1;
+        p.frames = frames; p.n_channels = sp->n_channels; p.n_pairs = (sp->n_channels + 1) / 2; p.real_last = sp->n_channels & 1;
         p.hist_len = sp->hist_len; p.hop = (int)(N - sp->hist_len); p.n_windows = (int)sc.n_windows;
         p.R = R; p.N = (int)N;
         p.spec = sp->d_spec; p.spec_per_sw = sc.spec_per_sw;
@@ -781,11 +792,12 @@ aw_status aw_spatializer_reserve(aw_spatializer *sp, int64_t max_frames) {
     if (!sp) return fail(AW_ERR_INVALID_ARGUMENT, "sp is NULL");
     if (max_frames <= 0) return fail(AW_ERR_INVALID_ARGUMENT, "max_frames must be positive");
     AW_HIP_TRY(hipSetDevice(sp->ctx->device));
-    if (sp->path == 1) {
+    const int lw_R_res = lw_choose(sp, max_frames, true);
+    if (sp->path == 1 || lw_R_res) {
         // shorter calls than max_frames may run on the partitioned kernels or on a smaller window: size for both kernel sets
-        const PartPlan pl = part_plan(sp, max_frames, part_budget(sp));
-        size_t need = pl.need;
-        const int lw_R = lw_choose(sp, max_frames, true);
+        size_t need = 0;
+        if (sp->path == 1) need = part_plan(sp, max_frames, part_budget(sp)).need;
+        const int lw_R = lw_R_res;
         if (lw_R) {
             const aw_spatializer::LwPlan *plan = nullptr;
             aw_status st = lw_get_plan(sp, lw_R, &plan);
@@ -812,12 +824,12 @@ aw_status aw_spatializer_process(aw_spatializer *sp, const float *in, float *out
     aw_status st = AW_OK;
     const int lw_R = lw_choose(sp, frames);
     sp->last_lw_R = lw_R;
-    if (sp->path == 0) st = sp_process_fused(sp, in, out, frames);
-    else if (lw_R) st = sp_process_longwin(sp, lw_R, in, out, frames);
+    if (lw_R) st = sp_process_longwin(sp, lw_R, in, out, frames);
+    else if (sp->path == 0) st = sp_process_fused(sp, in, out, frames);
     else st = sp_process_partitioned(sp, in, out, frames);
     if (st != AW_OK) return st;
     // carry the convolution tail: next call's history = last hist_len frames of (history ++ input)
-    if (!(sp->path == 1 && lw_R)) {      // (the long-window split kernel has written it on the way)
+    if (!lw_R) {      // (the long-window split kernel has written it on the way)
         float *h_old = sp->d_hist[sp->hist_cur], *h_new = sp->d_hist[sp->hist_cur ^ 1];
         SpStageTimer tm(sp);
         if (sp->profiling) tm.begin();
