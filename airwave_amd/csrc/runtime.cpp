@@ -664,9 +664,21 @@ static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, flo
 // written, rows read + s1/s2 written, s1/s2 read + stereo out), the partitioned ones ~29 C bytes per OUTPUT frame.
 // Path-0 spatializers (HRIRs one fused window can hold): HRIR length from which the long-window kernels measure faster than
 // the fused 8192- / 16384-frame tiles on long calls (tools/lw_sweep.py, 128 streams x 10 s); 1 << 30 = never.
+//   G frames/s fused / long-window:  C=1  8640 taps 139 / 99, 12288: 80 / 107;   C=2  8640: 94 / 81, 12288: 55 / 81;   C=3  8640: 69 / 61, 12288: 41 / 61;
+//   C=4  4320: 70 / 55, 6145: 41 / 54;   C=5  6145: 51 / 45, 8640: 41 / 45;   C=6  4320: 47 / 40, 6145: 31 / 41;   C=7  4320: 40 / 37, 6145: 35 / 37, 8640: 29 / 36
+//   (512 streams: 6145: 39 / 42);   C=8  4320: 40 / 33, 6145: 25 / 34;   9-14 channels 4320: 30-20 / 26-18, 6145: 19-13 / 26-18;   C=16  4320: 16.4 / 16.2
+// (profiles/round3_v1/lw_sweep.txt).  The long-window kernels' rate does not depend on the HRIR length; the fused tiles' hop shrinks with it.
 static int lw_fused_crossover_taps(int channels) {
-    (void)channels;
-    return 1 << 30;
+    switch (channels) {
+        case 1: return 10500;
+        case 2: case 3: return 9800;
+        case 4: return 5300;
+        case 5: return 7500;
+        case 6: case 8: return 5100;
+        case 7: return 5500;
+        case 16: return 4400;
+        default: return 5300;
+    }
 }
 
 static int lw_choose(const aw_spatializer *sp, int64_t frames, bool for_reserve = false) {
@@ -692,7 +704,7 @@ static int lw_choose(const aw_spatializer *sp, int64_t frames, bool for_reserve 
     const double part_cost = sp->path == 0 ? 1.25 * (double)frames * (12.0 * C + 24.0) : (double)frames * 29.0 * C;
     const long long N = (long long)best * awk::kLwM, hop = N - sp->hist_len;
     const long long row_tiles = (long long)sp->n_streams * ((frames + hop - 1) / hop) * (best / 2);
-    if (row_tiles < 128) return 0;                                       // too few tiles to fill the chip: the partitioned kernels' 4096-frame blocks
+    if (row_tiles < 32) return 0;        // (measured down to ONE stream x 10 s, 64 row tiles: 7 channels x 32768 taps 8.2 against 3.9 G frames/s partitioned)
     return best_cost < part_cost ? best : 0;
 }
 
