@@ -23,13 +23,34 @@ public enum HIPEqualizerError: Error {
     case parse(String)
 }
 
+/// One sample-rate-specific processor (`aw_eq`).  Destroyed when the LAST reference goes away — the control side's or the
+/// render thread's snapshot — and only ever on the control thread (see `retire`).  Retains the context `aw_eq_destroy` uses.
+final class EqualizerBox {
+    let handle: OpaquePointer
+    let sampleRate: Double
+    let context: HIPContext
+    init(_ h: OpaquePointer, sampleRate: Double, context: HIPContext) { handle = h; self.sampleRate = sampleRate; self.context = context }
+    deinit { aw_eq_destroy(handle) }
+}
+
 public final class HIPEqualizerEffect /* : AudioEqualizerEffect */ {
     private let context: HIPContext
-    private var processor: OpaquePointer?
-    private var sampleRate: Double = 0
+    // The publication scheme of Airwave/EqualizerRuntimeEffect.swift:6-8,57-61: the control thread publishes a processor under
+    // `processorLock`, the render thread takes one try-lock snapshot per callback into `audioThreadProcessor` and otherwise keeps
+    // the one it has — it can never observe a processor that `prepare` is tearing down.
+    private let processorLock = TryLock<EqualizerBox?>(initialState: nil)
+    private var controlProcessor: EqualizerBox?                  // control thread only
+    private var audioThreadProcessor: EqualizerBox?              // render thread only
+    // `aw_eq_destroy` frees device memory and synchronises a stream: never on the render thread.  A processor the render
+    // thread lets go of is parked (try-lock) and destroyed by the next control-side call, as in HIPSpatialEffect.
+    private let retiredLock = TryLock<[EqualizerBox]>(initialState: [])
+    private var awaitingRetirement: [EqualizerBox] = []          // render thread only; capacity reserved in init
 
-    public init(context: HIPContext) { self.context = context }
-    deinit { if let p = processor { aw_eq_destroy(p) } }
+    public init(context: HIPContext) {
+        self.context = context
+        awaitingRetirement.reserveCapacity(8)
+        retiredLock.withLock { $0.reserveCapacity(8) }
+    }
 
     /// EqualizerAPOParser.parse(data:filename:) -> definition handle (caller destroys with aw_eq_definition_destroy).
     public static func parse(data: Data) throws -> OpaquePointer {
@@ -52,50 +73,88 @@ public final class HIPEqualizerEffect /* : AudioEqualizerEffect */ {
     /// AudioEqualizerEffect.prepare(definition:sampleRate:)   EqualizerRuntimeEffect.swift:10-34
     public func prepare(preampDB: Double?, filters: [HIPEqualizerFilter], sampleRate: Double) throws {
         guard sampleRate.isFinite, sampleRate > 0 else { throw HIPEqualizerError.invalidSampleRate }
-        if processor == nil || self.sampleRate != sampleRate {
+        let box: EqualizerBox
+        if let current = controlProcessor, current.sampleRate == sampleRate {
+            box = current
+        } else {
             var p: OpaquePointer?
             guard aw_eq_create(context.handle, sampleRate, 1, 4096, &p) == AW_OK, let created = p else {
                 throw HIPEqualizerError.unavailable(String(cString: aw_last_error_message()))
             }
-            if let old = processor { aw_eq_destroy(old) }
-            processor = created
-            self.sampleRate = sampleRate
+            box = EqualizerBox(created, sampleRate: sampleRate, context: context)
+            controlProcessor = box
+            // Publish.  The previous processor is NOT destroyed here: the render thread may be inside `process` with it; it is
+            // released by the render thread's next successful snapshot and destroyed by a later control-side call.
+            processorLock.withLock { $0 = box }
         }
-        try publish(preampDB: preampDB, filters: filters)
+        drainRetiredProcessors()
+        try publish(box, preampDB: preampDB, filters: filters)
     }
 
     /// AudioEqualizerEffect.setTarget(definition:)   EqualizerRuntimeEffect.swift:36-48
     public func setTarget(preampDB: Double?, filters: [HIPEqualizerFilter]) throws {
-        guard processor != nil else {
+        guard let box = controlProcessor else {
             throw HIPEqualizerError.unavailable("Equalizer has not been prepared for an output.")
         }
-        try publish(preampDB: preampDB, filters: filters)
+        drainRetiredProcessors()
+        try publish(box, preampDB: preampDB, filters: filters)
     }
 
-    private func publish(preampDB: Double?, filters: [HIPEqualizerFilter]) throws {
-        guard let p = processor else { return }
+    /// `aw_eq_set_target` / `aw_eq_drain_retired` take the processor's own publication locks, `aw_eq_process_planar` only tries
+    /// them (ParametricEqualizerProcessor.swift:322,342,380,393): safe against a concurrent `process` on the same handle.
+    private func publish(_ box: EqualizerBox, preampDB: Double?, filters: [HIPEqualizerFilter]) throws {
         let def = preampDB.flatMap { makeDefinition(preampDB: $0, filters: filters) }   // nil = unity
         defer { if let d = def { aw_eq_definition_destroy(d) } }
-        let st = aw_eq_set_target(p, def)
+        let st = aw_eq_set_target(box.handle, def)
         if st != AW_OK {                                           // :27-33: fall back to unity, then report
             let reason = String(cString: aw_last_error_message())
-            _ = aw_eq_set_target(p, nil)
-            _ = aw_eq_drain_retired(p)
+            _ = aw_eq_set_target(box.handle, nil)
+            _ = aw_eq_drain_retired(box.handle)
             throw st == AW_ERR_EQ_INVALID_SAMPLE_RATE ? HIPEqualizerError.invalidSampleRate
                                                       : HIPEqualizerError.invalidFilter(reason: reason)
         }
-        _ = aw_eq_drain_retired(p)
+        _ = aw_eq_drain_retired(box.handle)
+    }
+
+    /// Control thread: destroys the processors the render thread has let go of (their deinit runs here, not in `process`).
+    public func drainRetiredProcessors() {
+        let dead = retiredLock.withLock { list -> [EqualizerBox] in let d = list; list.removeAll(keepingCapacity: true); return d }
+        _ = dead
     }
 
     /// StereoAudioProcessing.process   EqualizerRuntimeEffect.swift:50-78
     public func process(inputLeft: UnsafePointer<Float>, inputRight: UnsafePointer<Float>?,
                         outputLeft: UnsafeMutablePointer<Float>, outputRight: UnsafeMutablePointer<Float>,
                         frameCount: Int) {
+        var processor = audioThreadProcessor
+        enum Read { case available(EqualizerBox?) }
+        if let read = processorLock.withLockIfAvailable({ Read.available($0) }) {      // one non-blocking snapshot attempt
+            if case .available(let published) = read {
+                if let old = audioThreadProcessor, old !== published { retire(old) }
+                processor = published
+                audioThreadProcessor = published
+            }
+        }
+        if !awaitingRetirement.isEmpty { flushAwaitingRetirement() }
         guard let p = processor,
-              aw_eq_process_planar(p, inputLeft, inputRight, outputLeft, outputRight, Int32(frameCount)) == AW_OK else {
+              aw_eq_process_planar(p.handle, inputLeft, inputRight, outputLeft, outputRight, Int32(frameCount)) == AW_OK else {
             memcpy(outputLeft, inputLeft, frameCount * MemoryLayout<Float>.size)
             memcpy(outputRight, inputRight ?? inputLeft, frameCount * MemoryLayout<Float>.size)
             return
         }
+    }
+
+    /// Render thread: hand a processor over for destruction without ever blocking or freeing here.
+    private func retire(_ box: EqualizerBox) {
+        awaitingRetirement.append(box)
+        flushAwaitingRetirement()
+    }
+
+    private func flushAwaitingRetirement() {
+        let moved: Bool? = retiredLock.withLockIfAvailable { list in
+            for b in awaitingRetirement { list.append(b) }
+            return true
+        }
+        if moved != nil { awaitingRetirement.removeAll(keepingCapacity: true) }
     }
 }

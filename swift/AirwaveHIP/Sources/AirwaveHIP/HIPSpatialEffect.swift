@@ -7,7 +7,6 @@
 //  (call it off the render thread, as the reference does) and reports `HRIRActivationResult`.
 
 import Foundation
-import os
 import CAirwaveHIP
 
 public enum HIPActivationResult: Equatable {
@@ -28,9 +27,12 @@ public final class HIPContext {
 /// One activated renderer network.  Immutable once published; the C handle is destroyed when the LAST reference goes
 /// away — the control thread's or the render thread's snapshot, whichever drops it later — exactly the lifetime rule of
 /// `HRIRManager.RendererState` (Airwave/HRIRManager.swift:118-131), which ARC keeps alive while `audioThreadState` holds it.
+/// The box RETAINS the context: `aw_spatializer_destroy` dereferences it (device, stream), and boxes can outlive the
+/// effect's own `context` property during teardown (stored properties are released in declaration order).
 final class SpatializerBox {
     let handle: OpaquePointer
-    init(_ h: OpaquePointer) { handle = h }
+    let context: HIPContext
+    init(_ h: OpaquePointer, context: HIPContext) { handle = h; self.context = context }
     deinit { aw_spatializer_destroy(handle) }
 }
 
@@ -38,13 +40,13 @@ public final class HIPSpatialEffect /* : AudioSpatialEffect */ {
     private let context: HIPContext
     // Writers publish immutable state under one lock; the render thread makes one non-blocking snapshot attempt per
     // callback and otherwise keeps the state it already has (HRIRManager.swift:133-147, 539-548).
-    private let stateLock = OSAllocatedUnfairLock<SpatializerBox?>(initialState: nil)
-    nonisolated(unsafe) private var audioThreadState: SpatializerBox?      // touched by the render thread only
+    private let stateLock = TryLock<SpatializerBox?>(initialState: nil)      // TryLock.swift: pthread try-lock, Linux and Darwin
+    private var audioThreadState: SpatializerBox?                            // touched by the render thread only
     // Destroying a handle frees device memory and synchronises a HIP stream: never on the render thread.  A state the
     // render thread lets go of is parked here (try-lock; kept one more callback under contention) and destroyed by the
     // next control-side call — the retirement scheme of ParametricEqualizerProcessor (ParametricEqualizerProcessor.swift:380-406).
-    private let retiredLock = OSAllocatedUnfairLock<[SpatializerBox]>(initialState: [])
-    nonisolated(unsafe) private var awaitingRetirement: [SpatializerBox] = []   // render thread only; capacity reserved in init
+    private let retiredLock = TryLock<[SpatializerBox]>(initialState: [])
+    private var awaitingRetirement: [SpatializerBox] = []                    // render thread only; capacity reserved in init
 
     public init(context: HIPContext) {
         self.context = context
@@ -70,8 +72,10 @@ public final class HIPSpatialEffect /* : AudioSpatialEffect */ {
         guard status == AW_OK, let sp = created else {
             return .failure("Failed to activate preset: \(lastError())")   // HRIRManager.swift:441
         }
-        _ = aw_spatializer_reserve(sp, Int64(maxFramesPerCallback))         // process never allocates afterwards
-        let fresh = SpatializerBox(sp)
+        let fresh = SpatializerBox(sp, context: context)
+        guard aw_spatializer_reserve(sp, Int64(maxFramesPerCallback)) == AW_OK else {      // process never allocates afterwards
+            return .failure("Failed to activate preset: \(lastError())")                  // (`fresh` destroys the handle here, on the control thread)
+        }
         // Publish.  The previous box is NOT destroyed here: the render thread may be inside `process` with it; it dies
         // when the render thread's next successful snapshot replaces `audioThreadState` (deferred destruction by ARC).
         stateLock.withLock { $0 = fresh }
@@ -86,7 +90,7 @@ public final class HIPSpatialEffect /* : AudioSpatialEffect */ {
 
     /// Control thread: destroys the states the render thread has let go of (their deinit runs here, not in `process`).
     public func drainRetiredStates() {
-        let dead = retiredLock.withLock { list -> [SpatializerBox] in let d = list; list.removeAll(); return d }
+        let dead = retiredLock.withLock { list -> [SpatializerBox] in let d = list; list.removeAll(keepingCapacity: true); return d }
         _ = dead          // the boxes die at the end of this scope, on the calling (control) thread
     }
 

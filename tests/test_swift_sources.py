@@ -34,5 +34,38 @@ def test_publication_defers_destruction():
     src = open(SRC).read()
     act = _body(src, "public func activatePreset(")
     assert "stateLock.withLock" in act and "aw_spatializer_destroy" not in act and "aw_spatializer_reserve" in act
-    assert src.count("aw_spatializer_destroy") == 1            # only in SpatializerBox.deinit
+    assert src.count("aw_spatializer_destroy(") == 1           # the only call: SpatializerBox.deinit
     assert "deinit { aw_spatializer_destroy(handle) }" in src
+
+
+EQ = os.path.join(ROOT, "swift", "AirwaveHIP", "Sources", "AirwaveHIP", "HIPEqualizerEffect.swift")
+LOCK = os.path.join(ROOT, "swift", "AirwaveHIP", "Sources", "AirwaveHIP", "TryLock.swift")
+
+
+def test_equalizer_effect_publishes_behind_a_try_lock_and_retires_processors():
+    """EqualizerRuntimeEffect.swift:6-8,57-61: `prepare` publishes a new processor under the lock and never destroys the one the
+    render thread may be using; `process` takes a try-lock snapshot, never blocks, never destroys."""
+    src = open(EQ).read()
+    proc = _body(src, "public func process(")
+    assert "processorLock.withLockIfAvailable" in proc and not re.search(r"processorLock\.withLock\s*\{", proc)
+    assert "aw_eq_destroy" not in proc and "audioThreadProcessor" in proc
+    prep = _body(src, "public func prepare(")
+    assert "processorLock.withLock" in prep and "aw_eq_destroy" not in prep
+    assert src.count("aw_eq_destroy(") == 1 and "deinit { aw_eq_destroy(handle) }" in src       # the only call: EqualizerBox.deinit
+    for fn in ("private func retire(", "private func flushAwaitingRetirement("):
+        b = _body(src, fn)
+        assert not re.search(r"retiredLock\.withLock\s*\{", b) and "aw_eq_destroy" not in b
+    assert "withLockIfAvailable" in _body(src, "private func flushAwaitingRetirement(")
+
+
+def test_boxes_retain_their_context_and_the_package_builds_where_the_library_exists():
+    """A handle's destroy call dereferences its context, so the boxes that own handles keep the context alive (teardown order);
+    the try-lock is pthread based — `import os` / OSAllocatedUnfairLock exist on Darwin only, the ROCm library on Linux only."""
+    sp, eq, lock = open(SRC).read(), open(EQ).read(), open(LOCK).read()
+    assert "let context: HIPContext" in _body(sp, "final class SpatializerBox") and "let context: HIPContext" in _body(eq, "final class EqualizerBox")
+    for src in (sp, eq):
+        assert "import os" not in src and "OSAllocatedUnfairLock" not in src and "nonisolated(unsafe)" not in src
+        assert "removeAll()" not in src                        # keepingCapacity: the render thread's later append must not allocate
+    assert "pthread_mutex_trylock" in lock and "canImport(Glibc)" in lock
+    act = _body(sp, "public func activatePreset(")
+    assert re.search(r"guard aw_spatializer_reserve\(.*== AW_OK else", act)       # a failed reserve is an activation failure
