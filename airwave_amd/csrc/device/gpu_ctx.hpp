@@ -216,62 +216,6 @@ struct GpuCtx {
         asm volatile("" : "+v"(v.x), "+v"(v.y));
         return v;
     }
-    // Tile flags of the sibling-workgroup kernels (tile_olsh.hpp): the even-bin workgroup publishes its stores, the
-    // odd-bin one (dispatched later: higher workgroup id) waits for them.  Agent scope: siblings may sit on different CUs.
-    // AW_SIB_SYNC: 2 = agent-scope release/acquire fences (portable, but on gfx950 they write back / invalidate the whole L2:
-    // measured 7.5 ms per cfg-2 launch), 1 = same-XCD protocol (siblings share one L2: stores are complete at L2 after
-    // vmcnt(0), the flag is an L2 atomic, the sibling reads the output around its L1), 0 = no synchronisation (timing only).
-#ifndef AW_SIB_SYNC
-#define AW_SIB_SYNC 1
-#endif
-    __device__ __forceinline__ void flag_release(int *flag, int epoch) const {
-#if AW_SIB_SYNC == 2
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-#elif AW_SIB_SYNC == 1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's output stores are acknowledged by the L2
-        __syncthreads();
-        if (threadIdx.x == 0) (void)__hip_atomic_exchange(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-        (void)flag; (void)epoch;
-#endif
-    }
-    // Every spin is bounded (~1 s): a sibling that never arrives sets the launch's error word instead of hanging the GPU;
-    // the host reports it at the next call (runtime.cpp).
-    __device__ __forceinline__ void flag_acquire(int *flag, int epoch, int *error_word) const {
-#if AW_SIB_SYNC == 2
-        if (threadIdx.x == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(4);
-            if (spins >= (1 << 22)) (void)__hip_atomic_exchange(error_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#elif AW_SIB_SYNC == 1
-        if (threadIdx.x == 0) {
-            int spins = 0;
-            while (__hip_atomic_fetch_add(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(4);
-            if (spins >= (1 << 22)) (void)__hip_atomic_exchange(error_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-#else
-        (void)flag; (void)epoch; (void)error_word;
-#endif
-    }
-    // the odd-bin sibling's read of what its partner stored: around the L1 (sc0), from the XCD's L2
-    __device__ __forceinline__ cf ld_out(const float *p) const {
-#if AW_SIB_SYNC == 1
-        // a relaxed agent-scope atomic load: hipcc emits a cache-bypassing global_load_dwordx2 and tracks its vmcnt
-        const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cf r;
-        r.x = __uint_as_float((unsigned)v);
-        r.y = __uint_as_float((unsigned)(v >> 32));
-        return r;
-#else
-        return *reinterpret_cast<const cf *>(p);
-#endif
-    }
     // Exchanges inside one wave need no s_barrier: a wave's LDS instructions execute in issue
     // order.  The fences only stop the compiler from moving LDS accesses across the exchange.
     __device__ __forceinline__ void wave_sync() const {

@@ -43,21 +43,6 @@ __global__ void __launch_bounds__(kThreads) aw_fused_ols_kernel(TileParams p, lo
 }
 
 
-// Sibling form (tile_olsh.hpp): workgroups 2s and 2s + 1 of an XCD group take the even and the odd bins of the same
-// tiles.  blockIdx = 8 * slot + xcd, so the odd-bin sibling has the higher id and is dispatched after its partner.
-template <int CS, int NP, bool INTERIOR>
-__global__ void __launch_bounds__(kThreads, 4) aw_fused_olsq_kernel(TileParams p, long long n_tiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
-    const long long g = gridDim.x, b = blockIdx.x;          // g is a multiple of 16
-    const long long xcd = b % 8, slot = b / 8;
-    const long long pairs_per_xcd = g / 16;
-    const long long q8 = n_tiles / 8, r8 = n_tiles % 8;
-    const long long lo = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const long long hi = lo + (xcd < r8 ? q8 + 1 : q8);
-    tiles_fused_olsq<GpuCtx, CS, NP, INTERIOR>(ctx, p, lo + slot / 2, pairs_per_xcd, hi, (int)(slot & 1));
-}
-
 // Windows [tile_lo, tile_hi) of every stream lie inside the call's input (INTERIOR), the others touch the
 // history or the zero page.  p.tile_lo/hi carry the window range here.
 #ifndef AW_FWD_RUNS
@@ -170,7 +155,6 @@ hipError_t prepare_kernels(LaunchCfg *cfg) {
         // workgroups would leave groups without a workgroup and their tiles uncomputed
         if (g_persistent_wgs < 8) g_persistent_wgs = 8;
         if (const char *e3 = getenv("AW_WIDE_TWO_PASS")) cfg->wide_two_pass = atoi(e3) != 0;      // A/B: 1 = two passes, 0 = run-time loop
-        if (const char *e4 = getenv("AW_OLSH_WGS_PER_CU")) cfg->olsh_wgs_per_cu = atoi(e4) > 0 ? atoi(e4) : 2;
         cfg->debug_occupancy = getenv("AW_DEBUG_OCCUPANCY") != nullptr;
         if (const char *e5 = getenv("AW_STAMP_THREAD")) cfg->stamp_thread = atoi(e5);
         if (const char *e6 = getenv("AW_EQ_EAR_SPLIT")) cfg->eq_ear_split = atoi(e6);
@@ -208,24 +192,6 @@ hipError_t prepare_kernels(LaunchCfg *cfg) {
 #undef AW_SET_GENACC
     AW_FOR_EACH_GEN(AW_SET_GEN)
     AW_FOR_EACH_BVEC(AW_SET_BVEC)
-#define AW_SET_Q(CS, NP)                                                                                \
-    if (e == hipSuccess)                                                                                \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_olsq_kernel<CS, NP, true>),    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kHLdsBytes);
-#define AW_SET_QGEN(NP)                                                                                 \
-    if (e == hipSuccess)                                                                                \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_olsq_kernel<0, NP, false>),    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kHLdsBytes);
-#define AW_SET_QB(CS, NP)                                                                               \
-    if (e == hipSuccess)                                                                                \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_olsq_kernel<CS, NP, false>),   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kHLdsBytes);
-    AW_FOR_EACH_VEC(AW_SET_Q)
-    AW_FOR_EACH_GEN(AW_SET_QGEN)
-    AW_FOR_EACH_BVEC(AW_SET_QB)
-#undef AW_SET_Q
-#undef AW_SET_QGEN
-#undef AW_SET_QB
 #define AW_SET_VEC2(CS, NB)                                                                          \
     if (e == hipSuccess)                                                                             \
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_fused_ols2_kernel<CS, NB, true>), \
@@ -399,122 +365,6 @@ hipError_t launch_fused_ols(const TileParams &p_in, int n_streams, hipStream_t s
         if (ev1 && !dom_int) (void)hipEventRecord(ev1, stream);
     }
     return hipGetLastError();
-}
-
-// Placement probe for the sibling kernels: their cheap flag protocol needs workgroups b and b + 8 on one XCD (one L2).
-// HIP does not promise that, so it is measured, with the launch shape the kernels use, before they are enabled.
-__global__ void __launch_bounds__(kThreads, 4) aw_xcc_probe_kernel(int *out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (threadIdx.x == 0) {
-        smem[0] = 1;                                                    // the LDS allocation is part of the launch shape
-        out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 0xf);   // HW_REG_XCC_ID[3:0]
-    }
-}
-
-hipError_t probe_sibling_placement(hipStream_t stream, int persistent_wgs, bool *ok) {
-    *ok = false;
-    const int grid = 2 * (persistent_wgs >= 8 ? persistent_wgs : 256) / 16 * 16;
-    if (grid < 16) return hipSuccess;
-    int *d = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d), grid * sizeof(int));
-    if (e != hipSuccess) return e;
-    std::vector<int> h((size_t)grid, -1);
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_xcc_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kHLdsBytes);
-    for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) {
-        hipLaunchKernelGGL(aw_xcc_probe_kernel, dim3((unsigned)grid), dim3(kThreads), kHLdsBytes, stream, d);
-        e = hipMemcpyAsync(h.data(), d, grid * sizeof(int), hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) break;
-        bool good = true;
-        for (int b = 8; b < grid; ++b) good = good && h[b] == h[b - 8] && h[b] >= 0;
-        if (rep == 0) *ok = good; else *ok = *ok && good;
-    }
-    (void)hipFree(d);
-    return e;
-}
-
-// The same split for the sibling-workgroup kernels (tile_olsh.hpp): grid = 2 workgroups per CU.
-const char *fused_olsh_kernel_name(int C) {
-    switch (C) {
-        case 2: return "aw_fused_olsq_kernel<2, 1, true>";
-        case 4: return "aw_fused_olsq_kernel<4, 2, true>";
-        case 6: return "aw_fused_olsq_kernel<6, 3, true>";
-        case 7: return "aw_fused_olsq_kernel<7, 4, true>";
-        case 8: return "aw_fused_olsq_kernel<8, 4, true>";
-        case 14: return "aw_fused_olsq_kernel<14, 0, true>";
-        case 12: return "aw_fused_olsq_kernel<12, 0, true>";
-        case 16: return "aw_fused_olsq_kernel<16, 0, true>";
-        default: return "aw_fused_olsq_kernel<0, NP, false>";
-    }
-}
-
-
-hipError_t launch_fused_olsh(const TileParams &p_in, int n_streams, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
-                             long long *dominant_tiles) {
-    TileParams p = p_in;
-    long long lo = (p.hist_len + p.hop - 1) / p.hop;
-    const long long usable = p.frames - ((p.n_channels % 4 != 0 && p.n_channels != 2) ? 1 : 0);
-    long long hi = (usable - kN + p.hist_len) >= 0 ? (usable - kN + p.hist_len) / p.hop + 1 : 0;
-    if (hi > p.tiles_per_stream) hi = p.tiles_per_stream;
-    if (hi < lo) hi = lo;
-    if (lo > p.tiles_per_stream) { lo = p.tiles_per_stream; hi = lo; }
-    if (!has_vec_variant(p.n_channels)) { lo = 0; hi = 0; }
-    p.tile_lo = (int)lo; p.tile_hi = (int)hi;
-    const long long n_int = (long long)n_streams * (hi - lo);
-    const long long n_bnd = (long long)n_streams * (p.tiles_per_stream - (hi - lo));
-    if (n_int > 0x7fffffffLL || n_bnd > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (p.debug_occupancy) {
-        int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&aw_fused_olsq_kernel<8, 4, true>), kThreads, kHLdsBytes);
-        hipFuncAttributes fa{};
-        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&aw_fused_olsq_kernel<8, 4, true>));
-        fprintf(stderr, "[aw] olsq<8,4,true>: %d workgroups per CU (regs %d, static LDS %zu, scratch %zu)\n", nb, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes);
-    }
-    const long long max_wgs = (long long)(p.persistent_wgs >= 8 ? p.persistent_wgs : 256) * (p.olsh_wgs_per_cu > 0 ? p.olsh_wgs_per_cu : 2);
-    const dim3 block(kThreads);
-    const bool dom_int = n_int > 0;
-    if (dominant_tiles) *dominant_tiles = dom_int ? n_int : n_bnd;
-    if (!p.flags) return hipErrorInvalidValue;
-    {                                    // sibling workgroups: grid = 2 x (tile slots rounded up to a multiple of 8)
-        auto sib_grid = [&](long long n) {
-            long long slots = n < max_wgs / 2 ? n : max_wgs / 2;
-            slots = (slots + 7) / 8 * 8;
-            return dim3((unsigned)(2 * slots));
-        };
-        if (n_int > 0) {
-            const dim3 grid = sib_grid(n_int);
-            if (ev0) (void)hipEventRecord(ev0, stream);
-            switch (p.n_channels) {
-#define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_fused_olsq_kernel<CS, NP, true>), grid, block, kHLdsBytes, stream, p, n_int); break;
-                AW_FOR_EACH_VEC(AW_CASE)
-#undef AW_CASE
-                default: break;
-            }
-            if (ev1) (void)hipEventRecord(ev1, stream);
-        }
-        if (n_bnd > 0) {
-            p.epoch += 1;
-            const dim3 grid = sib_grid(n_bnd);
-            if (ev0 && !dom_int) (void)hipEventRecord(ev0, stream);
-            bool done = false;
-            switch (p.n_channels) {
-#define AW_CASE(CS, NP) case CS: hipLaunchKernelGGL((aw_fused_olsq_kernel<CS, NP, false>), grid, block, kHLdsBytes, stream, p, n_bnd); done = true; break;
-                AW_FOR_EACH_BVEC(AW_CASE)
-#undef AW_CASE
-                default: break;
-            }
-            if (!done) {
-                switch (p.n_pairs <= 4 ? p.n_pairs : 0) {
-#define AW_CASE(NP) case NP: hipLaunchKernelGGL((aw_fused_olsq_kernel<0, NP, false>), grid, block, kHLdsBytes, stream, p, n_bnd); break;
-                    AW_FOR_EACH_GEN(AW_CASE)
-#undef AW_CASE
-                    default: break;
-                }
-            }
-            if (ev1 && !dom_int) (void)hipEventRecord(ev1, stream);
-        }
-        return hipGetLastError();
-    }
 }
 
 // 16384-frame windows: same interior / boundary split, in real frames.

@@ -5,7 +5,6 @@
 #include <cstdint>
 
 #include "tile_ols2.hpp"
-#include "tile_olsh.hpp"
 #include "tile_march.hpp"
 #include "tile_lw.hpp"
 
@@ -25,12 +24,6 @@ struct StageTimer {
 hipError_t launch_fused_ols(const TileParams &p, int n_streams, hipStream_t stream, hipEvent_t ev0 = nullptr,
                             hipEvent_t ev1 = nullptr, long long *dominant_tiles = nullptr);
 const char *fused_ols_kernel_name(int n_channels);
-// the two-workgroups-per-CU cut of the 8192-frame tile (tile_olsh.hpp); same TileParams as launch_fused_ols
-hipError_t launch_fused_olsh(const TileParams &p, int n_streams, hipStream_t stream, hipEvent_t ev0 = nullptr,
-                             hipEvent_t ev1 = nullptr, long long *dominant_tiles = nullptr);
-const char *fused_olsh_kernel_name(int n_channels);
-// measures whether workgroups b and b + 8 of the sibling kernels' launch shape share an XCD (two probe launches, synchronous)
-hipError_t probe_sibling_placement(hipStream_t stream, int persistent_wgs, bool *ok);
 // 16384-frame windows (tile_ols2.hpp); p.hop / p.hist_len in real frames, p.tab = cf4 tables, p.n_pairs = pseudo-pairs.
 hipError_t launch_fused_ols2(const TileParams &p, int n_streams, hipStream_t stream, hipEvent_t ev0 = nullptr,
                              hipEvent_t ev1 = nullptr, long long *dominant_tiles = nullptr);
@@ -67,7 +60,6 @@ struct LaunchCfg {
     int cus = 256;                // compute units of the context's device
     int persistent_wgs = 256;     // grid of the persistent tile kernels (AW_PERSISTENT_WGS; >= 8: the kernels deal tiles to 8 XCD groups)
     int wide_two_pass = 2;        // 10/12/14 channels: 2 = one pass over two eight-channel groups (16: two passes), 1 = two compile-time passes (AW_WIDE_TWO_PASS=1), 0 = the run-time-loop kernels (AW_WIDE_TWO_PASS=0)
-    int olsh_wgs_per_cu = 2;      // sibling-workgroup kernels (AW_OLSH_WGS_PER_CU)
     int debug_occupancy = 0;      // AW_DEBUG_OCCUPANCY
     int stamp_thread = 0;         // AW_STAMP_THREAD (diagnostic builds)
     int eq_ear_split = -1;        // AW_EQ_EAR_SPLIT: -1 automatic, 0 / 1 forced

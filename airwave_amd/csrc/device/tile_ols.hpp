@@ -95,16 +95,12 @@ struct TileParams {
     int first_valid;        // first window position that is stored (N - hop)
     int persistent_wgs;     // grid of the persistent kernels (LaunchCfg, from the context); 0 = 256
     int wide_two_pass;      // LaunchCfg::wide_two_pass
-    int olsh_wgs_per_cu;    // LaunchCfg::olsh_wgs_per_cu
     int debug_occupancy;    // LaunchCfg::debug_occupancy
     int ch_base;            // second pass of a wide layout: `in`, `hist` and `tab` are shifted by this many channels (8); 0 otherwise
     int fwd_one_pair;       // forward kernel form: 1 = one channel pair per workgroup (two workgroups per CU), 0 = all pairs in one workgroup
     int herm_last;          // odd channel count: the last pair's input is real, its spectrum Hermitian — rows 9..15 are neither stored nor read
     int stagger;            // tuning: waves 4-7 idle this many 64-cycle slots after each barrier (phase offset)
     unsigned long long *dbg; // diagnostic builds only (AW_STAMPS): [workgroup][16] s_memtime stamps of wave 0
-    // sibling-workgroup kernels (tile_olsh.hpp) only:
-    int *flags;             // [tiles of the launch]: set to `epoch` by the even-bin workgroup once its output is stored; flags[-1] = error word
-    int epoch;              // launch sequence number of this spatializer (flags are never reset)
 };
 constexpr int kStamps = 32;
 

@@ -293,11 +293,6 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
         sp->n_pairs = (2 * n_in + 1) / 2;                            // pseudo-pairs of the half-rate 2C-channel view
     } else if (fits1 && !force_partitioned) {
         sp->path = 0;
-        if (const char *e = getenv("AW_KERNEL_H")) sp->fusedh = atoi(e) == 2 ? 2 : 0;     // experimental sibling-workgroup kernels (tile_olsh.hpp)
-        if (sp->fusedh) {           // ... only where the dispatcher is measured to co-locate siblings (their flag protocol needs one L2)
-            bool ok = false;
-            if (awk::probe_sibling_placement(ctx->stream, ctx->cfg.persistent_wgs, &ok) != hipSuccess || !ok) sp->fusedh = 0;
-        }
         sp->hop = align_hop(ctx, N - (hrir->taps - 1));
         sp->hist_len = N - sp->hop;
         sp->partitions = 1;
@@ -373,7 +368,6 @@ void aw_spatializer_destroy(aw_spatializer *sp) {
         if (pl.d_step) (void)hipFree(pl.d_step);
         if (pl.d_tw1m) (void)hipFree(pl.d_tw1m);
     }
-    if (sp->d_flags) (void)hipFree(sp->d_flags);
     if (sp->d_dbg) (void)hipFree(sp->d_dbg);
     if (sp->d_stage_in) (void)hipFree(sp->d_stage_in);
     if (sp->d_stage_out) (void)hipFree(sp->d_stage_out);
@@ -477,7 +471,7 @@ int32_t aw_spatializer_kernel_time(aw_spatializer *sp, double *avg_ms, const cha
     }
     sp->pending.clear();
     if (avg_ms) *avg_ms = sp->kernel_launches ? sp->kernel_ms_sum / sp->kernel_launches : 0.0;
-    if (kernel_name) *kernel_name = sp->last_lw_R ? "aw_lw_split_kernel + aw_lw_rows_kernel + aw_lw_merge_kernel" : sp->path == 0 ? (sp->fused2 ? awk::fused_ols2_kernel_name(sp->n_channels) : sp->fusedh ? awk::fused_olsh_kernel_name(sp->n_channels) : awk::fused_ols_kernel_name(sp->n_channels)) : (sp->cmac_group ? "aw_part_forward_kernel + aw_part_cmac_kernel + aw_part_inverse_kernel" : "aw_part_forward_kernel + aw_part_march_kernel + aw_part_inverse_kernel");
+    if (kernel_name) *kernel_name = sp->last_lw_R ? "aw_lw_split_kernel + aw_lw_rows_kernel + aw_lw_merge_kernel" : sp->path == 0 ? (sp->fused2 ? awk::fused_ols2_kernel_name(sp->n_channels) : awk::fused_ols_kernel_name(sp->n_channels)) : (sp->cmac_group ? "aw_part_forward_kernel + aw_part_cmac_kernel + aw_part_inverse_kernel" : "aw_part_forward_kernel + aw_part_march_kernel + aw_part_inverse_kernel");
     const int n = sp->kernel_launches;
     sp->kernel_ms_sum = 0.0;
     sp->kernel_launches = 0;
@@ -504,7 +498,7 @@ aw_status aw_spatializer_debug_stamps(aw_spatializer *sp, uint64_t *host_out, in
 
 static void sp_fill_cfg(const aw_spatializer *sp, awk::TileParams &p) {
     const awk::LaunchCfg &c = sp->ctx->cfg;
-    p.persistent_wgs = c.persistent_wgs; p.wide_two_pass = c.wide_two_pass; p.olsh_wgs_per_cu = c.olsh_wgs_per_cu;
+    p.persistent_wgs = c.persistent_wgs; p.wide_two_pass = c.wide_two_pass;
     p.debug_occupancy = c.debug_occupancy;
 }
 
@@ -533,34 +527,10 @@ static aw_status sp_process_fused(aw_spatializer *sp, const float *in, float *ou
         p.dbg = sp->d_dbg;
     }
 #endif
-    if (sp->fusedh == 2) {
-        const size_t need = (size_t)sp->n_streams * p.tiles_per_stream + 1;       // word 0: error word of the bounded spins
-        if (sp->d_flags && sp->epoch > 0) {      // a sibling timed out in an earlier call: its output is not trustworthy
-            int err = 0;
-            AW_HIP_TRY(hipMemcpyAsync(&err, sp->d_flags, sizeof(int), hipMemcpyDeviceToHost, sp->ctx->stream));
-            AW_HIP_TRY(hipStreamSynchronize(sp->ctx->stream));
-            if (err) return fail(AW_ERR_HIP, "sibling-workgroup kernel: a tile flag wait timed out in a previous call (AW_KERNEL_H=2 is experimental; unset it)");
-        }
-        if (sp->flags_cap < need) {
-            if (sp->d_flags) AW_HIP_TRY(hipFree(sp->d_flags));
-            sp->d_flags = nullptr; sp->flags_cap = 0;
-            AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sp->d_flags), need * sizeof(int)));
-            AW_HIP_TRY(hipMemsetAsync(sp->d_flags, 0, need * sizeof(int), sp->ctx->stream));
-            sp->flags_cap = need;
-        }
-        p.flags = sp->d_flags + 1;
-        p.epoch = sp->epoch + 1;          // the launcher uses epoch and epoch + 1 (interior, boundary launch)
-        sp->epoch += 2;
-        if (sp->epoch > 0x7ffffff0) {     // wrap: start over with cleared flags
-            AW_HIP_TRY(hipMemsetAsync(sp->d_flags + 1, 0, (sp->flags_cap - 1) * sizeof(int), sp->ctx->stream));
-            sp->epoch = 0;
-        }
-    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (sp->profiling) { e0 = sp_get_event(sp); e1 = sp_get_event(sp); }
     long long dom_tiles = 0;
     if (sp->fused2) AW_HIP_TRY(awk::launch_fused_ols2(p, sp->n_streams, sp->ctx->stream, e0, e1, &dom_tiles));
-    else if (sp->fusedh) AW_HIP_TRY(awk::launch_fused_olsh(p, sp->n_streams, sp->ctx->stream, e0, e1, &dom_tiles));
     else AW_HIP_TRY(awk::launch_fused_ols(p, sp->n_streams, sp->ctx->stream, e0, e1, &dom_tiles));
     // output frames the timed launch produced (tiles x hop, the last tile of a stream may be short)
     sp->dominant_frames = std::min<long long>(dom_tiles * (long long)sp->hop, (long long)sp->n_streams * frames);

@@ -46,10 +46,6 @@ struct aw_spatializer {
     aw_context *ctx = nullptr;
     int n_channels = 0, n_pairs = 0, n_streams = 0, taps = 0;
     int path = 0;             // 0 fused single-partition overlap-save, 1 partitioned
-    int fusedh = 0;           // 2: path 0, 8192-frame windows, on the sibling-workgroup kernels (device/tile_olsh.hpp; AW_KERNEL_H=2)
-    int *d_flags = nullptr;   // sibling kernels: one word per tile of a launch, compared with the launch epoch (never reset)
-    size_t flags_cap = 0;
-    int epoch = 0;
     bool fused2 = false;      // path 0 on 16384-frame windows (polyphase, two output spectra): device/tile_ols2.hpp
     int hop = 0, hist_len = 0, partitions = 1;
     awk::cf2 *d_tab = nullptr;          // [partitions][pairs][N]

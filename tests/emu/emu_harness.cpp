@@ -15,7 +15,6 @@
 #include <vector>
 
 #include "../../airwave_amd/csrc/device/tile_ols.hpp"
-#include "../../airwave_amd/csrc/device/tile_olsh.hpp"
 #include "../../airwave_amd/csrc/device/tile_march.hpp"
 #include "../../airwave_amd/csrc/device/tile_lw.hpp"
 #include "../../airwave_amd/csrc/device/eq_cascade.hpp"
@@ -88,10 +87,6 @@ struct EmuCtx {
     double row_bcast15(double v) const { const int l = tid_ & 63; return lane_value(v, ((l >> 4) & 1) ? (l & ~15) - 1 : -1, 0.0); }
     double row_bcast31(double v) const { const int l = tid_ & 63; return lane_value(v, l >= 32 ? 31 : -1, 0.0); }
     double wave_shr1(double v, double fill) const { const int l = tid_ & 63; return lane_value(v, l > 0 ? l - 1 : -1, fill); }
-    // sibling flags: the emulation runs workgroups one after the other, the even-bin one first
-    void flag_release(int *flag, int epoch) const { sh->wg.arrive_and_wait(); if (tid_ == 0) *flag = epoch; }
-    awk::cf ld_out(const float *q) const { return *reinterpret_cast<const awk::cf *>(q); }
-    void flag_acquire(int *flag, int epoch, int *) const { if (*flag != epoch) std::abort(); sh->wg.arrive_and_wait(); }
 };
 
 }  // namespace
@@ -187,54 +182,14 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
     if (hi > p.tiles_per_stream) hi = p.tiles_per_stream;
     if (hi < lo) hi = lo;
     if (lo > p.tiles_per_stream) { lo = p.tiles_per_stream; hi = lo; }
-    const bool vec = variant == 4 ? ((n_channels >= 2 && n_channels <= 8) || n_channels == 12 || n_channels == 14 || n_channels == 16)      // awk::has_vec_variant
-                                  : ((n_channels >= 2 && n_channels <= 8) ||
-                                     (n_channels >= 9 && n_channels <= 15 && (variant != 5 || !(n_channels & 1))) || n_channels == 16);
-    if (!vec || (variant != 1 && variant != 4 && variant != 5)) { lo = 0; hi = 0; }
+    const bool vec = (n_channels >= 2 && n_channels <= 8) ||
+                     (n_channels >= 9 && n_channels <= 15 && (variant != 5 || !(n_channels & 1))) || n_channels == 16;
+    if (!vec || (variant != 1 && variant != 5)) { lo = 0; hi = 0; }
     p.tile_lo = (int)lo; p.tile_hi = (int)hi;
     EmuShared sh;
-    std::vector<int> flags((size_t)n_streams * p.tiles_per_stream + 1, 0);
-    p.flags = flags.data() + 1;
     // emulate a persistent launch with a few workgroups, each walking several tiles
     auto run = [&](bool interior, long long n_tiles) {
         const long long G = n_tiles < 3 ? n_tiles : 3;
-        p.epoch += 1;
-        if (variant == 4) {                // sibling workgroups (tile_olsh.hpp): even bins first, then odd bins
-            for (long long g = 0; g < 2 * G; ++g) {
-                const int q = (int)(g & 1);
-                const long long g2 = g / 2;
-                std::vector<std::thread> th;
-                th.reserve(kThreads);
-                for (int t = 0; t < kThreads; ++t)
-                    th.emplace_back([&, t]() {
-                        EmuCtx ctx{t, &sh};
-                        if (interior) {
-                            switch (n_channels) {
-                                case 2: tiles_fused_olsq<EmuCtx, 2, 1, true>(ctx, p, g2, G, n_tiles, q); break;
-                                case 3: tiles_fused_olsq<EmuCtx, 3, 2, true>(ctx, p, g2, G, n_tiles, q); break;
-                                case 4: tiles_fused_olsq<EmuCtx, 4, 2, true>(ctx, p, g2, G, n_tiles, q); break;
-                                case 5: tiles_fused_olsq<EmuCtx, 5, 3, true>(ctx, p, g2, G, n_tiles, q); break;
-                                case 6: tiles_fused_olsq<EmuCtx, 6, 3, true>(ctx, p, g2, G, n_tiles, q); break;
-                                case 7: tiles_fused_olsq<EmuCtx, 7, 4, true>(ctx, p, g2, G, n_tiles, q); break;
-                                case 8: tiles_fused_olsq<EmuCtx, 8, 4, true>(ctx, p, g2, G, n_tiles, q); break;
-                                case 14: tiles_fused_olsq<EmuCtx, 14, 0, true>(ctx, p, g2, G, n_tiles, q); break;
-                                case 12: tiles_fused_olsq<EmuCtx, 12, 0, true>(ctx, p, g2, G, n_tiles, q); break;
-                                default: tiles_fused_olsq<EmuCtx, 16, 0, true>(ctx, p, g2, G, n_tiles, q); break;
-                            }
-                        } else {
-                            switch (p.n_pairs <= 4 ? p.n_pairs : 0) {
-                                case 1: tiles_fused_olsq<EmuCtx, 0, 1, false>(ctx, p, g2, G, n_tiles, q); break;
-                                case 2: tiles_fused_olsq<EmuCtx, 0, 2, false>(ctx, p, g2, G, n_tiles, q); break;
-                                case 3: tiles_fused_olsq<EmuCtx, 0, 3, false>(ctx, p, g2, G, n_tiles, q); break;
-                                case 4: tiles_fused_olsq<EmuCtx, 0, 4, false>(ctx, p, g2, G, n_tiles, q); break;
-                                default: tiles_fused_olsq<EmuCtx, 0, 0, false>(ctx, p, g2, G, n_tiles, q); break;
-                            }
-                        }
-                    });
-                for (auto &x : th) x.join();
-            }
-            return;
-        }
         for (long long g = 0; g < G; ++g) {
             std::vector<std::thread> th;
             th.reserve(kThreads);

@@ -90,20 +90,6 @@ def test_emulated_16384_window_path(oracle, channels, taps, frames):
     assert oracle.peak_rel_error(y[0], oracle.spatialize_f64(x[0], h, lt, rt)) < TOL
 
 
-@pytest.mark.parametrize("channels,taps,frames", [(8, 4320, 16500), (7, 4319, 13001), (2, 300, 9000), (5, 6100, 12001), (14, 1001, 17001)])
-def test_emulated_sibling_workgroup_tiles(oracle, channels, taps, frames):
-    """tile_olsh.hpp (opt-in AW_KERNEL_H=2): the 8192-frame tile as two half-spectra in sibling workgroups — even bins
-    store, odd bins read-modify-write after the tile flag; interior and boundary kernels, short and long histories
-    (a history below 4096 frames makes both output halves of a tile valid)."""
-    h = oracle.synth_hrir(14, taps, seed=4)
-    lt = (np.arange(channels) % 14).astype(np.int32)
-    rt = ((np.arange(channels) + 7) % 14).astype(np.int32)
-    x = oracle.synth_input(1, frames, channels, seed=channels)
-    y = emu.fused_ols(x, h, lt, rt, variant=4)
-    assert not np.isnan(y).any()
-    assert oracle.peak_rel_error(y[0], oracle.spatialize_f64(x[0], h, lt, rt)) < TOL
-
-
 @pytest.mark.parametrize("cmac", ["march", "group"])
 def test_emulated_partitioned_more_than_eight_partitions(oracle, cmac):
     """P = 10 partitions: both CMAC kernels take the partitions 8 at a time, so this exercises a second, partial pass

@@ -93,25 +93,6 @@ def test_interior_kernels_of_every_vector_layout(aw, oracle, golden_dir, channel
         assert oracle.peak_rel_error(y[s], oracle.spatialize_f64(x[s], tracks, lt, rt)) < TOL
 
 
-@pytest.mark.parametrize("channels,taps", [(2, 300), (4, 4320), (7, 4319), (8, 4320), (14, 6100), (5, 1001)])
-def test_sibling_workgroup_kernels_opt_in(aw, oracle, channels, taps, monkeypatch):
-    """AW_KERNEL_H=2 (read at creation): the experimental two-workgroups-per-CU kernels of tile_olsh.hpp — interior and
-    boundary launches, two calls (history carry, flag epochs), histories below and above 4096 frames."""
-    monkeypatch.setenv("AW_KERNEL_H", "2")
-    monkeypatch.setenv("AW_WINDOW", "8192")
-    h = oracle.synth_hrir(14, taps, seed=taps)
-    lt = (np.arange(channels) % 14).astype(np.int32)
-    rt = ((np.arange(channels) + 7) % 14).astype(np.int32)
-    frames = 30011
-    x = oracle.synth_input(3, frames, channels, seed=channels)
-    sp = aw.Spatializer(aw.HRIR(h), lt, rt, n_streams=3)
-    assert "olsq" in sp.kernel_time()[2]
-    y = np.concatenate([sp.process(x[:, :17000]), sp.process(x[:, 17000:])], axis=1)
-    assert not np.isnan(y).any()
-    for s in (0, 2):
-        assert oracle.peak_rel_error(y[s], oracle.spatialize_f64(x[s], h, lt, rt)) < TOL
-
-
 @pytest.mark.parametrize("taps", [1, 2, 511, 512, 513, 4097, 6145])
 def test_hrir_lengths_on_the_fused_path(aw, oracle, taps):
     h = oracle.synth_hrir(4, taps, seed=taps)

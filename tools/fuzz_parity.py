@@ -27,14 +27,13 @@ while time.time() < t_end:
     if r < 0.25: env["AW_WINDOW"] = "8192"
     elif r < 0.5: env["AW_WINDOW"] = "16384"
     elif r < 0.6: env["AW_WINDOW"] = "4096"     # the partitioned path whatever the HRIR length
-    if rng.random() < 0.25: env["AW_KERNEL_H"] = "2"
     r2 = rng.random()
     if r2 < 0.15: env["AW_PART_FWD"] = "1"
     elif r2 < 0.3: env["AW_PART_FWD"] = "2"
     if rng.random() < 0.1: env["AW_PART_CMAC"] = "group"
     if rng.random() < 0.1: env["AW_PART_HERM"] = "0"
     if rng.random() < 0.15: env["AW_SPEC_SCRATCH_MB"] = str(int(rng.choice([1, 3, 16])))      # several stream chunks
-    for k in ("AW_WINDOW", "AW_KERNEL_H", "AW_PART_FWD", "AW_PART_CMAC", "AW_PART_HERM", "AW_SPEC_SCRATCH_MB"):
+    for k in ("AW_WINDOW", "AW_PART_FWD", "AW_PART_CMAC", "AW_PART_HERM", "AW_SPEC_SCRATCH_MB"):
         os.environ.pop(k, None)
     os.environ.update(env)
     n_tracks = int(rng.choice([2, 7, 14]))
