@@ -15,6 +15,13 @@ __global__ void __launch_bounds__(kThreads, RA == 16 ? 2 : 4) aw_lw_split_kernel
     lw_split_tiles<GpuCtx, RA, CS, WIDE>(ctx, p, (long long)blockIdx.x, (long long)gridDim.x, n_tiles);
 }
 
+template <int RA, int CS1>
+__global__ void __launch_bounds__(kThreads, RA == 16 ? 2 : 4) aw_lw_split_wide_kernel(LwParams p, long long n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
+    lw_split_wide_tiles<GpuCtx, RA, CS1>(ctx, p, (long long)blockIdx.x, (long long)gridDim.x, n_tiles);
+}
+
 // Row pairs are pinned to XCDs (blockIdx % 8 labels the XCD): XCD x walks the row pairs x, x + 8, ... one after the other
 // and, within a row pair, every (stream, window); its 32 workgroups therefore share one 512 KB table slice at a time.
 template <int NP, bool REAL_LAST>
@@ -71,6 +78,12 @@ hipError_t prepare_lw_kernels() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lw_split_lds_bytes<RA>());
     AW_LW_FOR_RA_CS(AW_SET)
 #undef AW_SET
+#define AW_SET(RA, CS)                                                                                 \
+    if (e == hipSuccess)                                                                               \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_split_wide_kernel<RA, CS>),      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lw_split_lds_bytes<RA>());
+    AW_LW_FOR_RA_CS(AW_SET)
+#undef AW_SET
 #define AW_SET(NP)                                                                                     \
     if (e == hipSuccess)                                                                               \
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_rows_kernel<NP, false>),         \
@@ -105,7 +118,25 @@ hipError_t launch_lw_split(const LwParams &p_in, int n_streams, hipStream_t stre
     if (n_tiles <= 0) return hipSuccess;
     if (n_tiles > 0x7fffffffLL || p_in.n_channels < 1 || p_in.n_channels > 16) return hipErrorInvalidValue;
     const int ra = p_in.R / 8;
-    const bool wide = p_in.n_channels > 8;           // two launches, one per group of (up to) eight channels
+    const bool wide = p_in.n_channels > 8;
+    if (wide && !p_in.wide_groups) {                 // 9-16 channels: one launch, both channel halves of a frame in one wave
+        const long long nt = (long long)n_streams * p_in.n_windows * kLwChunksW;
+        if (nt > 0x7fffffffLL || !p_in.tail) return hipErrorInvalidValue;
+        const int cs1 = p_in.n_channels - 8;
+        if (tm) tm->begin();
+        bool done = false;
+#define AW_CASE(RA, CS)                                                                                                            \
+        if (!done && ra == RA && cs1 == CS) {                                                                                      \
+            hipLaunchKernelGGL((aw_lw_split_wide_kernel<RA, CS>), dim3(lw_grid(nt, p_in, RA == 16 ? 1 : 2)), dim3(kThreads),      \
+                               lw_split_lds_bytes<RA>(), stream, p_in, nt);                                                        \
+            done = true;                                                                                                           \
+        }
+        AW_LW_FOR_RA_CS(AW_CASE)
+#undef AW_CASE
+        if (tm) tm->end("aw_lw_split_wide_kernel");
+        return done ? hipGetLastError() : hipErrorInvalidValue;
+    }
+    // (A/B: AW_LW_WIDE_GROUPS=1) two launches, one per group of (up to) eight channels: every input line is read twice
     for (int c0 = 0; c0 < p_in.n_channels; c0 += 8) {
         LwParams p = p_in;
         p.ch0 = c0; p.pair0 = c0 / 2;

@@ -61,7 +61,9 @@ struct LwParams {
     const float *zeros;     // >= 64 bytes of zeros
     long long frames;       // frames per stream in this call
     int n_channels, n_pairs;
-    int ch0, pair0;         // split kernel, layouts of 9-16 channels: this launch's group of up to eight channels starts at channel ch0 = 2 pair0
+    int ch0, pair0;         // split kernel, grouped form for 9-16 channels (A/B only): this launch's group of up to eight channels starts at ch0 = 2 pair0
+    const float *tail;      // wide split kernel (9-16 channels): a copy of the LAST frame of the last stream of `in`, followed by >= 4 zeros
+    int n_streams;          // streams in this launch (the wide split kernel redirects the last frame of the last one to `tail`)
     int real_last;          // odd channel count: the last pair's second channel is absent (real input)
     int hist_len;           // N - hop >= taps - 1: window positions below it are discarded
     int hop;                // new output frames per window
@@ -79,6 +81,7 @@ struct LwParams {
     const cf *tw1m;         // [512]: w_4096^{t}
     const cf *twa, *twb;    // sub-FFT twiddles of the context (tile_ols.hpp)
     int persistent_wgs;
+    int wide_groups;        // 9-16 channels: 1 = the split kernel once per group of eight channels (A/B: AW_LW_WIDE_GROUPS=1), 0 = one launch
     int rows_pairs_per_batch;   // rows kernel form: 2 = two pairs per batch, one workgroup per CU; 1 = one pair per batch, two workgroups per CU
 };
 
@@ -291,6 +294,128 @@ AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
                     if (kb < 4) {
                         ctx.st_stream(dst + (long long)k1 * kLwM, cmul(v[kb], tlo[kb & 3]));
                     } else if (!real_pair) {
+                        ctx.st_stream(dst + (long long)k1 * kLwM, cmul(conj(v[kb]), tup[(7 - kb) & 3]));
+                    }
+                }
+            }
+        });
+    }
+}
+
+
+// Layouts of 9-16 channels in ONE launch: a wave covers 32 consecutive frames t and both halves of their channels — lanes
+// 0-31 channels 0-7 (pairs 0-3), lanes 32-63 channels 8..C-1 (pairs 4..) — so every 128-byte line of the input crosses the
+// fabric once (one launch per group of eight channels read every line twice: 14 channels 16.6 ms for what is 11 ms of bytes).
+// Every lane issues the same two 16-byte loads per frame; the second half's may run up to 3 floats past its frame (into the
+// next frame, the history buffer's slack or the zero page — values that are never used); the one place that would leave the
+// caller's buffer, the last frame of the last stream, is read from a padded copy (p.tail).  Tile id = (stream, window) * 128 + tc.
+constexpr int kLwTwW = 32;
+constexpr int kLwChunksW = kLwM / kLwTwW;
+
+template <class Ctx, int RA, int CS1>
+AW_HD void lw_split_wide_tiles(Ctx &ctx, const LwParams &p, long long first, long long step, long long end) {
+    static_assert(RA == 4 || RA == 8 || RA == 16, "R = 32, 64 or 128 rows");
+    static_assert(CS1 >= 1 && CS1 <= 8, "channels 8 .. 8 + CS1 - 1 in the second half");
+    constexpr int C = 8 + CS1, NP1 = (CS1 + 1) / 2, NPASS = 2, NCOMBO = RA / 4, G = RA >= 8 ? RA / 8 : 1;
+    if (first >= end) return;
+    const int lane = ctx.lane(), wave = ctx.wave();
+    const int tl = lane & 31, half = lane >> 5;
+    const int nph = half ? NP1 : 4;                      // pairs this lane's half holds
+    cf *lds = ctx.lds();
+    cf *sm = lds + 2 * RA * 8 * 64;
+    lw_small_tables<RA>(ctx, p, sm);
+    float raw[RA][8];
+    auto load_tile = [&](long long id) {
+        const long long sw = (long long)((unsigned long long)id / (unsigned)kLwChunksW);
+        const int tc = (int)(id - sw * kLwChunksW);
+        const long long stream = sw / p.n_windows;
+        const int win = (int)(sw - stream * p.n_windows);
+        const float *in_s = p.in + stream * p.frames * C + 8 * half;
+        const float *hist_s = p.hist + stream * (long long)p.hist_len * C + 8 * half;
+        const bool last_stream = stream == p.n_streams - 1;
+        const long long fb = (long long)win * p.hop - p.hist_len + (long long)kLwM * wave + tc * kLwTwW + tl;
+#pragma unroll
+        for (int j2 = 0; j2 < RA; ++j2) {
+            const long long f = fb + (long long)kLwM * 8 * j2;
+            const float *src = f < 0 ? hist_s + ((long long)p.hist_len + f) * C : (f >= p.frames ? p.zeros : in_s + f * C);
+            if (last_stream && f == p.frames - 1) src = p.tail + 8 * half;
+            // second half with at most four channels: its second load has nothing to fetch
+            const float *src2 = (CS1 <= 4 && half) ? p.zeros : src + 4;
+            const f4u a = *reinterpret_cast<const f4u *>(src);
+            const f4u b = *reinterpret_cast<const f4u *>(src2);
+            raw[j2][0] = a.x; raw[j2][1] = a.y; raw[j2][2] = a.z; raw[j2][3] = a.w;
+            raw[j2][4] = b.x; raw[j2][5] = b.y; raw[j2][6] = b.z; raw[j2][7] = b.w;
+        }
+    };
+    load_tile(first);
+    for (long long id = first; id < end; id += step) {
+        const long long sw = (long long)((unsigned long long)id / (unsigned)kLwChunksW);
+        const int tc = (int)(id - sw * kLwChunksW);
+        const int t = tc * kLwTwW + tl;
+        const int tc64 = tc >> 1, lane64 = 32 * (tc & 1) + tl;      // the twiddle tables' (64-frame chunk, lane) coordinates of t
+        cf *spec_sw = p.spec + sw * p.spec_per_sw;
+        cf S[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) S[m] = p.tw_step[m * kLwM + t];
+        if (p.hist_out) {             // uniform.  The next call's history: frames [frames - hist_len, frames) of (history ++ input)
+            const long long stream = sw / p.n_windows;
+            const int win = (int)(sw - stream * p.n_windows);
+            const long long fb = (long long)win * p.hop - p.hist_len + (long long)kLwM * wave + t;
+            float *ho = p.hist_out + stream * (long long)p.hist_len * C + 8 * half;
+#pragma unroll
+            for (int j2 = 0; j2 < RA; ++j2) {
+                const long long i = fb + (long long)kLwM * 8 * j2 - (p.frames - p.hist_len);
+                if (i >= 0 && i < p.hist_len) {
+                    if (half == 0) lw_store_frame<8, false>(ho + i * C, raw[j2]);
+                    else {
+                        float d[CS1];
+#pragma unroll
+                        for (int c = 0; c < CS1; ++c) d[c] = raw[j2][c];
+                        lw_store_frame<CS1, false>(ho + i * C, d);
+                    }
+                }
+            }
+        }
+        lw_unroll<NPASS>([&](auto PP) {
+            constexpr int pp = PP.value;
+            if (pp > 0 || id != first) ctx.barrier();
+            // step 1: local pairs 2 pp, 2 pp + 1 of this lane's half (a half without that pair transforms zeros / an unused value)
+            lw_unroll<2>([&](auto Q) {
+                constexpr int q = Q.value, pair = 2 * pp + q;
+                cf x[RA];
+                // the second channel of a real last pair (odd channel count) must be a true zero
+                const bool has_b = half == 0 || 2 * pair + 1 < CS1;
+#pragma unroll
+                for (int j2 = 0; j2 < RA; ++j2) x[j2] = mk(raw[j2][2 * pair], has_b ? raw[j2][2 * pair + 1] : 0.0f);
+                lw_odd_dft<false, RA>(x);
+#pragma unroll
+                for (int ka = 0; ka < RA; ++ka) lds[((q * RA + ka) * 8 + wave) * 64 + lane] = x[ka];
+            });
+            if constexpr (pp == NPASS - 1) load_tile(id + step < end ? id + step : id);
+            ctx.barrier();
+#pragma unroll
+            for (int i = 0; i < NCOMBO; ++i) {
+                const int q = RA >= 8 ? i / G : wave / RA;                      // uniform
+                const int ka = RA >= 8 ? wave + 8 * (i % G) : wave % RA;
+                const int pair = 2 * pp + q;                                    // local to the half
+                cf v[8];
+#pragma unroll
+                for (int j1 = 0; j1 < 8; ++j1) v[j1] = ctx.ld(lds + ((q * RA + ka) * 8 + j1) * 64 + lane);
+#pragma unroll
+                for (int j1 = 1; j1 < 8; ++j1) v[j1] = cmul(v[j1], ctx.ld(sm + ka * 8 + j1));
+                fft8<false>(v);
+                cf tlo[4], tup[4];
+                lw_row_twiddles<RA>(ctx, sm, ka, tc64, lane64, S, tlo);
+                lw_row_twiddles<RA>(ctx, sm, RA - 1 - ka, tc64, lane64, S, tup);
+                const bool live = pair < nph;                                   // per lane half
+                const bool real_pair = (CS1 & 1) && half == 1 && pair == NP1 - 1;
+                cf *dst = spec_sw + (long long)(4 * half + pair) * p.N + t;
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) {
+                    const int k1 = RA * kb + ka;
+                    if (kb < 4) {
+                        if (live) ctx.st_stream(dst + (long long)k1 * kLwM, cmul(v[kb], tlo[kb & 3]));
+                    } else if (live && !real_pair) {
                         ctx.st_stream(dst + (long long)k1 * kLwM, cmul(conj(v[kb]), tup[(7 - kb) & 3]));
                     }
                 }

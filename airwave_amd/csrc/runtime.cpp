@@ -360,6 +360,7 @@ void aw_spatializer_destroy(aw_spatializer *sp) {
     for (int i = 0; i < 2; ++i)
         if (sp->d_hist[i]) (void)hipFree(sp->d_hist[i]);
     if (sp->d_spec) (void)hipFree(sp->d_spec);
+    if (sp->d_tail) (void)hipFree(sp->d_tail);
     for (auto &pl : sp->lw_plans) {
         if (pl.d_tab) (void)hipFree(pl.d_tab);
         if (pl.d_coarse) (void)hipFree(pl.d_coarse);
@@ -747,6 +748,17 @@ static aw_status sp_process_longwin(aw_spatializer *sp, int R, const float *in, 
         p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb;
         p.persistent_wgs = sp->ctx->cfg.persistent_wgs;
         p.rows_pairs_per_batch = sp->ctx->cfg.lw_rows_pb;
+        p.wide_groups = sp->ctx->cfg.lw_wide_groups;
+        p.n_streams = ns;
+        if (sp->n_channels > 8) {        // the wide split kernel reads the last frame of the last stream from a padded copy
+            if (!sp->d_tail) {
+                AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sp->d_tail), 32 * sizeof(float)));
+                AW_HIP_TRY(hipMemsetAsync(sp->d_tail, 0, 32 * sizeof(float), sp->ctx->stream));
+            }
+            AW_HIP_TRY(hipMemcpyAsync(sp->d_tail, p.in + ((size_t)ns * frames - 1) * sp->n_channels, sp->n_channels * sizeof(float),
+                                      hipMemcpyDeviceToDevice, sp->ctx->stream));
+            p.tail = sp->d_tail;
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (sp->profiling) {
             e0 = sp_get_event(sp); e1 = sp_get_event(sp);

@@ -66,6 +66,7 @@ struct aw_spatializer {
     std::vector<float> lw_tracks;       // the HRIR and channel map, kept for the lazily built tables
     std::vector<int32_t> lw_left, lw_right;
     int lw_n_tracks = 0;
+    float *d_tail = nullptr;            // 32 floats: the last frame of the last stream of a call + zeros (wide split kernel, tile_lw.hpp)
     int last_lw_R = 0;                  // R of the last call (0: the partitioned kernels ran)
     int64_t reserved_frames = 0;        // aw_spatializer_reserve(): buffers are sized for calls up to this many frames
     // host-entry staging (grow-only)

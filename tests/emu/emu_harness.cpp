@@ -353,7 +353,7 @@ int emu_partitioned(const float *in, float *out, const float *hist, const float 
 // The long-window path (tile_lw.hpp): split -> rows -> merge on windows of N = R x 4096 frames, R in {32, 64, 128}.
 // hist: [stream][hist_len][C] or NULL; hist_len = N - hop must be >= taps - 1 (hop given by the caller).
 int emu_longwin(const float *in, float *out, const float *hist, const float *tracks, int n_tracks, int taps, int n_channels,
-                const int32_t *left_track, const int32_t *right_track, long long frames, int n_streams, int R, int hop, int rows_pb, float *hist_out) {
+                const int32_t *left_track, const int32_t *right_track, long long frames, int n_streams, int R, int hop, int rows_pb, float *hist_out, int wide_groups) {
     using namespace awk;
     if (R != 32 && R != 64 && R != 128) return -1;
     const long long N = (long long)R * kLwM;
@@ -385,8 +385,23 @@ int emu_longwin(const float *in, float *out, const float *hist, const float *tra
         for (auto &x : th) x.join();
     };
     const long long n_st = n_sw * kLwChunks;
+    std::vector<float> tail(32, 0.f);
+    std::memcpy(tail.data(), in + ((size_t)n_streams * frames - 1) * n_channels, n_channels * sizeof(float));
+    p.tail = tail.data(); p.n_streams = n_streams;
     auto split = [&](auto RA) {
         constexpr int ra = decltype(RA)::value;
+        if (n_channels > 8 && !wide_groups) {              // one launch: both channel halves of a frame in one wave
+            const long long n_stw = n_sw * kLwChunksW;
+            run([&](EmuCtx &ctx) {
+                switch (n_channels - 8) {
+                    case 1: lw_split_wide_tiles<EmuCtx, ra, 1>(ctx, p, 0, 1, n_stw); break; case 2: lw_split_wide_tiles<EmuCtx, ra, 2>(ctx, p, 0, 1, n_stw); break;
+                    case 3: lw_split_wide_tiles<EmuCtx, ra, 3>(ctx, p, 0, 1, n_stw); break; case 4: lw_split_wide_tiles<EmuCtx, ra, 4>(ctx, p, 0, 1, n_stw); break;
+                    case 5: lw_split_wide_tiles<EmuCtx, ra, 5>(ctx, p, 0, 1, n_stw); break; case 6: lw_split_wide_tiles<EmuCtx, ra, 6>(ctx, p, 0, 1, n_stw); break;
+                    case 7: lw_split_wide_tiles<EmuCtx, ra, 7>(ctx, p, 0, 1, n_stw); break; default: lw_split_wide_tiles<EmuCtx, ra, 8>(ctx, p, 0, 1, n_stw); break;
+                }
+            });
+            return;
+        }
         for (int c0 = 0; c0 < n_channels; c0 += 8) {          // layouts of 9-16 channels: one pass per group of eight channels
             LwParams q = p;
             q.ch0 = c0; q.pair0 = c0 / 2;

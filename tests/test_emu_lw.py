@@ -22,7 +22,7 @@ def _case(oracle, channels, taps, frames, R, seed=5, hop=None, hist_frames=0):
     return h, lt, rt, x, ref
 
 
-@pytest.mark.parametrize("channels,rows_pb", [(7, 2), (8, 2), (1, 2), (2, 2), (5, 2), (7, 1), (6, 1), (1, 1), (14, 1), (9, 1), (13, 2), (16, 1)])
+@pytest.mark.parametrize("channels,rows_pb", [(7, 2), (8, 2), (1, 2), (2, 2), (5, 2), (7, 1), (6, 1), (1, 1), (14, 1), (9, 1), (13, 2), (16, 1), (12, 1), (11, 1)])
 def test_emulated_long_window_matches_truth(oracle, channels, rows_pb):
     # one window of 32 x 4096 frames holds the whole call: history (zeros), input, zero fill past the end;
     # rows_pb = channel pairs per batch of the rows kernel (1: the two-workgroups-per-CU form)
@@ -78,3 +78,24 @@ def test_emulated_split_kernel_carries_a_short_calls_tail(oracle):
     assert np.array_equal(hist_out, x[:, -hist_len:])
     for ear in range(2):
         assert oracle.peak_rel_error(y[0, :, ear], ref[hist_len:, ear]) < TOL
+
+
+def test_emulated_wide_layout_carries_history_and_matches_the_grouped_form(oracle):
+    # 14 channels, two windows, history in and out: the one-launch wide split kernel (both channel halves in a wave) against
+    # the truth and against the one-launch-per-group form; the call's very last frame is read through the padded tail copy
+    taps, R, C = 30000, 32, 14
+    N = R * 4096
+    hist_len = 32768
+    hop = N - hist_len
+    frames = 110000
+    h, lt, rt, x, ref = _case(oracle, C, taps, frames, R, hist_frames=hist_len)
+    hist = x[:, :hist_len].copy()
+    outs = []
+    for groups in (False, True):
+        hist_out = np.full((1, hist_len, C), np.nan, dtype=np.float32)
+        y = emu.longwin(x[:, hist_len:], h, lt, rt, R=R, hop=hop, hist=hist, hist_out=hist_out, rows_pb=1, wide_groups=groups)
+        assert np.array_equal(hist_out, x[:, -hist_len:])
+        for ear in range(2):
+            assert oracle.peak_rel_error(y[0, :, ear], ref[hist_len:, ear]) < TOL
+        outs.append(y)
+    assert np.array_equal(outs[0], outs[1])
