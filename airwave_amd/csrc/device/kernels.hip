@@ -160,7 +160,6 @@ hipError_t prepare_kernels(LaunchCfg *cfg) {
         if (const char *e6 = getenv("AW_EQ_EAR_SPLIT")) cfg->eq_ear_split = atoi(e6);
         if (const char *e7 = getenv("AW_LW_ROWS_PB")) cfg->lw_rows_pb = atoi(e7) == 2 ? 2 : 1;
         if (const char *e8 = getenv("AW_HOP_ALIGN")) cfg->hop_align = atoi(e8);
-        if (const char *e9 = getenv("AW_LW_WIDE_GROUPS")) cfg->lw_wide_groups = atoi(e9) != 0;
     }
 #define AW_SET_VEC(CS, NP)                                                                           \
     if (e == hipSuccess)                                                                             \

@@ -64,7 +64,6 @@ struct LaunchCfg {
     int stamp_thread = 0;         // AW_STAMP_THREAD (diagnostic builds)
     int eq_ear_split = -1;        // AW_EQ_EAR_SPLIT: -1 automatic, 0 / 1 forced
     int lw_rows_pb = 1;           // long-window rows kernel: channel pairs per batch (AW_LW_ROWS_PB; 1 = one exchange buffer, two workgroups per CU)
-    int lw_wide_groups = 0;       // long-window split kernel for 9-16 channels once per group of eight channels (AW_LW_WIDE_GROUPS=1, A/B)
     int hop_align = 64;           // fused windows start on multiples of this many frames (AW_HOP_ALIGN; 1 = off)
 };
 hipError_t prepare_kernels(LaunchCfg *cfg);   // fills cfg from the current device + environment; sets the dynamic-LDS attribute on every tile kernel

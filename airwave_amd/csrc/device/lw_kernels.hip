@@ -8,11 +8,11 @@ namespace awk {
 
 // Tile id = (stream, window) * 64 + t-chunk: workgroups that run at the same time read and write neighbouring 64-frame
 // pieces of the same R strided sub-sequences (whole DRAM pages between them).
-template <int RA, int CS, bool WIDE = false>
+template <int RA, int CS>
 __global__ void __launch_bounds__(kThreads, RA == 16 ? 2 : 4) aw_lw_split_kernel(LwParams p, long long n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
-    lw_split_tiles<GpuCtx, RA, CS, WIDE>(ctx, p, (long long)blockIdx.x, (long long)gridDim.x, n_tiles);
+    lw_split_tiles<GpuCtx, RA, CS>(ctx, p, (long long)blockIdx.x, (long long)gridDim.x, n_tiles);
 }
 
 template <int RA, int CS1>
@@ -74,12 +74,6 @@ hipError_t prepare_lw_kernels() {
 #undef AW_SET
 #define AW_SET(RA, CS)                                                                                 \
     if (e == hipSuccess)                                                                               \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_split_kernel<RA, CS, true>),     \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lw_split_lds_bytes<RA>());
-    AW_LW_FOR_RA_CS(AW_SET)
-#undef AW_SET
-#define AW_SET(RA, CS)                                                                                 \
-    if (e == hipSuccess)                                                                               \
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_split_wide_kernel<RA, CS>),      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lw_split_lds_bytes<RA>());
     AW_LW_FOR_RA_CS(AW_SET)
@@ -113,49 +107,27 @@ static unsigned lw_grid(long long n_tiles, const LwParams &p, int wgs_per_cu) {
     return (unsigned)(n_tiles < wgs ? n_tiles : wgs);
 }
 
-hipError_t launch_lw_split(const LwParams &p_in, int n_streams, hipStream_t stream, StageTimer *tm) {
-    const long long n_tiles = (long long)n_streams * p_in.n_windows * kLwChunks;
+hipError_t launch_lw_split(const LwParams &p, int n_streams, hipStream_t stream, StageTimer *tm) {
+    if (p.n_channels < 1 || p.n_channels > 16) return hipErrorInvalidValue;
+    const int ra = p.R / 8;
+    const bool wide = p.n_channels > 8;              // 9-16 channels: both channel halves of a frame in one wave, 32 frames per tile
+    const long long n_tiles = (long long)n_streams * p.n_windows * (wide ? kLwChunksW : kLwChunks);
     if (n_tiles <= 0) return hipSuccess;
-    if (n_tiles > 0x7fffffffLL || p_in.n_channels < 1 || p_in.n_channels > 16) return hipErrorInvalidValue;
-    const int ra = p_in.R / 8;
-    const bool wide = p_in.n_channels > 8;
-    if (wide && !p_in.wide_groups) {                 // 9-16 channels: one launch, both channel halves of a frame in one wave
-        const long long nt = (long long)n_streams * p_in.n_windows * kLwChunksW;
-        if (nt > 0x7fffffffLL || !p_in.tail) return hipErrorInvalidValue;
-        const int cs1 = p_in.n_channels - 8;
-        if (tm) tm->begin();
-        bool done = false;
+    if (n_tiles > 0x7fffffffLL || (wide && !p.tail)) return hipErrorInvalidValue;
+    const int cs = wide ? p.n_channels - 8 : p.n_channels;
+    if (tm) tm->begin();
+    bool done = false;
 #define AW_CASE(RA, CS)                                                                                                            \
-        if (!done && ra == RA && cs1 == CS) {                                                                                      \
-            hipLaunchKernelGGL((aw_lw_split_wide_kernel<RA, CS>), dim3(lw_grid(nt, p_in, RA == 16 ? 1 : 2)), dim3(kThreads),      \
-                               lw_split_lds_bytes<RA>(), stream, p_in, nt);                                                        \
-            done = true;                                                                                                           \
-        }
-        AW_LW_FOR_RA_CS(AW_CASE)
-#undef AW_CASE
-        if (tm) tm->end("aw_lw_split_wide_kernel");
-        return done ? hipGetLastError() : hipErrorInvalidValue;
+    if (!done && ra == RA && cs == CS) {                                                                                           \
+        const dim3 grid(lw_grid(n_tiles, p, RA == 16 ? 1 : 2));                                                                    \
+        if (wide) hipLaunchKernelGGL((aw_lw_split_wide_kernel<RA, CS>), grid, dim3(kThreads), lw_split_lds_bytes<RA>(), stream, p, n_tiles);   \
+        else hipLaunchKernelGGL((aw_lw_split_kernel<RA, CS>), grid, dim3(kThreads), lw_split_lds_bytes<RA>(), stream, p, n_tiles);             \
+        done = true;                                                                                                               \
     }
-    // (A/B: AW_LW_WIDE_GROUPS=1) two launches, one per group of (up to) eight channels: every input line is read twice
-    for (int c0 = 0; c0 < p_in.n_channels; c0 += 8) {
-        LwParams p = p_in;
-        p.ch0 = c0; p.pair0 = c0 / 2;
-        const int cs = p.n_channels - c0 < 8 ? p.n_channels - c0 : 8;
-        if (tm) tm->begin();
-        bool done = false;
-#define AW_CASE(RA, CS)                                                                                                            \
-        if (!done && ra == RA && cs == CS) {                                                                                       \
-            const dim3 grid(lw_grid(n_tiles, p, RA == 16 ? 1 : 2));                                                                \
-            if (wide) hipLaunchKernelGGL((aw_lw_split_kernel<RA, CS, true>), grid, dim3(kThreads), lw_split_lds_bytes<RA>(), stream, p, n_tiles);   \
-            else hipLaunchKernelGGL((aw_lw_split_kernel<RA, CS, false>), grid, dim3(kThreads), lw_split_lds_bytes<RA>(), stream, p, n_tiles);       \
-            done = true;                                                                                                           \
-        }
-        AW_LW_FOR_RA_CS(AW_CASE)
+    AW_LW_FOR_RA_CS(AW_CASE)
 #undef AW_CASE
-        if (tm) tm->end("aw_lw_split_kernel");
-        if (!done) return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
+    if (tm) tm->end(wide ? "aw_lw_split_wide_kernel" : "aw_lw_split_kernel");
+    return done ? hipGetLastError() : hipErrorInvalidValue;
 }
 
 hipError_t launch_lw_rows(const LwParams &p, int n_streams, hipStream_t stream, StageTimer *tm) {

@@ -61,7 +61,6 @@ struct LwParams {
     const float *zeros;     // >= 64 bytes of zeros
     long long frames;       // frames per stream in this call
     int n_channels, n_pairs;
-    int ch0, pair0;         // split kernel, grouped form for 9-16 channels (A/B only): this launch's group of up to eight channels starts at ch0 = 2 pair0
     const float *tail;      // wide split kernel (9-16 channels): a copy of the LAST frame of the last stream of `in`, followed by >= 4 zeros
     int n_streams;          // streams in this launch (the wide split kernel redirects the last frame of the last one to `tail`)
     int real_last;          // odd channel count: the last pair's second channel is absent (real input)
@@ -81,7 +80,6 @@ struct LwParams {
     const cf *tw1m;         // [512]: w_4096^{t}
     const cf *twa, *twb;    // sub-FFT twiddles of the context (tile_ols.hpp)
     int persistent_wgs;
-    int wide_groups;        // 9-16 channels: 1 = the split kernel once per group of eight channels (A/B: AW_LW_WIDE_GROUPS=1), 0 = one launch
     int rows_pairs_per_batch;   // rows kernel form: 2 = two pairs per batch, one workgroup per CU; 1 = one pair per batch, two workgroups per CU
 };
 
@@ -190,15 +188,13 @@ AW_HD void lw_row_twiddles(Ctx &ctx, const cf *sm, int ka, int tc, int lane, con
 // Tile id = (stream, window) * 64 + tc.  512 threads: wave = j1, lane = t - 64 tc.  LDS: [2][RA][8][64] complex.
 template <int RA> constexpr int lw_split_lds_elems() { return 2 * RA * 8 * 64 + lw_small_elems<RA>(); }
 
-// WIDE (layouts of 9-16 channels): the launch handles the group of CS <= 8 channels starting at p.ch0 of frames that are
-// p.n_channels wide (dword-aligned loads); otherwise the frame IS the group (CS == p.n_channels, compile-time stride).
-template <class Ctx, int RA, int CS, bool WIDE = false>
+// Layouts of up to eight channels (CS == p.n_channels; 9-16 channels: lw_split_wide_tiles below).
+template <class Ctx, int RA, int CS>
 AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long long step, long long end) {
     static_assert(RA == 4 || RA == 8 || RA == 16, "R = 32, 64 or 128 rows");
-    static_assert(CS >= 1 && CS <= 8, "up to eight channels per group");
-    constexpr bool AL = !WIDE && CS % 4 == 0;
-    const int CF = WIDE ? p.n_channels : CS;              // floats per frame
-    const int c0 = WIDE ? p.ch0 : 0, pair0 = WIDE ? p.pair0 : 0;
+    static_assert(CS >= 1 && CS <= 8, "up to eight channels");
+    constexpr bool AL = CS % 4 == 0;
+    constexpr int CF = CS, c0 = 0, pair0 = 0;
     constexpr int NP = (CS + 1) / 2, NPASS = (NP + 1) / 2, NCOMBO = RA / 4, G = RA >= 8 ? RA / 8 : 1;
     if (first >= end) return;
     const int lane = ctx.lane(), wave = ctx.wave();
@@ -305,7 +301,7 @@ AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
 
 // Layouts of 9-16 channels in ONE launch: a wave covers 32 consecutive frames t and both halves of their channels — lanes
 // 0-31 channels 0-7 (pairs 0-3), lanes 32-63 channels 8..C-1 (pairs 4..) — so every 128-byte line of the input crosses the
-// fabric once (one launch per group of eight channels read every line twice: 14 channels 16.6 ms for what is 11 ms of bytes).
+// fabric once (one launch per group of eight channels read every line twice: cfg 3 with 14 channels 16.3 against 11.8 ms).
 // Every lane issues the same two 16-byte loads per frame; the second half's may run up to 3 floats past its frame (into the
 // next frame, the history buffer's slack or the zero page — values that are never used); the one place that would leave the
 // caller's buffer, the last frame of the last stream, is read from a padded copy (p.tail).  Tile id = (stream, window) * 128 + tc.

@@ -748,7 +748,6 @@ static aw_status sp_process_longwin(aw_spatializer *sp, int R, const float *in, 
         p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb;
         p.persistent_wgs = sp->ctx->cfg.persistent_wgs;
         p.rows_pairs_per_batch = sp->ctx->cfg.lw_rows_pb;
-        p.wide_groups = sp->ctx->cfg.lw_wide_groups;
         p.n_streams = ns;
         if (sp->n_channels > 8) {        // the wide split kernel reads the last frame of the last stream from a padded copy
             if (!sp->d_tail) {

@@ -30,7 +30,7 @@ def lib():
         _lib.emu_partitioned.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
                                          ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
         _lib.emu_longwin.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
-                                     ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int]
+                                     ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
         _lib.emu_fft_small.argtypes = [fp, ctypes.c_int, ctypes.c_int]
         _lib.emu_eq_process.argtypes = [fp, fp, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_longlong, ctypes.c_double,
                                         ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int]
@@ -75,7 +75,7 @@ def partitioned(x, tracks, left_track, right_track, hist=None, cmac="march"):
     return out
 
 
-def longwin(x, tracks, left_track, right_track, R=32, hop=None, hist=None, rows_pb=2, hist_out=None, wide_groups=False):
+def longwin(x, tracks, left_track, right_track, R=32, hop=None, hist=None, rows_pb=2, hist_out=None):
     """Long-window path (tile_lw.hpp): windows of R x 4096 frames; x: [streams][frames][C] -> [streams][frames][2]."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     S, F, C = x.shape
@@ -92,7 +92,7 @@ def longwin(x, tracks, left_track, right_track, R=32, hop=None, hist=None, rows_
         assert h.shape == (S, N - hop, C)
     rc = lib().emu_longwin(x.ctypes.data_as(fp), out.ctypes.data_as(fp), None if h is None else h.ctypes.data_as(fp),
                            tr.ctypes.data_as(fp), tr.shape[0], tr.shape[1], C, lt.ctypes.data_as(ip), rt.ctypes.data_as(ip),
-                           F, S, R, hop, rows_pb, None if hist_out is None else hist_out.ctypes.data_as(fp), int(wide_groups))
+                           F, S, R, hop, rows_pb, None if hist_out is None else hist_out.ctypes.data_as(fp))
     assert rc == 0, rc
     return out
 

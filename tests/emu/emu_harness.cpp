@@ -353,7 +353,7 @@ int emu_partitioned(const float *in, float *out, const float *hist, const float 
 // The long-window path (tile_lw.hpp): split -> rows -> merge on windows of N = R x 4096 frames, R in {32, 64, 128}.
 // hist: [stream][hist_len][C] or NULL; hist_len = N - hop must be >= taps - 1 (hop given by the caller).
 int emu_longwin(const float *in, float *out, const float *hist, const float *tracks, int n_tracks, int taps, int n_channels,
-                const int32_t *left_track, const int32_t *right_track, long long frames, int n_streams, int R, int hop, int rows_pb, float *hist_out, int wide_groups) {
+                const int32_t *left_track, const int32_t *right_track, long long frames, int n_streams, int R, int hop, int rows_pb, float *hist_out) {
     using namespace awk;
     if (R != 32 && R != 64 && R != 128) return -1;
     const long long N = (long long)R * kLwM;
@@ -390,7 +390,7 @@ int emu_longwin(const float *in, float *out, const float *hist, const float *tra
     p.tail = tail.data(); p.n_streams = n_streams;
     auto split = [&](auto RA) {
         constexpr int ra = decltype(RA)::value;
-        if (n_channels > 8 && !wide_groups) {              // one launch: both channel halves of a frame in one wave
+        if (n_channels > 8) {              // one launch: both channel halves of a frame in one wave
             const long long n_stw = n_sw * kLwChunksW;
             run([&](EmuCtx &ctx) {
                 switch (n_channels - 8) {
@@ -402,23 +402,14 @@ int emu_longwin(const float *in, float *out, const float *hist, const float *tra
             });
             return;
         }
-        for (int c0 = 0; c0 < n_channels; c0 += 8) {          // layouts of 9-16 channels: one pass per group of eight channels
-            LwParams q = p;
-            q.ch0 = c0; q.pair0 = c0 / 2;
-            const int cs = std::min(8, n_channels - c0);
-            const bool wide = n_channels > 8;
-            run([&](EmuCtx &ctx) {
-                auto go = [&](auto CS) {
-                    constexpr int c = decltype(CS)::value;
-                    if (wide) lw_split_tiles<EmuCtx, ra, c, true>(ctx, q, 0, 1, n_st);
-                    else lw_split_tiles<EmuCtx, ra, c, false>(ctx, q, 0, 1, n_st);
-                };
-                switch (cs) {
-                    case 1: go(LwIdx<1>{}); break; case 2: go(LwIdx<2>{}); break; case 3: go(LwIdx<3>{}); break; case 4: go(LwIdx<4>{}); break;
-                    case 5: go(LwIdx<5>{}); break; case 6: go(LwIdx<6>{}); break; case 7: go(LwIdx<7>{}); break; default: go(LwIdx<8>{}); break;
-                }
-            });
-        }
+        run([&](EmuCtx &ctx) {
+            switch (n_channels) {
+                case 1: lw_split_tiles<EmuCtx, ra, 1>(ctx, p, 0, 1, n_st); break; case 2: lw_split_tiles<EmuCtx, ra, 2>(ctx, p, 0, 1, n_st); break;
+                case 3: lw_split_tiles<EmuCtx, ra, 3>(ctx, p, 0, 1, n_st); break; case 4: lw_split_tiles<EmuCtx, ra, 4>(ctx, p, 0, 1, n_st); break;
+                case 5: lw_split_tiles<EmuCtx, ra, 5>(ctx, p, 0, 1, n_st); break; case 6: lw_split_tiles<EmuCtx, ra, 6>(ctx, p, 0, 1, n_st); break;
+                case 7: lw_split_tiles<EmuCtx, ra, 7>(ctx, p, 0, 1, n_st); break; default: lw_split_tiles<EmuCtx, ra, 8>(ctx, p, 0, 1, n_st); break;
+            }
+        });
     };
     if (R == 32) split(LwIdx<4>{}); else if (R == 64) split(LwIdx<8>{}); else split(LwIdx<16>{});
     const long long n_rt = n_sw * (R / 2);
