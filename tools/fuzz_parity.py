@@ -33,7 +33,13 @@ while time.time() < t_end:
     if rng.random() < 0.1: env["AW_PART_CMAC"] = "group"
     if rng.random() < 0.1: env["AW_PART_HERM"] = "0"
     if rng.random() < 0.15: env["AW_SPEC_SCRATCH_MB"] = str(int(rng.choice([1, 3, 16])))      # several stream chunks
-    for k in ("AW_WINDOW", "AW_PART_FWD", "AW_PART_CMAC", "AW_PART_HERM", "AW_SPEC_SCRATCH_MB"):
+    r3 = rng.random()                            # long-window kernels (tile_lw.hpp): forced window length, forced off, or the policy
+    if r3 < 0.3:
+        env["AW_LW"] = str(int(rng.choice([32, 64, 128])))
+        if rng.random() < 0.5: env["AW_LW_ROWS_PB"] = "2"
+        if rng.random() < 0.6: total = int(rng.integers(30000, 330000))          # calls that fill a window or more
+    elif r3 < 0.4: env["AW_LW"] = "0"
+    for k in ("AW_WINDOW", "AW_PART_FWD", "AW_PART_CMAC", "AW_PART_HERM", "AW_SPEC_SCRATCH_MB", "AW_LW", "AW_LW_ROWS_PB"):
         os.environ.pop(k, None)
     os.environ.update(env)
     n_tracks = int(rng.choice([2, 7, 14]))
@@ -49,7 +55,8 @@ while time.time() < t_end:
     if os.environ.get("AW_FUZZ_TRACE"):
         print("CASE", C, taps, S, total, bounds, env, n_tracks, flush=True)
     try:
-        sp = aw.Spatializer(aw.HRIR(h), lt, rt, n_streams=S)
+        ctx = aw.Context(0) if "AW_LW_ROWS_PB" in env else None        # (that knob is read when a context is created)
+        sp = aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=S, ctx=ctx) if ctx else aw.Spatializer(aw.HRIR(h), lt, rt, n_streams=S)
         info = sp.info()
         y = np.concatenate([sp.process(x[:, a:b]) for a, b in zip(bounds[:-1], bounds[1:])], axis=1)
         err = 0.0
