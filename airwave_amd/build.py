@@ -34,7 +34,9 @@ EXTRA_FLAGS = {"device/march_kernels.hip": [] if os.environ.get("AW_MARCH_SLP") 
                # the tile kernels too: SLP packs butterflies into v_pk_add/mul/fma_f32, which issue at HALF the rate of the scalar
                # forms on gfx950 (tools/ubench/valu_rate: 4.7 against 2.45 cycles) and need v_mov pairs on top — the FFT core alone
                # runs 3.03 instead of 3.78 us per transform without it (tools/ubench/fft_core), cfg 4 / 5 gain 10-13 %, cfg 3 4 %
-               "device/lw_kernels.hip": ["-fno-slp-vectorize"],
+               # long-window kernels: at their 16 waves per CU the first sub-FFT exchange in registers (permlane swaps) and plain
+               # single ds_read_b64 (no read2 fusion) measure 4.88 -> 4.72-4.75 ms on the cfg 3 rows kernel (the 8-wave tile kernels: +-1 %)
+               "device/lw_kernels.hip": ["-fno-slp-vectorize", "-DAW_XA_REG=1", "-DAW_LDS_ATOMIC_READS=1"],
                "device/kernels.hip": [] if os.environ.get("AW_KERNELS_SLP") else ["-fno-slp-vectorize"]}
 HEADERS = sorted(os.path.relpath(os.path.join(d, f), CSRC) for d, _, fs in os.walk(CSRC) for f in fs if f.endswith((".hpp", ".h"))) + [
     "../../include/airwave_hip.h",
