@@ -170,16 +170,22 @@ template <int CS, bool ALIGNED = (CS % 4 == 0)> AW_HD void lw_store_frame(float 
 
 // The small twiddle tables of the split / merge kernels live in LDS behind the exchange buffer (global loads of them — two
 // per output value — were most of the kernels' vector-memory instructions and their exposed latency: 174 of 330 per tile).
-template <int RA> constexpr int lw_small_elems() { return RA * 8 + 2 * RA * 64; }
-template <int RA, class Ctx>
+// FINE_LDS = false (merge kernel): the per-lane `fine` table stays in global memory (four coalesced loads per tile), so that the
+// kernel's LDS footprint — 64 KB of exchange buffer — leaves room for two workgroups per CU.
+template <int RA, bool FINE_LDS = true> constexpr int lw_small_elems() { return RA * 8 + RA * 64 + (FINE_LDS ? RA * 64 : 0); }
+template <int RA, bool FINE_LDS = true, class Ctx>
 AW_HD void lw_small_tables(Ctx &ctx, const LwParams &p, cf *sm) {            // [twr RA x 8][coarse RA x 64][fine RA x 64]; visible after the next barrier
     for (int i = ctx.tid(); i < RA * 8; i += kThreads) sm[i] = p.tw_r[i];
-    for (int i = ctx.tid(); i < RA * 64; i += kThreads) { sm[RA * 8 + i] = p.tw_coarse[i]; sm[RA * 8 + RA * 64 + i] = p.tw_fine[i]; }
+    for (int i = ctx.tid(); i < RA * 64; i += kThreads) {
+        sm[RA * 8 + i] = p.tw_coarse[i];
+        if constexpr (FINE_LDS) sm[RA * 8 + RA * 64 + i] = p.tw_fine[i];
+    }
 }
 // the four row twiddles base(ka) * {1, S1, S2, S3} of one ka
-template <int RA, class Ctx>
-AW_HD void lw_row_twiddles(Ctx &ctx, const cf *sm, int ka, int tc, int lane, const cf (&S)[3], cf (&tau)[4]) {
-    tau[0] = cmul(ctx.ld(sm + RA * 8 + ka * 64 + tc), ctx.ld(sm + RA * 8 + RA * 64 + ka * 64 + lane));
+template <int RA, bool FINE_LDS = true, class Ctx>
+AW_HD void lw_row_twiddles(Ctx &ctx, const LwParams &p, const cf *sm, int ka, int tc, int lane, const cf (&S)[3], cf (&tau)[4]) {
+    const cf fine = FINE_LDS ? ctx.ld(sm + RA * 8 + RA * 64 + ka * 64 + lane) : p.tw_fine[ka * 64 + lane];
+    tau[0] = cmul(ctx.ld(sm + RA * 8 + ka * 64 + tc), fine);
 #pragma unroll
     for (int m = 1; m < 4; ++m) tau[m] = cmul(tau[0], S[m - 1]);
 }
@@ -277,8 +283,8 @@ AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
                 for (int j1 = 1; j1 < 8; ++j1) v[j1] = cmul(v[j1], ctx.ld(sm + ka * 8 + j1));
                 fft8<false>(v);
                 cf tlo[4], tup[4];
-                lw_row_twiddles<RA>(ctx, sm, ka, tc, lane, S, tlo);
-                lw_row_twiddles<RA>(ctx, sm, RA - 1 - ka, tc, lane, S, tup);
+                lw_row_twiddles<RA>(ctx, p, sm, ka, tc, lane, S, tlo);
+                lw_row_twiddles<RA>(ctx, p, sm, RA - 1 - ka, tc, lane, S, tup);
                 const bool real_pair = (CS & 1) && pair == NP - 1;        // (an odd layout's last group carries its real last channel)
                 cf *dst = spec_sw + (long long)(pair0 + pair) * p.N + t;
 #pragma unroll
@@ -401,8 +407,8 @@ AW_HD void lw_split_wide_tiles(Ctx &ctx, const LwParams &p, long long first, lon
                 for (int j1 = 1; j1 < 8; ++j1) v[j1] = cmul(v[j1], ctx.ld(sm + ka * 8 + j1));
                 fft8<false>(v);
                 cf tlo[4], tup[4];
-                lw_row_twiddles<RA>(ctx, sm, ka, tc64, lane64, S, tlo);
-                lw_row_twiddles<RA>(ctx, sm, RA - 1 - ka, tc64, lane64, S, tup);
+                lw_row_twiddles<RA>(ctx, p, sm, ka, tc64, lane64, S, tlo);
+                lw_row_twiddles<RA>(ctx, p, sm, RA - 1 - ka, tc64, lane64, S, tup);
                 const bool live = pair < nph;                                   // per lane half
                 const bool real_pair = (CS1 & 1) && half == 1 && pair == NP1 - 1;
                 cf *dst = spec_sw + (long long)(4 * half + pair) * p.N + t;
@@ -645,7 +651,7 @@ AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long
 
 // ---- kernel 3: merge -------------------------------------------------------------------------------------------------
 // Tile id = (stream, window) * 64 + tc.  512 threads.  LDS: [RA][8][64] complex.
-template <int RA> constexpr int lw_merge_lds_elems() { return RA * 8 * 64 + lw_small_elems<RA>(); }
+template <int RA> constexpr int lw_merge_lds_elems() { return RA * 8 * 64 + lw_small_elems<RA, false>(); }
 
 template <class Ctx, int RA>
 AW_HD void lw_merge_tiles(Ctx &ctx, const LwParams &p, long long first, long long step, long long end) {
@@ -654,7 +660,7 @@ AW_HD void lw_merge_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
     const int lane = ctx.lane(), wave = ctx.wave();
     cf *lds = ctx.lds();
     cf *sm = lds + RA * 8 * 64;
-    lw_small_tables<RA>(ctx, p, sm);
+    lw_small_tables<RA, false>(ctx, p, sm);
     if (first < end) ctx.barrier();
     for (long long id = first; id < end; id += step) {
         const long long sw = (long long)((unsigned long long)id / (unsigned)kLwChunks);
@@ -679,8 +685,8 @@ AW_HD void lw_merge_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
             cf S[3], tlo[4], tup[4];
 #pragma unroll
             for (int m = 0; m < 3; ++m) S[m] = p.tw_step[m * kLwM + t];
-            lw_row_twiddles<RA>(ctx, sm, ka, tc, lane, S, tlo);
-            lw_row_twiddles<RA>(ctx, sm, RA - 1 - ka, tc, lane, S, tup);
+            lw_row_twiddles<RA, false>(ctx, p, sm, ka, tc, lane, S, tlo);
+            lw_row_twiddles<RA, false>(ctx, p, sm, RA - 1 - ka, tc, lane, S, tup);
 #pragma unroll
             for (int kb = 0; kb < 8; ++kb) {          // rows of the lower half: s1 of row pair k1; upper half: s2 of row pair R-1-k1, conj-reversed
                 const cf v = cmulc(g[kb], kb < 4 ? tlo[kb & 3] : tup[(7 - kb) & 3]);
