@@ -120,7 +120,9 @@ AW_API int32_t aw_spatializer_channel_count(const aw_spatializer *sp);
 /* Introspection for benches/tests: 0 fft length, 1 hop, 2 partitions, 3 path (0 fused, 1 partitioned),
  * 4 history frames, 5 output frames produced by the launch that aw_spatializer_kernel_time() times
  * (the interior-tile launch of the last call; the few boundary tiles are a second, untimed launch),
- * 6 bytes of grow-only internal device buffers currently allocated (sized by aw_spatializer_reserve or by the largest call so far). */
+ * 6 bytes of grow-only internal device buffers currently allocated (sized by aw_spatializer_reserve or by the largest call so far),
+ * 7 rows R of the last call's windows when it ran on the long-window kernels (windows of R x 4096 frames; 0: it ran on the
+ *   fused / partitioned kernels that 0-3 describe).  The kernel set is chosen per call; results do not depend on it. */
 AW_API int64_t aw_spatializer_info(const aw_spatializer *sp, int32_t what);
 /* Average device time of the dominant kernel over the launches since the last call (HIP events
  * on the context stream); used for bench.py's roofline object.  Returns launches counted. */
