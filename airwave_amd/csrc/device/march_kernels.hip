@@ -35,7 +35,7 @@ template <int PQ, int LG, bool ACC>
 __global__ void __launch_bounds__(kMarchThreads, AW_MARCH_MIN_WAVES) aw_part_march_kernel(TileParams p, int q0, int n_streams) {
     const int g = (int)(blockIdx.x * kMarchThreads + threadIdx.x);
     const int j_raw = g / LG, pl = g % LG;
-    const bool real = j_raw < kMarchSlots;               // the last workgroup's spare lanes repeat the last slot and store nothing
+    const bool real = j_raw < kMarchSlots;               // the last workgroup's spare lanes repeat the last slot: whole lane groups that compute and (first pass) store the same values to the same addresses as the real one
     const int j = real ? j_raw : kMarchSlots - 1;
     const long long s0 = (long long)blockIdx.y * AW_MARCH_STREAMS;
     const long long s1 = s0 + AW_MARCH_STREAMS < n_streams ? s0 + AW_MARCH_STREAMS : n_streams;

@@ -732,9 +732,11 @@ AW_HD void tiles_part_forward(Ctx &ctx, const TileParams &p, long long first, lo
     auto load = [&](const float *in_s, const float *hist_s, long long f0, int t, int c0, float (&raw)[16][kBatchCh]) {
         if constexpr (MODE == 2) load_batch_head<CS>(p, in_s, hist_s, f0, t, c0, raw);
         else load_batch<CS, MODE == 1>(p, in_s, hist_s, f0, t, c0, raw);
-        // Odd channel counts: the whole-frame vector loads put the next frame's first sample into the padding lane of
-        // the last pair.  Zero tables cancel it, but the Hermitian shortcut (herm_last) needs that pair's input REAL.
-        if constexpr (MODE != 0 && CS > 0 && (CS & 1)) {
+        // Frames that are not whole float4s: the whole-frame vector loads put the next frame's first samples into the padding lanes
+        // of the last batch.  Zero tables would cancel finite values, but (a) the Hermitian shortcut (herm_last) needs an odd layout's
+        // last pair REAL and (b) the frame after a stream's last history frame belongs to the NEXT stream: a NaN there must not
+        // reach this stream (0 x NaN) — streams are independent in the reference.  So the padding lanes are zeroed.
+        if constexpr (MODE != 0 && CS > 2 && CS % 4 != 0) {
             if (c0 + kBatchCh > CS) {                              // uniform: the last batch
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
@@ -769,7 +771,7 @@ AW_HD void tiles_part_forward(Ctx &ctx, const TileParams &p, long long first, lo
         if constexpr (kWhole) {
             if constexpr (MODE == 2) load_batch2_head<CS>(p, in_w, p.hist + w.stream * (long long)p.hist_len * Cn, fw, t, raw, raw_b);
             else load_batch2<CS>(in_w, fw, t, raw, raw_b);
-            if constexpr ((CS & 1) != 0) {                  // the padding lane of an odd layout's last pair must be a real zero (herm_last)
+            if constexpr (CS % 4 != 0) {                    // the padding lanes of the last batch must be real zeros (herm_last; no NaN from the next stream's history)
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
 #pragma unroll

@@ -375,3 +375,25 @@ def test_random_call_splits_on_every_path(aw, oracle, taps, channels, seed):
         parts.append(sp.process(np.ascontiguousarray(x[:, pos:pos + n])))
         pos += n
     assert np.max(np.abs(np.concatenate(parts, axis=1) - whole)) <= 3e-6 * np.abs(whole).max()
+
+
+@pytest.mark.parametrize("channels", [3, 5, 6, 7])
+def test_streams_stay_independent_when_a_neighbour_holds_nan(aw, oracle, monkeypatch, channels):
+    """Layouts whose frames are not whole float4s are read with 16-byte loads that run into the next frame — after a stream's last
+    history frame that is the NEXT stream's history.  A NaN there must not reach this stream (the reference's streams share nothing):
+    partitioned kernels (head windows read the history) and the long-window kernels."""
+    taps, S, F = 20000, 3, 9000
+    h = oracle.synth_hrir(14, taps, seed=5)
+    lt = (np.arange(channels) % 14).astype(np.int32)
+    rt = ((np.arange(channels) + 7) % 14).astype(np.int32)
+    x = oracle.synth_input(S, 2 * F, channels, seed=3)
+    bad = x.copy()
+    bad[1] = np.nan                                    # stream 1 is poisoned from the first call on
+    for lw in ("0", "32"):
+        monkeypatch.setenv("AW_LW", lw)
+        sp = aw.Spatializer(aw.HRIR(h), lt, rt, n_streams=S)
+        sp.process(bad[:, :F])
+        y = sp.process(bad[:, F:]) if lw == "0" else sp.process(np.ascontiguousarray(np.concatenate([bad[:, F:]] * 8, axis=1)))[:, :F]
+        for s in (0, 2):
+            assert np.isfinite(y[s]).all(), (lw, s)
+            assert oracle.peak_rel_error(y[s], oracle.spatialize_f64(x[s], h, lt, rt)[F:]) < TOL, (lw, s)
