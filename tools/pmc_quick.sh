@@ -12,8 +12,8 @@ agg=collections.defaultdict(list)
 for f in glob.glob(o+"/**/*counter_collection.csv",recursive=True):
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"].split("(")[0].replace("void awk::","").replace("awk::","")
-        if k.startswith("aw_part") or k.startswith("aw_fused") or k.startswith("aw_eq"): agg[(k,r["Counter_Name"])].append(float(r["Counter_Value"]))
+        if k.startswith("aw_part") or k.startswith("aw_fused") or k.startswith("aw_eq") or k.startswith("aw_lw"): agg[(k,r["Counter_Name"])].append(float(r["Counter_Value"]))
 for (k,c),vals in sorted(agg.items()):
-    print(f"{v:8s} {k:44s} {c:20s} n={len(vals):3d} {sum(vals)/3*(128 if "RD" in c else 64)/1e9:8.3f} ~GB/step (approximate: every read request counted as 128 B, every write as 64 B, 3 steps assumed; tools/profile_collect2.py sizes requests by class)")
+    print(f"{v:8s} {k:44s} {c:20s} n={len(vals):3d} {sum(vals)/3*(128 if 'RD' in c else 64)/1e9:8.3f} ~GB/step (approximate: every read request counted as 128 B, every write as 64 B, 3 steps assumed; tools/profile_collect2.py sizes requests by class)")
 PY
 done
