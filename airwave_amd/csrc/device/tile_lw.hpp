@@ -43,12 +43,6 @@ constexpr int kLwInner = kLwM / kSub;       // 8 inner rows of 512 per row: radi
 constexpr int kLwTw = 64;                   // frames t per split / merge tile: one wave wide
 constexpr int kLwChunks = kLwM / kLwTw;     // 64 tiles per (stream, window)
 
-#ifndef AW_LW_TAB_EARLY
-#define AW_LW_TAB_EARLY 0           // rows kernel: table entries of a pair fetched before its sub-FFTs
-#endif
-#ifndef AW_LW_PREFETCH_EARLY
-#define AW_LW_PREFETCH_EARLY 0      // rows kernel, fetch of the next tile's first batch: 0 under the final pass, 1 right after the last pass 1, 2 before the inverse sub-FFTs
-#endif
 
 struct alignas(16) LwTab { cf t0, t1, t2, t3; };
 
@@ -555,10 +549,8 @@ AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long
                     }
                 }
             }
-            // the next batch's rows — of this tile or, after the last batch, of the workgroup's next tile (the last tile re-reads
-            // its own) — travel under this batch's sub-FFTs (and, for the next tile, under the whole inverse transform)
+            // the next batch's rows travel under this batch's sub-FFTs
             if constexpr (b + 1 < NB) load_batch(vid, b + 1);
-            else if constexpr (AW_LW_PREFETCH_EARLY == 1) load_batch(vid + step < end ? vid + step : vid, 0);
             ctx.barrier();
 #pragma unroll
             for (int h = 0; h < PB; ++h) {
@@ -587,11 +579,6 @@ AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long
                     }
                 } else {
                     cf z[2][8];
-#if AW_LW_TAB_EARLY
-                    LwTab Tq[8];          // issued before the sub-FFTs: the L2 round trip hides under them (64 more live registers)
-#pragma unroll
-                    for (int kc = 0; kc < 8; ++kc) Tq[kc] = tb[64 * kc];
-#endif
                     ctx.template ld8x2<64>(z[0], row0 + lane, z[1], row1 + lane);
                     ctx.wave_sync();
                     sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);
@@ -599,8 +586,6 @@ AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long
                     for (int kc = 0; kc < 8; ++kc) {
 #ifdef AW_LW_ABL_ROWS_NOTAB       // timing ablation only (wrong results)
                         const LwTab T{mk(1.f, 0.5f * lane), mk(0.3f, 0.1f), mk(0.2f * pair, 0.7f), mk(0.25f * kc, 1.f * wave)};
-#elif AW_LW_TAB_EARLY
-                        const LwTab T = Tq[kc];
 #else
                         const LwTab T = tb[64 * kc];
 #endif
@@ -617,12 +602,13 @@ AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long
         {
             cf *row0 = buf0 + wave * kRowStride, *row1 = buf0 + (8 + wave) * kRowStride;
             ctx.wave_sync();                                  // this wave's forward reads of its rows are complete
-            if constexpr (AW_LW_PREFETCH_EARLY == 2) load_batch(vid + step < end ? vid + step : vid, 0);      // under the whole inverse transform
             sub_fft512x2<true>(ctx, wacc, row0, row1, twa, twb, lane);
 #pragma unroll
             for (int kc = 0; kc < 8; ++kc) { row0[lane + 64 * kc] = wacc[0][kc]; row1[lane + 64 * kc] = wacc[1][kc]; }
         }
-        if constexpr (AW_LW_PREFETCH_EARLY == 0) load_batch(vid + step < end ? vid + step : vid, 0);      // the next tile's first batch under the final pass only
+        // the next tile's first batch travels under the final pass only: fetched a batch earlier — after the last pass 1 or before the
+        // inverse sub-FFTs — it costs 104-540 B of scratch per thread and measures slower (5.6 -> 6.7 ms on cfg 3)
+        load_batch(vid + step < end ? vid + step : vid, 0);
         ctx.barrier();
         {
             cf pw[8];
