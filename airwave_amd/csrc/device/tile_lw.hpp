@@ -1,12 +1,13 @@
-// tile_lw.hpp — the LONG-WINDOW path for long HRIRs (cfg 3: 32 768 taps): single-partition overlap-save on windows of
-// N = R x 4096 frames (R = 32, 64, 128: N = 131 072 ... 524 288), the transform run as a four-step FFT through HBM scratch.
+// tile_lw.hpp — the LONG-WINDOW path for long calls (cfg 3's 32 768-tap HRIRs; past a measured HRIR length every layout,
+// runtime.cpp lw_choose): single-partition overlap-save on windows of N = R x 4096 frames (R = 32, 64, 128: N = 131 072 ...
+// 524 288), the transform run as a four-step FFT through HBM scratch.
 //
 // Replaces, for a whole window of one stream at once, what ConvolutionEngine.process does per 512-frame block with a
 // frequency-domain delay line (Airwave/ConvolutionEngine.swift:232-367) and what RealtimeAudioProcessor.processPendingBlock
 // sums over speakers (Airwave/RealtimeAudioProcessor.swift:141-172).  Against the partitioned path of tile_ols.hpp /
 // tile_march.hpp (B = 4096, 2x overlap, spectra of every window written and read once per partition step) a window
 // N >> taps overlaps by N / (N - taps) only (1.07 for 10 s streams on N = 524 288) and needs no delay line at all:
-// 115 instead of 203 bytes of fabric traffic per output frame on cfg 3.
+// 119 instead of 203 bytes of fabric traffic per output frame on cfg 3, measured.
 //
 // Odd-frequency transform.  All spectra are sampled at k + 1/2:  X[k] = sum_n x[n] w_N^{n (k + 1/2)}, w_N = exp(-2 pi i / N).
 // The wrap-around of the product then carries a minus sign (negacyclic), which overlap-save discards anyway, and the
@@ -42,7 +43,6 @@ constexpr int kLwM = 4096;                  // row length (frames between the R 
 constexpr int kLwInner = kLwM / kSub;       // 8 inner rows of 512 per row: radix of the row kernel's pass 1
 constexpr int kLwTw = 64;                   // frames t per split / merge tile: one wave wide
 constexpr int kLwChunks = kLwM / kLwTw;     // 64 tiles per (stream, window)
-
 
 struct alignas(16) LwTab { cf t0, t1, t2, t3; };
 
