@@ -112,3 +112,35 @@ def test_reserved_spatializer_never_reallocates(oracle, monkeypatch):
     ref = oracle.spatialize_f64(np.concatenate([flat[s * n:(s + 1) * n].cpu().numpy() for n in sizes]), h, lt, rt)
     n = sizes[-1]
     assert oracle.peak_rel_error(y.view(-1, 2)[s * n:(s + 1) * n].cpu().numpy(), ref[-n:]) < TOL
+
+
+@pytest.mark.parametrize("fmt", ["float32", "pcm16"])
+def test_imported_long_tap_wav_through_preset_activation(aw, oracle, tmp_path, fmt):
+    """BASELINE cfg 3 reads "HeSuVi 14ch 48kHz -> imported .wav HRIR (long tap)": a 14-track 32768-frame WAV written here goes through
+    the product's own reader and activatePreset (HRIRManager.swift:347-446: load -> hesuvi14 map -> engines), and a long call of the
+    activated renderer network runs on the long-window kernels; the oracle reads the same file."""
+    import struct
+    taps, C = 32768, 14
+    h = oracle.synth_hrir(C, taps, seed=1234)
+    h = (h / np.abs(h).max() * 0.9).astype(np.float32)
+    inter = np.ascontiguousarray(h.T)                                  # [frame][track]
+    if fmt == "float32":
+        data, tag, bits = inter.astype("<f4").tobytes(), 3, 32
+    else:
+        data, tag, bits = np.round(inter * 32767.0).astype("<i2").tobytes(), 1, 16
+    block = C * bits // 8
+    body = b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, tag, C, 48000, 48000 * block, block, bits) + b"data" + struct.pack("<I", len(data)) + data
+    path = str(tmp_path / f"long_{fmt}.wav")
+    open(path, "wb").write(b"RIFF" + struct.pack("<I", len(body)) + body)
+    speakers = ["FL", "FR", "FC", "BL", "BR", "SL", "SR"]
+    layout = aw.InputLayout(speakers, "7 speakers")
+    mgr = aw.HRIRManager()
+    sp = mgr.activatePreset(path, 48000.0, layout, n_streams=2)
+    assert mgr.isReady and sp.info()["path"] == 1
+    x = oracle.synth_input(2, 200000, 7, seed=4)
+    y = sp.process(x)
+    assert sp.info()["long_window_rows"] == 64
+    tracks, lt, rt = oracle.assemble_tracks(oracle.wav_load(path), speakers)
+    assert tracks.shape == (14, taps)
+    for s in range(2):
+        assert oracle.peak_rel_error(y[s], oracle.spatialize_f64(x[s], tracks, lt, rt)) < TOL
