@@ -80,16 +80,21 @@ def build(force: bool = False, verbose: bool = False, stamps: bool = False, defi
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     common = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"--offload-arch={ARCH}",
               "-Wall", "-Wno-unused-result", "-ffp-contract=fast"] + [f"-D{d}" for d in defines] + os.environ.get("AW_EXTRA_HIPCC_FLAGS", "").split()
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         spath = os.path.join(CSRC, src)
         opath = os.path.join(OBJ, src.replace("/", "_") + ".o")
         objs.append(opath)
         if (force and (not only or src in only)) or (src in only) or _stale(opath, [spath] + hdrs):
-            cmd = [hipcc()] + common + EXTRA_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", spath, "-o", opath]
+            jobs.append([hipcc()] + common + EXTRA_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", spath, "-o", opath])
+    if jobs:          # the translation units are independent: a few hipcc processes side by side (each peaks at ~2 GB)
+        from concurrent.futures import ThreadPoolExecutor
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
+        with ThreadPoolExecutor(max_workers=int(os.environ.get("AW_BUILD_JOBS", "4"))) as ex:
+            list(ex.map(run, jobs))
     if force or _stale(OUT, objs):
         cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs
         if verbose:
