@@ -632,7 +632,7 @@ static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, flo
 // Per call: windows of N = R x 4096 frames, R in {32, 64, 128}, hop = N - hist_len (hist_len = P x 4096 >= taps, the history the
 // partitioned kernels keep too, so both kernel sets serve the same spatializer and the choice is free per call).
 // Cost model (fabric bytes): the long-window kernels move 12 C + 24 bytes per WINDOW frame (input + rows
-// written, rows read + s1/s2 written, s1/s2 read + stereo out), the partitioned ones ~29 C bytes per OUTPUT frame.
+// written, rows read + s1/s2 written, s1/s2 read + stereo out); what they are compared with: below.
 // Path-0 spatializers (HRIRs one fused window can hold): HRIR length from which the long-window kernels measure faster than
 // the fused 8192- / 16384-frame tiles on long calls (tools/lw_sweep.py, 128 streams x 10 s); 1 << 30 = never.
 //   G frames/s fused / long-window:  C=1  8640 taps 139 / 99, 12288: 80 / 107;   C=2  8640: 94 / 81, 12288: 55 / 81;   C=3  8640: 69 / 61, 12288: 41 / 61;
@@ -671,12 +671,25 @@ static int lw_choose(const aw_spatializer *sp, int64_t frames, bool for_reserve 
         if (!best || cost < best_cost) { best = R; best_cost = cost; }
     }
     if (!best || sp->lw_mode > 0) return best;
-    // path 0: past the measured crossover (above) the long call only has to fill its windows; path 1: against the partitioned kernels
-    const double part_cost = sp->path == 0 ? 1.25 * (double)frames * (12.0 * C + 24.0) : (double)frames * 29.0 * C;
     const long long N = (long long)best * awk::kLwM, hop = N - sp->hist_len;
     const long long row_tiles = (long long)sp->n_streams * ((frames + hop - 1) / hop) * (best / 2);
     if (row_tiles < 32) return 0;        // (measured down to ONE stream x 10 s, 64 row tiles: 7 channels x 32768 taps 8.2 against 3.9 G frames/s partitioned)
-    return best_cost < part_cost ? best : 0;
+    double other_cost;
+    if (sp->path == 0) {
+        // past the measured crossover (above) the long call only has to fill its windows to 80 %
+        other_cost = 1.25 * (double)frames * (12.0 * C + 24.0);
+    } else {
+        // Partitioned kernels, in the same currency (fabric-byte equivalents at the rate both kernel sets reach): a long call costs
+        // ~110 + 13 C bytes per output frame up to eight channels (measured 20-23 G frames/s for C = 7, 29 for C = 2; the one-pair
+        // forward kernels of wider layouts ~30 C), 86 % of it per input WINDOW (forward transform + marched CMAC) — and a call of
+        // n blocks transforms n + P - 1 windows, which is what makes short calls expensive there — and 14 % per output block.
+        // tools/lw_calls_sweep.py (G frames/s, partitioned / long-window, 128 streams x 7 channels x 32768 taps): 16 384 frames
+        // 6.2 / 5.9, 32 768: 9.9 / 10.9, 49 152: 11.5 / 15.6, 65 536: 13.1 / 20.0, 131 072: 15.8 / 21.0, 480 000: 20.0 / 35.8.
+        const double b_part = C <= 8 ? 110.0 + 13.0 * C : 30.0 * C;
+        const long long blocks = (frames + sp->hop - 1) / sp->hop;
+        other_cost = (double)sp->hop * b_part * (0.86 * (double)(blocks + sp->partitions - 1) + 0.14 * (double)blocks);
+    }
+    return best_cost < other_cost ? best : 0;
 }
 
 static aw_status lw_get_plan(aw_spatializer *sp, int R, const aw_spatializer::LwPlan **out) {
