@@ -319,6 +319,11 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
     if (sp->lw_mode != 0) {
         sp->lw_tracks = hrir->tracks; sp->lw_n_tracks = hrir->n_tracks;
         sp->lw_left.assign(left_track, left_track + n_in); sp->lw_right.assign(right_track, right_track + n_in);
+        if (n_in > 8) {                  // 32 floats for the wide split kernel's padded copy of a call's very last frame (tile_lw.hpp)
+            hipError_t et = hipMalloc(reinterpret_cast<void **>(&sp->d_tail), 32 * sizeof(float));
+            if (et == hipSuccess) et = hipMemsetAsync(sp->d_tail, 0, 32 * sizeof(float), ctx->stream);
+            if (et != hipSuccess) { aw_spatializer_destroy(sp); return awr::hip_fail(et, "spatializer setup"); }
+        }
     }
     std::vector<awk::cf2> tab, all;
     if (sp->fused2) {
@@ -710,8 +715,12 @@ static aw_status lw_get_plan(aw_spatializer *sp, int R, const aw_spatializer::Lw
     if (e == hipSuccess) e = up(t.step.data(), t.step.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_step));
     if (e == hipSuccess) e = up(t.tw_r.data(), t.tw_r.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_tw_r));
     if (e == hipSuccess) e = up(t.tw1m.data(), t.tw1m.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_tw1m));
-    sp->lw_plans.push_back(pl);             // owned (and freed) by the spatializer even when an upload failed half way
-    if (e != hipSuccess) return awr::hip_fail(e, "long-window tables");
+    if (e != hipSuccess) {                  // nothing half-built stays behind: the next call tries again (or takes the partitioned kernels)
+        for (void *d : {(void *)pl.d_tab, (void *)pl.d_coarse, (void *)pl.d_fine, (void *)pl.d_step, (void *)pl.d_tw_r, (void *)pl.d_tw1m})
+            if (d) (void)hipFree(d);
+        return awr::hip_fail(e, "long-window tables");
+    }
+    sp->lw_plans.push_back(pl);
     *out = &sp->lw_plans.back();
     return AW_OK;
 }
@@ -762,11 +771,7 @@ static aw_status sp_process_longwin(aw_spatializer *sp, int R, const float *in, 
         p.persistent_wgs = sp->ctx->cfg.persistent_wgs;
         p.rows_pairs_per_batch = sp->ctx->cfg.lw_rows_pb;
         p.n_streams = ns;
-        if (sp->n_channels > 8) {        // the wide split kernel reads the last frame of the last stream from a padded copy
-            if (!sp->d_tail) {
-                AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sp->d_tail), 32 * sizeof(float)));
-                AW_HIP_TRY(hipMemsetAsync(sp->d_tail, 0, 32 * sizeof(float), sp->ctx->stream));
-            }
+        if (sp->n_channels > 8) {        // the wide split kernel reads the last frame of the last stream from a padded copy (allocated at create)
             AW_HIP_TRY(hipMemcpyAsync(sp->d_tail, p.in + ((size_t)ns * frames - 1) * sp->n_channels, sp->n_channels * sizeof(float),
                                       hipMemcpyDeviceToDevice, sp->ctx->stream));
             p.tail = sp->d_tail;
