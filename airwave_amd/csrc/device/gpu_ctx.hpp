@@ -144,10 +144,14 @@ struct GpuCtx {
     __device__ __forceinline__ void xswap32(unsigned &lo, unsigned &hi, int bit) const {
         if (bit == 5) { auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false); lo = r[0]; hi = r[1]; }
         else if (bit == 4) { auto r = __builtin_amdgcn_permlane16_swap(lo, hi, false, false); lo = r[0]; hi = r[1]; }
-        else {
+        else if (bit == 3) {
             const unsigned t = hi;
             hi = __builtin_amdgcn_update_dpp(hi, lo, 0x128, 0xf, 0x3, false);   // lanes 0-7 of every row: hi <- lo of lane + 8
             lo = __builtin_amdgcn_update_dpp(lo, t, 0x128, 0xf, 0xc, false);    // lanes 8-15: lo <- old hi of lane - 8
+        } else {                                                                // bit == 2: partner = lane ^ 4, bank-masked row shifts by 4
+            const unsigned t = hi;
+            hi = __builtin_amdgcn_update_dpp(hi, lo, 0x104, 0xf, 0x5, false);   // row_shl:4, lanes 0-3 / 8-11 of every row: hi <- lo of lane + 4
+            lo = __builtin_amdgcn_update_dpp(lo, t, 0x114, 0xf, 0xa, false);    // row_shr:4, lanes 4-7 / 12-15: lo <- old hi of lane - 4
         }
     }
     __device__ __forceinline__ void xswap(cf &lo, cf &hi, int bit) const {

@@ -160,6 +160,8 @@ hipError_t prepare_kernels(LaunchCfg *cfg) {
         if (const char *e6 = getenv("AW_EQ_EAR_SPLIT")) cfg->eq_ear_split = atoi(e6);
         if (const char *e7 = getenv("AW_LW_ROWS_PB")) cfg->lw_rows_pb = atoi(e7) == 2 ? 2 : 1;
         if (const char *e8 = getenv("AW_HOP_ALIGN")) cfg->hop_align = atoi(e8);
+        if (const char *e9 = getenv("AW_LW_ROWS_FORM")) cfg->lw_rows_form = atoi(e9) == 8 ? 8 : 16;
+        if (const char *e10 = getenv("AW_LW_ROWS16_WGS")) cfg->lw_rows16_wgs = atoi(e10) >= 1 && atoi(e10) <= 4 ? atoi(e10) : cfg->lw_rows16_wgs;
     }
 #define AW_SET_VEC(CS, NP)                                                                           \
     if (e == hipSuccess)                                                                             \

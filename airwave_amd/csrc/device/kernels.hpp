@@ -7,6 +7,7 @@
 #include "tile_ols2.hpp"
 #include "tile_march.hpp"
 #include "tile_lw.hpp"
+#include "tile_lw16.hpp"
 
 namespace awk {
 
@@ -63,7 +64,9 @@ struct LaunchCfg {
     int debug_occupancy = 0;      // AW_DEBUG_OCCUPANCY
     int stamp_thread = 0;         // AW_STAMP_THREAD (diagnostic builds)
     int eq_ear_split = -1;        // AW_EQ_EAR_SPLIT: -1 automatic, 0 / 1 forced
-    int lw_rows_pb = 1;           // long-window rows kernel: channel pairs per batch (AW_LW_ROWS_PB; 1 = one exchange buffer, two workgroups per CU)
+    int lw_rows_pb = 1;           // long-window rows kernel, 8-point forms: channel pairs per batch (AW_LW_ROWS_PB; 1 = one exchange buffer, two workgroups per CU)
+    int lw_rows_form = 16;        // long-window rows kernel: 16 = 256-thread workgroups, 16 points of one row per thread (tile_lw16.hpp); 8 = the 8-point forms (AW_LW_ROWS_FORM)
+    int lw_rows16_wgs = 3;        // workgroups per CU of the 16-point rows kernel's persistent grid (AW_LW_ROWS16_WGS)
     int hop_align = 64;           // fused windows start on multiples of this many frames (AW_HOP_ALIGN; 1 = off)
 };
 hipError_t prepare_kernels(LaunchCfg *cfg);   // fills cfg from the current device + environment; sets the dynamic-LDS attribute on every tile kernel

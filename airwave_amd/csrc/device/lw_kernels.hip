@@ -3,6 +3,7 @@
 #include "kernels.hpp"
 #include "gpu_ctx.hpp"
 #include "tile_lw.hpp"
+#include "tile_lw16.hpp"
 
 namespace awk {
 
@@ -47,6 +48,22 @@ __global__ void __launch_bounds__(kThreads, 4) aw_lw_rows1_kernel(LwParams p, lo
     const int n_rp = p.R / 2;
     const int n_rp_x = (n_rp - xcd + 7) / 8;
     lw_rows_tiles<GpuCtx, NP, REAL_LAST, 1>(ctx, p, (long long)slot, (long long)per_xcd_wg, (long long)n_rp_x * n_sw, n_sw, xcd, 8);
+}
+
+// 16 points of one row per thread, 256-thread workgroups (tile_lw16.hpp); the same XCD pinning of row pairs
+#ifndef AW_R16_MIN_WAVES
+#define AW_R16_MIN_WAVES 3
+#endif
+template <int NP, bool REAL_LAST>
+__global__ void __launch_bounds__(kR16Threads, AW_R16_MIN_WAVES) aw_lw_rows16_kernel(LwParams p, long long n_sw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
+    const int g = (int)gridDim.x, b = (int)blockIdx.x;
+    const int xcd = b % 8, slot = b / 8;
+    const int per_xcd_wg = (g - xcd + 7) / 8;
+    const int n_rp = p.R / 2;
+    const int n_rp_x = (n_rp - xcd + 7) / 8;
+    lw_rows16_tiles<GpuCtx, NP, REAL_LAST>(ctx, p, (long long)slot, (long long)per_xcd_wg, (long long)n_rp_x * n_sw, n_sw, xcd, 8);
 }
 
 template <int RA>
@@ -96,6 +113,15 @@ hipError_t prepare_lw_kernels() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLwRows1LdsBytes);
     AW_SET(1) AW_SET(2) AW_SET(3) AW_SET(4) AW_SET(5) AW_SET(6) AW_SET(7) AW_SET(8)
 #undef AW_SET
+#define AW_SET(NP)                                                                                     \
+    if (e == hipSuccess)                                                                               \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_rows16_kernel<NP, false>),       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kR16LdsBytes);             \
+    if (e == hipSuccess)                                                                               \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_rows16_kernel<NP, true>),        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kR16LdsBytes);
+    AW_SET(1) AW_SET(2) AW_SET(3) AW_SET(4) AW_SET(5) AW_SET(6) AW_SET(7) AW_SET(8)
+#undef AW_SET
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_merge_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lw_merge_lds_bytes<4>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_merge_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lw_merge_lds_bytes<8>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_merge_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lw_merge_lds_bytes<16>());
@@ -135,6 +161,26 @@ hipError_t launch_lw_rows(const LwParams &p, int n_streams, hipStream_t stream, 
     const long long n_tiles = n_sw * (p.R / 2);
     if (n_tiles <= 0) return hipSuccess;
     if (n_tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (p.rows_form == 16) {
+        if (!p.tab16 || !p.tw2) return hipErrorInvalidValue;
+        const int per_cu = p.rows16_wgs >= 1 && p.rows16_wgs <= 4 ? p.rows16_wgs : 3;
+        unsigned grid16 = lw_grid((n_tiles + 7) / 8 * 8, p, per_cu) / 8 * 8;
+        if (grid16 < 8) grid16 = 8;
+        if (tm) tm->begin();
+        const bool real16 = p.real_last != 0;
+        switch (p.n_pairs) {
+#define AW_CASE(NP)                                                                                                       \
+        case NP:                                                                                                          \
+            if (real16) hipLaunchKernelGGL((aw_lw_rows16_kernel<NP, true>), dim3(grid16), dim3(kR16Threads), kR16LdsBytes, stream, p, n_sw);   \
+            else hipLaunchKernelGGL((aw_lw_rows16_kernel<NP, false>), dim3(grid16), dim3(kR16Threads), kR16LdsBytes, stream, p, n_sw);         \
+            break;
+        AW_CASE(1) AW_CASE(2) AW_CASE(3) AW_CASE(4) AW_CASE(5) AW_CASE(6) AW_CASE(7) AW_CASE(8)
+#undef AW_CASE
+        default: return hipErrorInvalidValue;
+        }
+        if (tm) tm->end("aw_lw_rows_kernel");
+        return hipGetLastError();
+    }
     // 8 XCD groups: a grid that is a multiple of 8 (every group has the same number of workgroups), at least 8
     const bool one = p.rows_pairs_per_batch == 1 || p.n_pairs > 4;          // the two-pairs-per-batch form exists for up to four pairs
     unsigned grid = lw_grid((n_tiles + 7) / 8 * 8, p, one ? 2 : 1) / 8 * 8;

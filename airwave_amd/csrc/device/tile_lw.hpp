@@ -75,6 +75,11 @@ struct LwParams {
     const cf *twa, *twb;    // sub-FFT twiddles of the context (tile_ols.hpp)
     int persistent_wgs;
     int rows_pairs_per_batch;   // rows kernel form: 2 = two pairs per batch, one workgroup per CU; 1 = one pair per batch, two workgroups per CU
+    // rows kernel, 16-points-per-thread form (tile_lw16.hpp): 256-thread workgroups, one row at a time
+    int rows_form;              // 16 = that form (tab16 / tw2 are set), otherwise the 8-point forms above (tab is set)
+    const struct LwTab2 *tab16; // [row pair][pair][row ra | rb][m1 = 16][thread = 256]: {T0, T3} for row ra, {T1, T2} for row rb
+    const cf *tw2;              // [m0 = 16][a = 16]: w_256^{a m0}
+    int rows16_wgs;             // workgroups per CU of that form's persistent grid
 };
 
 // ---- compile-time constants: w_32^m = cos(pi m/16) - i sin(pi m/16) ---------------------------------------------

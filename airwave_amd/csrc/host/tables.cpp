@@ -136,7 +136,7 @@ static void fft_inplace_tw(std::vector<cd> &a, const std::vector<cd> &tw) {
 }
 
 void build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
-                     const int32_t *right_track, int R, LwTables &out) {
+                     const int32_t *right_track, int R, LwTables &out, int rows_form) {
     const int M = awk::kLwM;
     const size_t N = (size_t)R * M;
     const int n_pairs = (n_channels + 1) / 2;
@@ -162,7 +162,20 @@ void build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels
     std::vector<cd> tw(N / 2), mod(N);
     for (size_t k = 0; k < N / 2; ++k) { const double a = -2.0 * M_PI * (double)k / (double)N; tw[k] = cd(std::cos(a), std::sin(a)); }
     for (size_t n = 0; n < N; ++n) { const double a = -M_PI * (double)n / (double)N; mod[n] = cd(std::cos(a), std::sin(a)); }     // w_N^{n/2}
-    out.tab.assign((size_t)(R / 2) * n_pairs * M, awk::LwTab{awk::mk(0, 0), awk::mk(0, 0), awk::mk(0, 0), awk::mk(0, 0)});
+    const bool form16 = rows_form == 16;
+    out.tab.clear(); out.tab16.clear(); out.tw2.clear();
+    if (form16) {
+        out.tab16.assign((size_t)(R / 2) * n_pairs * 2 * M, awk::LwTab2{awk::mk(0, 0), awk::mk(0, 0)});
+        out.tw2.resize(256);
+        for (int m0 = 0; m0 < 16; ++m0)
+            for (int a = 0; a < 16; ++a) out.tw2[(size_t)m0 * 16 + a] = unit((double)a * m0, 256.0);
+        // position of row bin k2 in thread order
+    } else {
+        out.tab.assign((size_t)(R / 2) * n_pairs * M, awk::LwTab{awk::mk(0, 0), awk::mk(0, 0), awk::mk(0, 0), awk::mk(0, 0)});
+    }
+    std::vector<int> pos16(M, 0);                  // row bin k2 -> m1 * 256 + thread
+    for (int m1 = 0; m1 < 16; ++m1)
+        for (int th = 0; th < awk::kR16Threads; ++th) pos16[awk::r16_bin(th, m1)] = m1 * awk::kR16Threads + th;
     const double scale = 1.0 / (2.0 * (double)N);
     std::vector<cd> zl(N), zr(N);
     auto tap = [&](int track, size_t i) -> double {
@@ -190,9 +203,15 @@ void build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels
                 const cd Akp = (std::conj(zl[k]) + I * std::conj(zr[k])) * scale, Bkp = (zl[kp] + I * zr[kp]) * scale;
                 cd t0 = Ak, t1 = Bk, t2 = std::conj(Akp), t3 = std::conj(Bkp);
                 if (fold) { t0 += t1; t3 += t2; t1 = cd(0, 0); t2 = cd(0, 0); }
-                const int q1 = k2 & 7, q2 = k2 >> 3;
-                awk::LwTab &e = out.tab[(((size_t)rp * n_pairs + p) * awk::kLwInner + q1) * awk::kSub + q2];
-                e.t0 = c32(t0); e.t1 = c32(t1); e.t2 = c32(t2); e.t3 = c32(t3);
+                if (form16) {
+                    const size_t base = ((size_t)rp * n_pairs + p) * 2 * M + pos16[k2];
+                    out.tab16[base] = awk::LwTab2{c32(t0), c32(t3)};
+                    out.tab16[base + M] = awk::LwTab2{c32(t1), c32(t2)};
+                } else {
+                    const int q1 = k2 & 7, q2 = k2 >> 3;
+                    awk::LwTab &e = out.tab[(((size_t)rp * n_pairs + p) * awk::kLwInner + q1) * awk::kSub + q2];
+                    e.t0 = c32(t0); e.t1 = c32(t1); e.t2 = c32(t2); e.t3 = c32(t3);
+                }
             }
         }
     }

@@ -8,7 +8,7 @@
 #include <vector>
 
 #include "../device/tile_ols2.hpp"
-#include "../device/tile_lw.hpp"
+#include "../device/tile_lw16.hpp"
 
 namespace awh {
 
@@ -42,11 +42,16 @@ inline int poly_history_frames(int taps) { return 2 * (taps / 2); }          // 
 //   row twiddles w_2N^{t (2 k1 + 1)}, t = 64 tc + lane, k1 = RA m + ka (RA = R/8) as coarse[ka][tc] fine[ka][lane] step[m][t]:
 //   coarse [RA][64]: w_2N^{64 tc (2 ka + 1)};  fine [RA][64]: w_2N^{lane (2 ka + 1)};  step [3][4096]: w_2N^{2 RA m t}, m = 1..3;
 //   tw_r [RA][8]: w_2R^{j1 (2 ka + 1)};  tw1m [512]: w_4096^t
+//   rows_form 16 (device/tile_lw16.hpp) instead of `tab`:
+//   tab16  [R/2][pairs][2][16][256] {u, w}: the same four values per bin, split by the row they multiply — [0] = {T0, T3} (row ra),
+//          [1] = {T1, T2} (row rb; all zero for a folded real last channel) — at [m1][thread] for the bin k2 = r16_bin(thread, m1)
+//   tw2    [16][16]: w_256^{a m0} at [m0][a]
 struct LwTables {
     std::vector<awk::LwTab> tab;
-    std::vector<awk::cf> coarse, fine, step, tw_r, tw1m;
+    std::vector<awk::LwTab2> tab16;
+    std::vector<awk::cf> coarse, fine, step, tw_r, tw1m, tw2;
 };
 void build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
-                     const int32_t *right_track, int R, LwTables &out);
+                     const int32_t *right_track, int R, LwTables &out, int rows_form = 8);
 
 }  // namespace awh

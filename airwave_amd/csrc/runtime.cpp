@@ -368,6 +368,8 @@ void aw_spatializer_destroy(aw_spatializer *sp) {
     if (sp->d_tail) (void)hipFree(sp->d_tail);
     for (auto &pl : sp->lw_plans) {
         if (pl.d_tab) (void)hipFree(pl.d_tab);
+        if (pl.d_tab16) (void)hipFree(pl.d_tab16);
+        if (pl.d_tw2) (void)hipFree(pl.d_tw2);
         if (pl.d_coarse) (void)hipFree(pl.d_coarse);
         if (pl.d_fine) (void)hipFree(pl.d_fine);
         if (pl.d_tw_r) (void)hipFree(pl.d_tw_r);
@@ -701,7 +703,8 @@ static aw_status lw_get_plan(aw_spatializer *sp, int R, const aw_spatializer::Lw
     for (const auto &pl : sp->lw_plans)
         if (pl.R == R) { *out = &pl; return AW_OK; }
     awh::LwTables t;
-    awh::build_lw_tables(sp->lw_tracks.data(), sp->lw_n_tracks, sp->taps, sp->n_channels, sp->lw_left.data(), sp->lw_right.data(), R, t);
+    const int form = sp->ctx->cfg.lw_rows_form;          // which rows kernel the tables are laid out for (read once per context)
+    awh::build_lw_tables(sp->lw_tracks.data(), sp->lw_n_tracks, sp->taps, sp->n_channels, sp->lw_left.data(), sp->lw_right.data(), R, t, form);
     aw_spatializer::LwPlan pl;
     pl.R = R;
     auto up = [&](const void *src, size_t bytes, void **d) -> hipError_t {
@@ -709,14 +712,20 @@ static aw_status lw_get_plan(aw_spatializer *sp, int R, const aw_spatializer::Lw
         if (r != hipSuccess) return r;
         return hipMemcpy(*d, src, bytes, hipMemcpyHostToDevice);
     };
-    hipError_t e = up(t.tab.data(), t.tab.size() * sizeof(awk::LwTab), reinterpret_cast<void **>(&pl.d_tab));
+    hipError_t e = hipSuccess;
+    if (form == 16) {
+        e = up(t.tab16.data(), t.tab16.size() * sizeof(awk::LwTab2), reinterpret_cast<void **>(&pl.d_tab16));
+        if (e == hipSuccess) e = up(t.tw2.data(), t.tw2.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_tw2));
+    } else {
+        e = up(t.tab.data(), t.tab.size() * sizeof(awk::LwTab), reinterpret_cast<void **>(&pl.d_tab));
+    }
     if (e == hipSuccess) e = up(t.coarse.data(), t.coarse.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_coarse));
     if (e == hipSuccess) e = up(t.fine.data(), t.fine.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_fine));
     if (e == hipSuccess) e = up(t.step.data(), t.step.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_step));
     if (e == hipSuccess) e = up(t.tw_r.data(), t.tw_r.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_tw_r));
     if (e == hipSuccess) e = up(t.tw1m.data(), t.tw1m.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_tw1m));
     if (e != hipSuccess) {                  // nothing half-built stays behind: the next call tries again (or takes the partitioned kernels)
-        for (void *d : {(void *)pl.d_tab, (void *)pl.d_coarse, (void *)pl.d_fine, (void *)pl.d_step, (void *)pl.d_tw_r, (void *)pl.d_tw1m})
+        for (void *d : {(void *)pl.d_tab, (void *)pl.d_tab16, (void *)pl.d_tw2, (void *)pl.d_coarse, (void *)pl.d_fine, (void *)pl.d_step, (void *)pl.d_tw_r, (void *)pl.d_tw1m})
             if (d) (void)hipFree(d);
         return awr::hip_fail(e, "long-window tables");
     }
@@ -770,6 +779,7 @@ static aw_status sp_process_longwin(aw_spatializer *sp, int R, const float *in, 
         p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb;
         p.persistent_wgs = sp->ctx->cfg.persistent_wgs;
         p.rows_pairs_per_batch = sp->ctx->cfg.lw_rows_pb;
+        p.rows_form = plan->d_tab16 ? 16 : 8; p.tab16 = plan->d_tab16; p.tw2 = plan->d_tw2; p.rows16_wgs = sp->ctx->cfg.lw_rows16_wgs;
         p.n_streams = ns;
         if (sp->n_channels > 8) {        // the wide split kernel reads the last frame of the last stream from a padded copy (allocated at create)
             AW_HIP_TRY(hipMemcpyAsync(sp->d_tail, p.in + ((size_t)ns * frames - 1) * sp->n_channels, sp->n_channels * sizeof(float),

@@ -60,7 +60,7 @@ struct aw_spatializer {
     bool herm_ok = true;                // partitioned path, odd channel count: store/read only the non-redundant half of the last pair's spectrum
     // long-window path (device/tile_lw.hpp): chosen per call for long calls of a path-1 spatializer; tables per window length, built on first use
     // (aw_spatializer_reserve builds the one its max_frames implies)
-    struct LwPlan { int R = 0; awk::LwTab *d_tab = nullptr; awk::cf *d_coarse = nullptr, *d_fine = nullptr, *d_step = nullptr, *d_tw_r = nullptr, *d_tw1m = nullptr; };
+    struct LwPlan { int R = 0; awk::LwTab *d_tab = nullptr; awk::LwTab2 *d_tab16 = nullptr; awk::cf *d_tw2 = nullptr; awk::cf *d_coarse = nullptr, *d_fine = nullptr, *d_step = nullptr, *d_tw_r = nullptr, *d_tw1m = nullptr; };
     std::vector<LwPlan> lw_plans;
     int lw_mode = -1;                   // AW_LW at create: -1 automatic (cost model), 0 never, 32/64/128 force that R where it fits
     std::vector<float> lw_tracks;       // the HRIR and channel map, kept for the lazily built tables

@@ -11,7 +11,7 @@ _DEFS = os.environ.get("AW_EMU_DEFINES", "").split()          # e.g. "-DAW_SUBFF
 _LIB = os.path.join(_HERE, "libemu.so" if not _DEFS else "libemu_variant.so")
 _SRCS = [os.path.join(_HERE, "emu_harness.cpp"), os.path.join(_ROOT, "airwave_amd/csrc/host/tables.cpp"),
          os.path.join(_ROOT, "airwave_amd/csrc/host/eq.cpp")]
-_DEPS = _SRCS + [os.path.join(_ROOT, "airwave_amd/csrc/device", f) for f in ("tile_ols.hpp", "tile_ols2.hpp", "tile_march.hpp", "tile_lw.hpp", "cplx.hpp", "eq_cascade.hpp")] + [
+_DEPS = _SRCS + [os.path.join(_ROOT, "airwave_amd/csrc/device", f) for f in ("tile_ols.hpp", "tile_ols2.hpp", "tile_march.hpp", "tile_lw.hpp", "tile_lw16.hpp", "cplx.hpp", "eq_cascade.hpp")] + [
     os.path.join(_ROOT, "airwave_amd/csrc/host/tables.hpp"), os.path.join(_ROOT, "airwave_amd/csrc/host/eq.hpp")]
 _lib = None
 

@@ -17,6 +17,7 @@
 #include "../../airwave_amd/csrc/device/tile_ols.hpp"
 #include "../../airwave_amd/csrc/device/tile_march.hpp"
 #include "../../airwave_amd/csrc/device/tile_lw.hpp"
+#include "../../airwave_amd/csrc/device/tile_lw16.hpp"
 #include "../../airwave_amd/csrc/device/eq_cascade.hpp"
 #include "../../airwave_amd/csrc/host/eq.hpp"
 #include "../../airwave_amd/csrc/host/tables.hpp"
@@ -361,8 +362,10 @@ int emu_longwin(const float *in, float *out, const float *hist, const float *tra
     awh::Twiddles tw;
     awh::build_twiddles(tw);
     awh::LwTables lt;
-    awh::build_lw_tables(tracks, n_tracks, taps, n_channels, left_track, right_track, R, lt);
+    const bool form16 = rows_pb == 16;                   // the 16-points-per-thread rows kernel (tile_lw16.hpp)
+    awh::build_lw_tables(tracks, n_tracks, taps, n_channels, left_track, right_track, R, lt, form16 ? 16 : 8);
     LwParams p{};
+    p.rows_form = form16 ? 16 : 8; p.tab16 = lt.tab16.data(); p.tw2 = lt.tw2.data();
     p.in = in; p.out = out; p.zeros = g_zeros; p.frames = frames;
     p.n_channels = n_channels; p.n_pairs = (n_channels + 1) / 2; p.real_last = n_channels & 1;
     p.hop = hop; p.hist_len = (int)(N - hop); p.n_windows = (int)((frames + hop - 1) / hop);
@@ -429,7 +432,26 @@ int emu_longwin(const float *in, float *out, const float *hist, const float *tra
             if (p.real_last) go_np(LwIdx<1>{}); else go_np(LwIdx<0>{});
         });
     };
-    if (rows_pb == 1) rows(LwIdx<1>{}); else rows(LwIdx<2>{});
+    if (form16) {
+        EmuShared sh16(kR16Threads, (size_t)kR16LdsElems);
+        std::vector<std::thread> th;
+        th.reserve(kR16Threads);
+        for (int t = 0; t < kR16Threads; ++t)
+            th.emplace_back([&, t]() {
+                EmuCtx ctx{t, &sh16};
+                auto go = [&](auto NPP, auto REAL) {
+                    lw_rows16_tiles<EmuCtx, decltype(NPP)::value, (decltype(REAL)::value != 0)>(ctx, p, 0, 1, n_rt, n_sw, 0, 1);
+                };
+                auto go_np = [&](auto REAL) {
+                    switch (p.n_pairs) {
+                        case 1: go(LwIdx<1>{}, REAL); break; case 2: go(LwIdx<2>{}, REAL); break; case 3: go(LwIdx<3>{}, REAL); break; case 4: go(LwIdx<4>{}, REAL); break;
+                        case 5: go(LwIdx<5>{}, REAL); break; case 6: go(LwIdx<6>{}, REAL); break; case 7: go(LwIdx<7>{}, REAL); break; default: go(LwIdx<8>{}, REAL); break;
+                    }
+                };
+                if (p.real_last) go_np(LwIdx<1>{}); else go_np(LwIdx<0>{});
+            });
+        for (auto &x : th) x.join();
+    } else if (rows_pb == 1) rows(LwIdx<1>{}); else rows(LwIdx<2>{});
     run([&](EmuCtx &ctx) {
         if (R == 32) lw_merge_tiles<EmuCtx, 4>(ctx, p, 0, 1, n_st);
         else if (R == 64) lw_merge_tiles<EmuCtx, 8>(ctx, p, 0, 1, n_st);

@@ -22,10 +22,12 @@ def _case(oracle, channels, taps, frames, R, seed=5, hop=None, hist_frames=0):
     return h, lt, rt, x, ref
 
 
-@pytest.mark.parametrize("channels,rows_pb", [(7, 2), (8, 2), (1, 2), (2, 2), (5, 2), (7, 1), (6, 1), (1, 1), (14, 1), (9, 1), (13, 2), (16, 1), (12, 1), (11, 1)])
+@pytest.mark.parametrize("channels,rows_pb", [(7, 2), (8, 2), (1, 2), (2, 2), (5, 2), (7, 1), (6, 1), (1, 1), (14, 1), (9, 1), (13, 2), (16, 1), (12, 1), (11, 1),
+                                              (7, 16), (8, 16), (1, 16), (2, 16), (5, 16), (14, 16), (13, 16)])
 def test_emulated_long_window_matches_truth(oracle, channels, rows_pb):
     # one window of 32 x 4096 frames holds the whole call: history (zeros), input, zero fill past the end;
-    # rows_pb = channel pairs per batch of the rows kernel (1: the two-workgroups-per-CU form)
+    # rows_pb = channel pairs per batch of the rows kernel (1: the two-workgroups-per-CU form; 16: the 16-points-per-thread
+    # kernel of tile_lw16.hpp, 256-thread workgroups)
     taps, frames = 9000, 100000
     h, lt, rt, x, ref = _case(oracle, channels, taps, frames, 32)
     y = emu.longwin(x, h, lt, rt, R=32, rows_pb=rows_pb)
@@ -34,7 +36,8 @@ def test_emulated_long_window_matches_truth(oracle, channels, rows_pb):
         assert oracle.peak_rel_error(y[0, :, ear], ref[:, ear]) < TOL
 
 
-def test_emulated_long_window_two_windows_and_history(oracle):
+@pytest.mark.parametrize("rows_pb", [2, 16])
+def test_emulated_long_window_two_windows_and_history(oracle, rows_pb):
     # two windows (hop < frames), a history buffer carried from a previous call, an unmapped channel
     taps, R = 40000, 32
     N = R * 4096
@@ -46,19 +49,19 @@ def test_emulated_long_window_two_windows_and_history(oracle):
     ref = oracle.spatialize_f64(x[0], h, lt, rt)
     hist = x[:, :hist_len].copy()
     hist_out = np.full((1, hist_len, 6), np.nan, dtype=np.float32)
-    y = emu.longwin(x[:, hist_len:], h, lt, rt, R=R, hop=hop, hist=hist, hist_out=hist_out)
+    y = emu.longwin(x[:, hist_len:], h, lt, rt, R=R, hop=hop, hist=hist, hist_out=hist_out, rows_pb=rows_pb)
     assert not np.isnan(y).any()
     assert np.array_equal(hist_out, x[:, -hist_len:])          # the split kernel carried the convolution tail
     for ear in range(2):
         assert oracle.peak_rel_error(y[0, :, ear], ref[hist_len:, ear]) < TOL
 
 
-@pytest.mark.parametrize("R", [64, 128])
-def test_emulated_long_window_larger_radix(oracle, R):
+@pytest.mark.parametrize("R,rows_pb", [(64, 2), (128, 2), (64, 16), (128, 16)])
+def test_emulated_long_window_larger_radix(oracle, R, rows_pb):
     # R = 64 (in-thread radix 8) and R = 128 (radix 16): a short call in a large window — the kernels do the full work
     taps, frames = 33000, 20000
     h, lt, rt, x, ref = _case(oracle, 3, taps, frames, R)
-    y = emu.longwin(x, h, lt, rt, R=R)
+    y = emu.longwin(x, h, lt, rt, R=R, rows_pb=rows_pb)
     assert not np.isnan(y).any()
     for ear in range(2):
         assert oracle.peak_rel_error(y[0, :, ear], ref[:, ear]) < TOL
