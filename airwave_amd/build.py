@@ -21,6 +21,11 @@ SOURCES = [
     "device/kernels.hip",
     "device/march_kernels.hip",
     "device/lw_kernels.hip",
+    "device/lw_split_a.hip",
+    "device/lw_split_b.hip",
+    "device/lw_split_c.hip",
+    "device/lw_split_d.hip",
+    "device/lw_split_e.hip",
     "device/ols2_even_kernels.hip",
     "device/eq_kernels.hip",
     "runtime.cpp",
@@ -37,6 +42,8 @@ EXTRA_FLAGS = {"device/march_kernels.hip": [] if os.environ.get("AW_MARCH_SLP") 
                # long-window kernels: at their 16 waves per CU the first sub-FFT exchange in registers (permlane swaps) and plain
                # single ds_read_b64 (no read2 fusion) measure 4.88 -> 4.72-4.75 ms on the cfg 3 rows kernel (the 8-wave tile kernels: +-1 %)
                "device/lw_kernels.hip": ["-fno-slp-vectorize", "-DAW_XA_REG=1", "-DAW_LDS_ATOMIC_READS=1"],
+               "device/lw_split_a.hip": ["-fno-slp-vectorize"], "device/lw_split_b.hip": ["-fno-slp-vectorize"], "device/lw_split_c.hip": ["-fno-slp-vectorize"],
+               "device/lw_split_d.hip": ["-fno-slp-vectorize"], "device/lw_split_e.hip": ["-fno-slp-vectorize"],
                "device/kernels.hip": [] if os.environ.get("AW_KERNELS_SLP") else ["-fno-slp-vectorize"]}
 HEADERS = sorted(os.path.relpath(os.path.join(d, f), CSRC) for d, _, fs in os.walk(CSRC) for f in fs if f.endswith((".hpp", ".h"))) + [
     "../../include/airwave_hip.h",
@@ -93,7 +100,7 @@ def build(force: bool = False, verbose: bool = False, stamps: bool = False, defi
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
-        with ThreadPoolExecutor(max_workers=int(os.environ.get("AW_BUILD_JOBS", "4"))) as ex:
+        with ThreadPoolExecutor(max_workers=int(os.environ.get("AW_BUILD_JOBS", "8"))) as ex:
             list(ex.map(run, jobs))
     if force or _stale(OUT, objs):
         cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs

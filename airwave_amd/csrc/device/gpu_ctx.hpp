@@ -179,6 +179,9 @@ struct GpuCtx {
     }
     // data read once (rows of the long-window path's scratch): a non-temporal load (tile_march.hpp: 7.1 against 6.4 TB/s)
     __device__ __forceinline__ cf ld_stream(const cf *p) const {
+#ifdef AW_LD_STREAM_PLAIN        // A/B only
+        return *p;
+#endif
         typedef float v2f __attribute__((ext_vector_type(2)));
         const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p));
         return mk(v.x, v.y);

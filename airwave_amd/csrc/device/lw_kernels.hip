@@ -4,24 +4,9 @@
 #include "gpu_ctx.hpp"
 #include "tile_lw.hpp"
 #include "tile_lw16.hpp"
+#include "lw_split_inst.hpp"
 
 namespace awk {
-
-// Tile id = (stream, window) * 64 + t-chunk: workgroups that run at the same time read and write neighbouring 64-frame
-// pieces of the same R strided sub-sequences (whole DRAM pages between them).
-template <int RA, int CS>
-__global__ void __launch_bounds__(kThreads, RA == 16 ? 2 : 4) aw_lw_split_kernel(LwParams p, long long n_tiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
-    lw_split_tiles<GpuCtx, RA, CS>(ctx, p, (long long)blockIdx.x, (long long)gridDim.x, n_tiles);
-}
-
-template <int RA, int CS1>
-__global__ void __launch_bounds__(kThreads, RA == 16 ? 2 : 4) aw_lw_split_wide_kernel(LwParams p, long long n_tiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
-    lw_split_wide_tiles<GpuCtx, RA, CS1>(ctx, p, (long long)blockIdx.x, (long long)gridDim.x, n_tiles);
-}
 
 // Row pairs are pinned to XCDs (blockIdx % 8 labels the XCD): XCD x walks the row pairs x, x + 8, ... one after the other
 // and, within a row pair, every (stream, window); its 32 workgroups therefore share one 512 KB table slice at a time.
@@ -67,33 +52,21 @@ __global__ void __launch_bounds__(kR16Threads, AW_R16_MIN_WAVES) aw_lw_rows16_ke
 }
 
 template <int RA>
-__global__ void __launch_bounds__(kThreads, 4) aw_lw_merge_kernel(LwParams p, long long n_tiles) {
+__global__ void __launch_bounds__(kThreads, RA > 8 ? 2 : 4) aw_lw_merge_kernel(LwParams p, long long n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
     lw_merge_tiles<GpuCtx, RA>(ctx, p, (long long)blockIdx.x, (long long)gridDim.x, n_tiles);
 }
 
-#define AW_LW_FOR_CS(X, RA) X(RA, 1) X(RA, 2) X(RA, 3) X(RA, 4) X(RA, 5) X(RA, 6) X(RA, 7) X(RA, 8)
-#define AW_LW_FOR_RA_CS(X) AW_LW_FOR_CS(X, 4) AW_LW_FOR_CS(X, 8) AW_LW_FOR_CS(X, 16)
-
-template <int RA> constexpr int lw_split_lds_bytes() { return lw_split_lds_elems<RA>() * (int)sizeof(cf); }
 template <int RA> constexpr int lw_merge_lds_bytes() { return lw_merge_lds_elems<RA>() * (int)sizeof(cf); }
+#define AW_LW_FOR_RA(X) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(12) X(14) X(15) X(16)
 
 constexpr int kLwRows1LdsBytes = lw_rows_lds_elems<1>() * (int)sizeof(cf);
 
 hipError_t prepare_lw_kernels() {
     hipError_t e = hipSuccess;
-#define AW_SET(RA, CS)                                                                                 \
-    if (e == hipSuccess)                                                                               \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_split_kernel<RA, CS>),           \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lw_split_lds_bytes<RA>());
-    AW_LW_FOR_RA_CS(AW_SET)
-#undef AW_SET
-#define AW_SET(RA, CS)                                                                                 \
-    if (e == hipSuccess)                                                                               \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_split_wide_kernel<RA, CS>),      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lw_split_lds_bytes<RA>());
-    AW_LW_FOR_RA_CS(AW_SET)
+#define AW_SET(RA) if (e == hipSuccess) e = lw_split_prepare<RA>();
+    AW_LW_FOR_RA(AW_SET)
 #undef AW_SET
 #define AW_SET(NP)                                                                                     \
     if (e == hipSuccess)                                                                               \
@@ -122,9 +95,9 @@ hipError_t prepare_lw_kernels() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kR16LdsBytes);
     AW_SET(1) AW_SET(2) AW_SET(3) AW_SET(4) AW_SET(5) AW_SET(6) AW_SET(7) AW_SET(8)
 #undef AW_SET
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_merge_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lw_merge_lds_bytes<4>());
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_merge_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lw_merge_lds_bytes<8>());
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_merge_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lw_merge_lds_bytes<16>());
+#define AW_SET(RA) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&aw_lw_merge_kernel<RA>), hipFuncAttributeMaxDynamicSharedMemorySize, lw_merge_lds_bytes<RA>());
+    AW_LW_FOR_RA(AW_SET)
+#undef AW_SET
     return e;
 }
 
@@ -136,24 +109,23 @@ static unsigned lw_grid(long long n_tiles, const LwParams &p, int wgs_per_cu) {
 hipError_t launch_lw_split(const LwParams &p, int n_streams, hipStream_t stream, StageTimer *tm) {
     if (p.n_channels < 1 || p.n_channels > 16) return hipErrorInvalidValue;
     const int ra = p.R / 8;
+    if (p.R % 8 != 0 || !lw_ra_ok(ra)) return hipErrorInvalidValue;
     const bool wide = p.n_channels > 8;              // 9-16 channels: both channel halves of a frame in one wave, 32 frames per tile
     const long long n_tiles = (long long)n_streams * p.n_windows * (wide ? kLwChunksW : kLwChunks);
     if (n_tiles <= 0) return hipSuccess;
     if (n_tiles > 0x7fffffffLL || (wide && !p.tail)) return hipErrorInvalidValue;
     const int cs = wide ? p.n_channels - 8 : p.n_channels;
+    const dim3 grid(lw_grid(n_tiles, p, ra > 8 ? 1 : 2));
     if (tm) tm->begin();
-    bool done = false;
-#define AW_CASE(RA, CS)                                                                                                            \
-    if (!done && ra == RA && cs == CS) {                                                                                           \
-        const dim3 grid(lw_grid(n_tiles, p, RA == 16 ? 1 : 2));                                                                    \
-        if (wide) hipLaunchKernelGGL((aw_lw_split_wide_kernel<RA, CS>), grid, dim3(kThreads), lw_split_lds_bytes<RA>(), stream, p, n_tiles);   \
-        else hipLaunchKernelGGL((aw_lw_split_kernel<RA, CS>), grid, dim3(kThreads), lw_split_lds_bytes<RA>(), stream, p, n_tiles);             \
-        done = true;                                                                                                               \
-    }
-    AW_LW_FOR_RA_CS(AW_CASE)
+    hipError_t e = hipErrorInvalidValue;
+    switch (ra) {
+#define AW_CASE(RA) case RA: e = lw_split_launch<RA>(p, wide, cs, grid, stream, n_tiles); break;
+        AW_LW_FOR_RA(AW_CASE)
 #undef AW_CASE
+        default: break;
+    }
     if (tm) tm->end(wide ? "aw_lw_split_wide_kernel" : "aw_lw_split_kernel");
-    return done ? hipGetLastError() : hipErrorInvalidValue;
+    return e;
 }
 
 hipError_t launch_lw_rows(const LwParams &p, int n_streams, hipStream_t stream, StageTimer *tm) {
@@ -216,10 +188,10 @@ hipError_t launch_lw_merge(const LwParams &p, int n_streams, hipStream_t stream,
     if (n_tiles <= 0) return hipSuccess;
     if (n_tiles > 0x7fffffffLL) return hipErrorInvalidValue;
     if (tm) tm->begin();
-    switch (p.R) {
-        case 32: hipLaunchKernelGGL((aw_lw_merge_kernel<4>), dim3(lw_grid(n_tiles, p, 2)), dim3(kThreads), lw_merge_lds_bytes<4>(), stream, p, n_tiles); break;
-        case 64: hipLaunchKernelGGL((aw_lw_merge_kernel<8>), dim3(lw_grid(n_tiles, p, 2)), dim3(kThreads), lw_merge_lds_bytes<8>(), stream, p, n_tiles); break;
-        case 128: hipLaunchKernelGGL((aw_lw_merge_kernel<16>), dim3(lw_grid(n_tiles, p, 2)), dim3(kThreads), lw_merge_lds_bytes<16>(), stream, p, n_tiles); break;
+    switch (p.R / 8) {
+#define AW_CASE(RA) case RA: hipLaunchKernelGGL((aw_lw_merge_kernel<RA>), dim3(lw_grid(n_tiles, p, RA > 8 ? 1 : 2)), dim3(kThreads), lw_merge_lds_bytes<RA>(), stream, p, n_tiles); break;
+        AW_LW_FOR_RA(AW_CASE)
+#undef AW_CASE
         default: return hipErrorInvalidValue;
     }
     if (tm) tm->end("aw_lw_merge_kernel");

@@ -54,6 +54,8 @@ struct LwParams {
                             // frames of (history ++ input) — into the other history buffer (every such frame passes through it anyway)
     const float *zeros;     // >= 64 bytes of zeros
     long long frames;       // frames per stream in this call
+    long long frame0;       // a call may run as several groups of windows, each with its own window length: this launch's windows start at
+    long long frame_end;    // frame0 + win * hop (their history: the frames before, from `in` or, below 0, from `hist`) and store frames < frame_end
     int n_channels, n_pairs;
     const float *tail;      // wide split kernel (9-16 channels): a copy of the LAST frame of the last stream of `in`, followed by >= 4 zeros
     int n_streams;          // streams in this launch (the wide split kernel redirects the last frame of the last one to `tail`)
@@ -82,49 +84,113 @@ struct LwParams {
     int rows16_wgs;             // workgroups per CU of that form's persistent grid
 };
 
-// ---- compile-time constants: w_32^m = cos(pi m/16) - i sin(pi m/16) ---------------------------------------------
-constexpr float lw_cos16_q(int m) {       // cos(pi m / 16), 0 <= m <= 8
-    return m == 0 ? 1.0f : m == 1 ? 0.98078528040323044913f : m == 2 ? 0.92387953251128675613f : m == 3 ? 0.83146961230254523708f
-         : m == 4 ? 0.70710678118654752440f : m == 5 ? 0.55557023301960222474f : m == 6 ? 0.38268343236508977173f
-         : m == 7 ? 0.19509032201612826785f : 0.0f;
-}
-constexpr float lw_cos16(int m) {
-    m &= 31;
-    return m <= 8 ? lw_cos16_q(m) : m <= 16 ? -lw_cos16_q(16 - m) : m <= 24 ? -lw_cos16_q(m - 16) : lw_cos16_q(32 - m);
-}
-constexpr float lw_sin16(int m) { return lw_cos16(m - 8); }
-
-// a * w_32^M (forward) or a * conj(w_32^M) (INV)
-template <bool INV, int M> AW_HD cf lw_mul_w32(cf a) {
-    constexpr int m = M & 31;
-    if constexpr (m == 0) return a;
-    else if constexpr (m == 8) return rot90<INV>(a);
-    else if constexpr (m == 16) return mk(-a.x, -a.y);
-    else if constexpr (m == 24) return rot90<!INV>(a);
-    else {
-        constexpr float c = lw_cos16(m), s = INV ? lw_sin16(m) : -lw_sin16(m);
-        return mk(a.x * c - a.y * s, a.x * s + a.y * c);
-    }
-}
+// window lengths: R = 8 RA rows of 4096 frames, RA = 4 .. 16 without the primes 11 and 13 (the split / merge kernels run a DFT of that
+// size in registers, lw_fft below; the direct 11- and 13-point products make them compute-bound: 33-36 against 40-44 G frames/s on cfg 3's layout)
+constexpr bool lw_ra_ok(int ra) { return ra >= 4 && ra <= 16 && ra != 11 && ra != 13; }
 
 template <int I> struct LwIdx { static constexpr int value = I; };
 template <int NN, int I = 0, class F> AW_HD void lw_unroll(F &&f) {
     if constexpr (I < NN) { f(LwIdx<I>{}); lw_unroll<NN, I + 1>(f); }
 }
 
+// ---- compile-time unit roots for any order (the window lengths R = 8 RA with RA = 5, 6, 7, 10, 12, 14 need w_q, w_RA, w_2RA) ----
+// cos / sin of 2 pi num / den in double by range reduction to [0, pi/4] and Taylor series (constexpr in C++17 on both compilers)
+constexpr double lw_kPi = 3.14159265358979323846264338327950288;
+constexpr double lw_taylor_sin(double x) {   // |x| <= pi/4
+    const double x2 = x * x;
+    return x * (1.0 + x2 * (-1.0 / 6 + x2 * (1.0 / 120 + x2 * (-1.0 / 5040 + x2 * (1.0 / 362880 + x2 * (-1.0 / 39916800 + x2 * (1.0 / 6227020800.0 + x2 * (-1.0 / 1307674368000.0))))))));
+}
+constexpr double lw_taylor_cos(double x) {
+    const double x2 = x * x;
+    return 1.0 + x2 * (-0.5 + x2 * (1.0 / 24 + x2 * (-1.0 / 720 + x2 * (1.0 / 40320 + x2 * (-1.0 / 3628800 + x2 * (1.0 / 479001600.0 + x2 * (-1.0 / 87178291200.0 + x2 * (1.0 / 20922789888000.0))))))));
+}
+struct LwUnit { double c, s; };
+// exp(-2 pi i num / den) for integers num, den > 0: octant by exact integer arithmetic, then the series on the remainder
+constexpr LwUnit lw_unit(long long num, long long den) {
+    num %= den; if (num < 0) num += den;
+    // angle = 2 pi num / den = (pi / 4) (8 num / den): octant o = floor(8 num / den), remainder r in [0, 1)
+    const long long o = (8 * num) / den;
+    const double r = (double)(8 * num - o * den) / (double)den;          // fraction of an octant
+    const double a = r * (lw_kPi / 4);
+    const double c0 = lw_taylor_cos(a), s0 = lw_taylor_sin(a);          // angle within the octant
+    const double h = 0.70710678118654752440084436210484904;
+    // rotate by o octants: (c, s) of o * pi/4 + a
+    double c = 0, sn = 0;
+    switch (o & 7) {
+        case 0: c = c0; sn = s0; break;
+        case 1: c = h * (c0 - s0); sn = h * (c0 + s0); break;
+        case 2: c = -s0; sn = c0; break;
+        case 3: c = -h * (c0 + s0); sn = h * (c0 - s0); break;
+        case 4: c = -c0; sn = -s0; break;
+        case 5: c = -h * (c0 - s0); sn = -h * (c0 + s0); break;
+        case 6: c = s0; sn = -c0; break;
+        default: c = h * (c0 + s0); sn = -h * (c0 - s0); break;
+    }
+    return LwUnit{c, -sn};                                                // forward kernel: exp(-i angle)
+}
+// a * exp(-2 pi i NUM / DEN) (forward) or times its conjugate (INV)
+template <bool INV, int NUM, int DEN> AW_HD cf lw_mul_unit(cf a) {
+    constexpr int n = ((NUM % DEN) + DEN) % DEN;
+    if constexpr (n == 0) return a;
+    else if constexpr (4 * n == DEN) return rot90<INV>(a);
+    else if constexpr (2 * n == DEN) return mk(-a.x, -a.y);
+    else if constexpr (4 * n == 3 * DEN) return rot90<!INV>(a);
+    else {
+        constexpr LwUnit u = lw_unit(n, DEN);
+        constexpr float c = (float)u.c, s = (float)(INV ? -u.s : u.s);
+        return mk(a.x * c - a.y * s, a.x * s + a.y * c);
+    }
+}
+
+constexpr int lw_odd_part(int n) { return n % 2 == 0 ? lw_odd_part(n / 2) : n; }
+constexpr int lw_small_factor(int n) { return n % 3 == 0 ? 3 : n % 5 == 0 ? 5 : n % 7 == 0 ? 7 : n; }     // smallest odd prime factor (n odd, < 49)
+
+// DFT of size NN over the register index, natural order in and out (NN <= 16).  Powers of two are the butterflies of cplx.hpp; an odd
+// prime is a direct product; every other size splits as NN = A B, j = B ja + jb, k = ka + A kb: DFT_A over ja for every jb, twiddle
+// w_NN^{jb ka}, DFT_B over jb for every ka — A the odd part of an even size (the power of two last), the smallest prime of an odd one.
 template <bool INV, int NN> AW_HD void lw_fft(cf (&v)[NN]) {
-    static_assert(NN == 2 || NN == 4 || NN == 8 || NN == 16, "in-register radix");
-    if constexpr (NN == 16) fft16<INV>(v);
-    else if constexpr (NN == 8) fft8<INV>(v);
-    else if constexpr (NN == 4) fft4<INV>(v[0], v[1], v[2], v[3]);
-    else { const cf a = v[0] + v[1], b = v[0] - v[1]; v[0] = a; v[1] = b; }
+    static_assert(NN >= 1 && NN <= 16, "in-register DFT");
+    constexpr int q = lw_odd_part(NN);
+    if constexpr (NN == 1) {
+    } else if constexpr (q == 1) {
+        if constexpr (NN == 16) fft16<INV>(v);
+        else if constexpr (NN == 8) fft8<INV>(v);
+        else if constexpr (NN == 4) fft4<INV>(v[0], v[1], v[2], v[3]);
+        else { const cf a = v[0] + v[1], b = v[0] - v[1]; v[0] = a; v[1] = b; }
+    } else if constexpr (q == NN && lw_small_factor(NN) == NN) {          // odd prime: direct
+        cf y[NN];
+        lw_unroll<NN>([&](auto K) {
+            constexpr int k = K.value;
+            cf acc = v[0];
+            lw_unroll<NN - 1>([&](auto J) { acc = acc + lw_mul_unit<INV, (J.value + 1) * k, NN>(v[J.value + 1]); });
+            y[k] = acc;
+        });
+        lw_unroll<NN>([&](auto K) { v[K.value] = y[K.value]; });
+    } else {
+        constexpr int A = q == NN ? lw_small_factor(NN) : q, B = NN / A;
+        cf y[NN];                                    // y[ka * B + jb]
+        lw_unroll<B>([&](auto JB) {
+            constexpr int jb = JB.value;
+            cf z[A];
+            lw_unroll<A>([&](auto JA) { z[JA.value] = v[JA.value * B + jb]; });
+            lw_fft<INV, A>(z);
+            lw_unroll<A>([&](auto KA) { y[KA.value * B + jb] = lw_mul_unit<INV, jb * KA.value, NN>(z[KA.value]); });
+        });
+        lw_unroll<A>([&](auto KA) {
+            constexpr int ka = KA.value;
+            cf z[B];
+            lw_unroll<B>([&](auto JB) { z[JB.value] = y[ka * B + JB.value]; });
+            lw_fft<INV, B>(z);
+            lw_unroll<B>([&](auto KB) { v[ka + A * KB.value] = z[KB.value]; });
+        });
+    }
 }
 
 // odd DFT of size NN over the register index:  v[k] <- sum_j v[j] w_NN^{j (k + 1/2)}   (INV: conjugate kernel)
 template <bool INV, int NN> AW_HD void lw_odd_dft(cf (&v)[NN]) {
-    if constexpr (!INV) lw_unroll<NN>([&](auto J) { v[J.value] = lw_mul_w32<false, J.value * (16 / NN)>(v[J.value]); });
+    if constexpr (!INV) lw_unroll<NN>([&](auto J) { v[J.value] = lw_mul_unit<false, J.value, 2 * NN>(v[J.value]); });
     lw_fft<INV, NN>(v);
-    if constexpr (INV) lw_unroll<NN>([&](auto J) { v[J.value] = lw_mul_w32<true, J.value * (16 / NN)>(v[J.value]); });
+    if constexpr (INV) lw_unroll<NN>([&](auto J) { v[J.value] = lw_mul_unit<true, J.value, 2 * NN>(v[J.value]); });
 }
 
 struct __attribute__((packed, aligned(4))) f3u { float x, y, z; };
@@ -196,11 +262,11 @@ template <int RA> constexpr int lw_split_lds_elems() { return 2 * RA * 8 * 64 + 
 // Layouts of up to eight channels (CS == p.n_channels; 9-16 channels: lw_split_wide_tiles below).
 template <class Ctx, int RA, int CS>
 AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long long step, long long end) {
-    static_assert(RA == 4 || RA == 8 || RA == 16, "R = 32, 64 or 128 rows");
+    static_assert(lw_ra_ok(RA), "R = 8 RA rows");
     static_assert(CS >= 1 && CS <= 8, "up to eight channels");
     constexpr bool AL = CS % 4 == 0;
     constexpr int CF = CS, c0 = 0, pair0 = 0;
-    constexpr int NP = (CS + 1) / 2, NPASS = (NP + 1) / 2, NCOMBO = RA / 4, G = RA >= 8 ? RA / 8 : 1;
+    constexpr int NP = (CS + 1) / 2, NPASS = (NP + 1) / 2, NCOMBO = (2 * RA + 7) / 8;      // (pair of the pass, ka) combinations, one per wave and round
     if (first >= end) return;
     const int lane = ctx.lane(), wave = ctx.wave();
     cf *lds = ctx.lds();
@@ -214,7 +280,7 @@ AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
         const int win = (int)(sw - stream * p.n_windows);
         const float *in_s = p.in + stream * p.frames * CF + c0;
         const float *hist_s = p.hist + stream * (long long)p.hist_len * CF + c0;
-        const long long fb = (long long)win * p.hop - p.hist_len + (long long)kLwM * wave + tc * kLwTw + lane;
+        const long long fb = p.frame0 + (long long)win * p.hop - p.hist_len + (long long)kLwM * wave + tc * kLwTw + lane;
 #pragma unroll
         for (int j2 = 0; j2 < RA; ++j2) {
             const long long f = fb + (long long)kLwM * 8 * j2;
@@ -240,7 +306,7 @@ AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
         if (p.hist_out) {             // uniform.  The next call's history: frames [frames - hist_len, frames) of (history ++ input)
             const long long stream = sw / p.n_windows;
             const int win = (int)(sw - stream * p.n_windows);
-            const long long fb = (long long)win * p.hop - p.hist_len + (long long)kLwM * wave + t;
+            const long long fb = p.frame0 + (long long)win * p.hop - p.hist_len + (long long)kLwM * wave + t;
             float *ho = p.hist_out + stream * (long long)p.hist_len * CF + c0;
 #pragma unroll
             for (int j2 = 0; j2 < RA; ++j2) {
@@ -271,8 +337,9 @@ AW_HD void lw_split_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
             // the partner row R-1-k1 = RA (7 - kb) + (RA-1-ka) — base(RA-1-ka) S^(7-kb).
 #pragma unroll
             for (int i = 0; i < NCOMBO; ++i) {
-                const int q = RA >= 8 ? i / G : wave / RA;                      // uniform
-                const int ka = RA >= 8 ? wave + 8 * (i % G) : wave % RA;
+                const int combo = wave + 8 * i;                                 // uniform: (q, ka) = (combo / RA, combo % RA)
+                if (combo >= 2 * RA) continue;
+                const int q = combo / RA, ka = combo - q * RA;
                 const int pair = 2 * pp + q;
                 if (pair >= NP) continue;
                 cf v[8];
@@ -315,9 +382,9 @@ constexpr int kLwChunksW = kLwM / kLwTwW;
 
 template <class Ctx, int RA, int CS1>
 AW_HD void lw_split_wide_tiles(Ctx &ctx, const LwParams &p, long long first, long long step, long long end) {
-    static_assert(RA == 4 || RA == 8 || RA == 16, "R = 32, 64 or 128 rows");
+    static_assert(lw_ra_ok(RA), "R = 8 RA rows");
     static_assert(CS1 >= 1 && CS1 <= 8, "channels 8 .. 8 + CS1 - 1 in the second half");
-    constexpr int C = 8 + CS1, NP1 = (CS1 + 1) / 2, NPASS = 2, NCOMBO = RA / 4, G = RA >= 8 ? RA / 8 : 1;
+    constexpr int C = 8 + CS1, NP1 = (CS1 + 1) / 2, NPASS = 2, NCOMBO = (2 * RA + 7) / 8;
     if (first >= end) return;
     const int lane = ctx.lane(), wave = ctx.wave();
     const int tl = lane & 31, half = lane >> 5;
@@ -334,7 +401,7 @@ AW_HD void lw_split_wide_tiles(Ctx &ctx, const LwParams &p, long long first, lon
         const float *in_s = p.in + stream * p.frames * C + 8 * half;
         const float *hist_s = p.hist + stream * (long long)p.hist_len * C + 8 * half;
         const bool last_stream = stream == p.n_streams - 1;
-        const long long fb = (long long)win * p.hop - p.hist_len + (long long)kLwM * wave + tc * kLwTwW + tl;
+        const long long fb = p.frame0 + (long long)win * p.hop - p.hist_len + (long long)kLwM * wave + tc * kLwTwW + tl;
 #pragma unroll
         for (int j2 = 0; j2 < RA; ++j2) {
             const long long f = fb + (long long)kLwM * 8 * j2;
@@ -361,7 +428,7 @@ AW_HD void lw_split_wide_tiles(Ctx &ctx, const LwParams &p, long long first, lon
         if (p.hist_out) {             // uniform.  The next call's history: frames [frames - hist_len, frames) of (history ++ input)
             const long long stream = sw / p.n_windows;
             const int win = (int)(sw - stream * p.n_windows);
-            const long long fb = (long long)win * p.hop - p.hist_len + (long long)kLwM * wave + t;
+            const long long fb = p.frame0 + (long long)win * p.hop - p.hist_len + (long long)kLwM * wave + t;
             float *ho = p.hist_out + stream * (long long)p.hist_len * C + 8 * half;
 #pragma unroll
             for (int j2 = 0; j2 < RA; ++j2) {
@@ -396,8 +463,9 @@ AW_HD void lw_split_wide_tiles(Ctx &ctx, const LwParams &p, long long first, lon
             ctx.barrier();
 #pragma unroll
             for (int i = 0; i < NCOMBO; ++i) {
-                const int q = RA >= 8 ? i / G : wave / RA;                      // uniform
-                const int ka = RA >= 8 ? wave + 8 * (i % G) : wave % RA;
+                const int combo = wave + 8 * i;                                 // uniform
+                if (combo >= 2 * RA) continue;
+                const int q = combo / RA, ka = combo - q * RA;
                 const int pair = 2 * pp + q;                                    // local to the half
                 cf v[8];
 #pragma unroll
@@ -646,8 +714,8 @@ template <int RA> constexpr int lw_merge_lds_elems() { return RA * 8 * 64 + lw_s
 
 template <class Ctx, int RA>
 AW_HD void lw_merge_tiles(Ctx &ctx, const LwParams &p, long long first, long long step, long long end) {
-    static_assert(RA == 4 || RA == 8 || RA == 16, "R = 32, 64 or 128 rows");
-    constexpr int R = 8 * RA, NKA = RA >= 8 ? RA / 8 : 1;
+    static_assert(lw_ra_ok(RA), "R = 8 RA rows");
+    constexpr int R = 8 * RA, NKA = (RA + 7) / 8;
     const int lane = ctx.lane(), wave = ctx.wave();
     cf *lds = ctx.lds();
     cf *sm = lds + RA * 8 * 64;
@@ -694,12 +762,12 @@ AW_HD void lw_merge_tiles(Ctx &ctx, const LwParams &p, long long first, long lon
 #pragma unroll
         for (int ka = 0; ka < RA; ++ka) F[ka] = ctx.ld(lds + (ka * 8 + wave) * 64 + lane);
         lw_odd_dft<true, RA>(F);
-        const long long f0 = (long long)win * p.hop - p.hist_len;
+        const long long f0 = p.frame0 + (long long)win * p.hop - p.hist_len;
 #pragma unroll
         for (int j2 = 0; j2 < RA; ++j2) {
             const int n = kLwM * (wave + 8 * j2) + t;
             const long long f = f0 + n;
-            if (n >= p.hist_len && f < p.frames) ctx.st_stream(reinterpret_cast<cf *>(p.out + (stream * p.frames + f) * 2), F[j2]);
+            if (n >= p.hist_len && f < p.frame_end) ctx.st_stream(reinterpret_cast<cf *>(p.out + (stream * p.frames + f) * 2), F[j2]);
         }
     }
 }

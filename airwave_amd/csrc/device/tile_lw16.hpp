@@ -104,7 +104,7 @@ template <bool INV, class Ctx> AW_HD void r16_tw2_apply(Ctx &ctx, cf (&v)[16], c
 }
 
 // forward: v[j] = row[a + 16 b + 256 j]  ->  v[m1] = X[kappa + 16 alpha + 256 m1].  SB >= 0: phase stamps SB.. (diagnostic builds)
-template <int SB = -1, class Ctx> AW_HD void r16_forward(Ctx &ctx, cf (&v)[16], const R16Thread &th) {
+template <int SB = -1, class Ctx, class Hook> AW_HD void r16_forward(Ctx &ctx, cf (&v)[16], const R16Thread &th, Hook &&before_pass3) {
     auto stamp = [&](int i) {              // (the values pass through an opaque asm first: arithmetic does not float across the stamp)
         if constexpr (SB >= 0) {
 #pragma unroll
@@ -131,6 +131,7 @@ template <int SB = -1, class Ctx> AW_HD void r16_forward(Ctx &ctx, cf (&v)[16], 
     stamp(6);
     r16_lane_transpose(ctx, v, th);
     stamp(7);
+    before_pass3();                                  // the caller's first table requests travel under the last pass
     fft16<false>(v);
     stamp(8);
 }
@@ -159,6 +160,9 @@ template <bool AFTER_INVERSE, class Ctx> AW_HD void r16_inverse(Ctx &ctx, cf (&v
 #ifndef AW_R16_TAB_DEPTH
 #define AW_R16_TAB_DEPTH 2      // batches in flight (1: issue, await, use)
 #endif
+#ifndef AW_R16_TAB_EARLY
+#define AW_R16_TAB_EARLY 0      // 1: the first table batches are requested before the transform's last pass
+#endif
 #ifndef AW_R16_ORDER
 #define AW_R16_ORDER 0          // issue order of the row and table loads, see lw_rows16_tiles
 #endif
@@ -186,6 +190,9 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
     auto row_src = [&](const LwRowTile &tl, int idx) -> const cf * {     // idx = 2 pair + (0: row ra, 1: row rb)
         const int pair = idx >> 1;
         const int row = (idx & 1) ? R - 1 - tl.rp : tl.rp;
+#ifdef AW_R16_ABL_LINEAR_ROWS     // timing ablation only (wrong results): rows laid out [row pair][stream-window][row of the tile]
+        return p.spec + (((long long)tl.rp * n_sw + tl.sw) * NROWS + idx) * kLwM + nth + 0 * (row + pair);
+#endif
         return p.spec + tl.sw * p.spec_per_sw + (long long)pair * p.N + (long long)row * kLwM + nth;
     };
     cf raw[16];
@@ -244,7 +251,22 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
                 prefetch_next();
                 ctx.sched_fence_hard();
             }
-            r16_forward<SB>(ctx, v, th);
+            // Table entries in batches of K, DEPTH batches in flight, fenced: left in one loop hipcc emits load, s_waitcnt vmcnt(0),
+            // eight multiply-accumulates, sixteen times over — sixteen exposed L2 round trips per row (8.9 k of its 15.6 k cycles).
+            // AW_R16_TAB_EARLY: the first DEPTH - 1 batches are requested before the transform's last pass.
+            constexpr int K = AW_R16_TAB_K, NBATCH = 16 / K, DEPTH = AW_R16_TAB_DEPTH;
+            LwTab2 tq[kTabEarly ? 1 : DEPTH][K];
+            auto issue = [&](int bi) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) tq[bi % DEPTH][i] = tab_entry(bi * K + i);
+            };
+            auto issue_first = [&]() {
+                if constexpr (!kTabEarly) {
+#pragma unroll
+                    for (int bi = 0; bi < DEPTH - 1 && bi < NBATCH; ++bi) issue(bi);
+                }
+            };
+            r16_forward<SB>(ctx, v, th, [&]() { if constexpr (AW_R16_TAB_EARLY) { ctx.sched_fence_hard(); issue_first(); ctx.sched_fence_hard(); } });
             ctx.sched_fence_hard();               // (table loads hoisted above the transform end up in scratch)
             if constexpr (SB >= 0) ctx.stamp(10);
             if constexpr (kTabEarly) {
@@ -254,16 +276,7 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
                     w2acc[m1] = cfma(v[m1], T[kTabEarly ? m1 : 0].w, w2acc[m1]);
                 }
             } else {
-                // Table entries in batches of K, DEPTH batches in flight, fenced: left in one loop hipcc emits load, s_waitcnt vmcnt(0),
-                // eight multiply-accumulates, sixteen times over — sixteen exposed L2 round trips per row (8.9 k of its 15.6 k cycles).
-                constexpr int K = AW_R16_TAB_K, NBATCH = 16 / K, DEPTH = AW_R16_TAB_DEPTH;
-                LwTab2 tq[DEPTH][K];
-                auto issue = [&](int bi) {
-#pragma unroll
-                    for (int i = 0; i < K; ++i) tq[bi % DEPTH][i] = tab_entry(bi * K + i);
-                };
-#pragma unroll
-                for (int bi = 0; bi < DEPTH - 1 && bi < NBATCH; ++bi) issue(bi);
+                if constexpr (!AW_R16_TAB_EARLY) issue_first();
 #pragma unroll
                 for (int bi = 0; bi < NBATCH; ++bi) {
                     if (bi + DEPTH - 1 < NBATCH) issue(bi + DEPTH - 1);
@@ -284,7 +297,11 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
             if constexpr (SB >= 0) ctx.stamp(11);
         });
         ctx.stamp(12);
+#ifdef AW_R16_ABL_LINEAR_ROWS
+        cf *dst = p.wrows + ((long long)tl.rp * n_sw + tl.sw) * (long long)(2 * kLwM) + nth;
+#else
         cf *dst = p.wrows + (tl.sw * (R / 2) + tl.rp) * (long long)(2 * kLwM) + nth;
+#endif
         r16_inverse<false>(ctx, w1acc, th);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {

@@ -2,6 +2,7 @@
 
 #include <cmath>
 #include <complex>
+#include <thread>
 
 namespace awh {
 
@@ -135,6 +136,28 @@ static void fft_inplace_tw(std::vector<cd> &a, const std::vector<cd> &tw) {
     }
 }
 
+// DFT of any length n = 2^a q, q in {1, 3, 5, 7} (the window lengths N = 8 RA x 4096 of the long-window path): q interleaved
+// power-of-two transforms, then X[k] = sum_{n1 < q} w_n^{n1 k} Sub_{n1}[k mod (n / q)].  unit_n[j] = exp(-2 pi i j / n), j < n.
+static void fft_any(std::vector<cd> &a, const std::vector<cd> &unit_n) {
+    const size_t n = a.size();
+    size_t q = n;
+    while (q % 2 == 0) q /= 2;
+    const size_t P = n / q;
+    std::vector<cd> twP(P / 2);
+    for (size_t k = 0; k < P / 2; ++k) twP[k] = unit_n[k * q];
+    if (q == 1) { fft_inplace_tw(a, twP); return; }
+    std::vector<std::vector<cd>> sub(q, std::vector<cd>(P));
+    for (size_t n1 = 0; n1 < q; ++n1) {
+        for (size_t m = 0; m < P; ++m) sub[n1][m] = a[q * m + n1];
+        fft_inplace_tw(sub[n1], twP);
+    }
+    for (size_t k = 0; k < n; ++k) {
+        cd acc = sub[0][k % P];
+        for (size_t n1 = 1; n1 < q; ++n1) acc += unit_n[(n1 * k) % n] * sub[n1][k % P];
+        a[k] = acc;
+    }
+}
+
 void build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
                      const int32_t *right_track, int R, LwTables &out, int rows_form) {
     const int M = awk::kLwM;
@@ -159,8 +182,8 @@ void build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels
     out.tw1m.resize(512);
     for (int t = 0; t < 512; ++t) out.tw1m[t] = unit((double)t, (double)M);
     // filter tables
-    std::vector<cd> tw(N / 2), mod(N);
-    for (size_t k = 0; k < N / 2; ++k) { const double a = -2.0 * M_PI * (double)k / (double)N; tw[k] = cd(std::cos(a), std::sin(a)); }
+    std::vector<cd> unit_n(N), mod(N);
+    for (size_t k = 0; k < N; ++k) { const double a = -2.0 * M_PI * (double)k / (double)N; unit_n[k] = cd(std::cos(a), std::sin(a)); }
     for (size_t n = 0; n < N; ++n) { const double a = -M_PI * (double)n / (double)N; mod[n] = cd(std::cos(a), std::sin(a)); }     // w_N^{n/2}
     const bool form16 = rows_form == 16;
     out.tab.clear(); out.tab16.clear(); out.tw2.clear();
@@ -177,14 +200,17 @@ void build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels
     for (int m1 = 0; m1 < 16; ++m1)
         for (int th = 0; th < awk::kR16Threads; ++th) pos16[awk::r16_bin(th, m1)] = m1 * awk::kR16Threads + th;
     const double scale = 1.0 / (2.0 * (double)N);
-    std::vector<cd> zl(N), zr(N);
     auto tap = [&](int track, size_t i) -> double {
         if (track < 0 || track >= n_tracks) return 0.0;
         return i < (size_t)taps ? (double)tracks[(size_t)track * taps + i] : 0.0;
     };
     const cd I(0.0, 1.0);
     auto c32 = [](cd v) { return awk::mk((float)v.real(), (float)v.imag()); };
-    for (int p = 0; p < n_pairs; ++p) {
+    // one host thread per channel pair (two N-point transforms each; the pairs write disjoint table entries): the analogue of the
+    // per-engine partition FFTs of ConvolutionEngine.init (Airwave/ConvolutionEngine.swift:143-182), which the reference also runs off
+    // the audio thread
+    auto build_pair = [&](int p) {
+        std::vector<cd> zl(N), zr(N);
         const int a = 2 * p, b = 2 * p + 1;
         const int la = left_track[a], ra_ = right_track[a];
         const int lb = b < n_channels ? left_track[b] : -1, rb_ = b < n_channels ? right_track[b] : -1;
@@ -193,8 +219,8 @@ void build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels
             zl[i] = i < (size_t)taps ? cd(use_a ? tap(la, i) : 0.0, use_b ? tap(lb, i) : 0.0) * mod[i] : cd(0.0, 0.0);
             zr[i] = i < (size_t)taps ? cd(use_a ? tap(ra_, i) : 0.0, use_b ? tap(rb_, i) : 0.0) * mod[i] : cd(0.0, 0.0);
         }
-        fft_inplace_tw(zl, tw);
-        fft_inplace_tw(zr, tw);
+        fft_any(zl, unit_n);
+        fft_any(zr, unit_n);
         const bool fold = real_last && p == n_pairs - 1;
         for (int rp = 0; rp < R / 2; ++rp) {
             for (int k2 = 0; k2 < M; ++k2) {
@@ -214,7 +240,11 @@ void build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels
                 }
             }
         }
-    }
+    };
+    std::vector<std::thread> workers;
+    for (int p = 1; p < n_pairs; ++p) workers.emplace_back(build_pair, p);
+    build_pair(0);
+    for (auto &w : workers) w.join();
 }
 
 }  // namespace awh

@@ -304,7 +304,6 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
         // every tuning knob of this path is read here, never on the process path
         sp->cmac_group = sp->n_pairs > 8;                               // the marched kernel's lane groups hold up to 8 channel pairs
         if (const char *e = getenv("AW_PART_CMAC")) sp->cmac_group = sp->cmac_group || std::strcmp(e, "group") == 0;
-        if (const char *e = getenv("AW_SPEC_SCRATCH_MB")) sp->scratch_budget = (size_t)atoll(e) << 20;
         // forward kernel form: all pairs of a window in one workgroup up to 4 pairs (cfg 3: 11.2 against 12.1 ms); with more pairs
         // the four-channel batches of 56-byte-or-wider frames each re-read every line (14 channels: fabric reads 4.3x the input),
         // and one pair per workgroup — the pairs of a window side by side on one XCD — wins (27.0 -> 22.7 ms).  AW_PART_FWD=1|2 forces.
@@ -316,6 +315,8 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
     // they use the same history buffer.  AW_LW: 0 never, 32/64/128 force that window, unset = the measured policy.
     if (const char *e = getenv("AW_LW")) sp->lw_mode = atoi(e);
     if (n_in > 16) sp->lw_mode = 0;                                                      // up to eight channel pairs
+    // scratch budget per stream chunk: of the partitioned kernels and of the long-window ones, which also serve path-0 layouts
+    if (const char *e = getenv("AW_SPEC_SCRATCH_MB")) sp->scratch_budget = (size_t)atoll(e) << 20;
     if (sp->lw_mode != 0) {
         sp->lw_tracks = hrir->tracks; sp->lw_n_tracks = hrir->n_tracks;
         sp->lw_left.assign(left_track, left_track + n_in); sp->lw_right.assign(right_track, right_track + n_in);
@@ -399,6 +400,7 @@ int64_t aw_spatializer_info(const aw_spatializer *sp, int32_t what) {
         case 4: return sp->hist_len;
         case 5: return sp->dominant_frames;   // output frames covered by the launch aw_spatializer_kernel_time() times (last call)
         case 7: return sp->last_lw_R;         // long-window path: rows R of the last call's windows (N = R x 4096); 0 = the partitioned kernels ran
+        case 8: return sp->last_lw_R2;        // rows of the last call's remainder window when it ran as two groups of windows (0: one group)
         case 6: return (int64_t)(sp->spec_capacity * sizeof(awk::cf) + (sp->stage_in_cap + sp->stage_out_cap) * sizeof(float));   // grow-only device buffers, bytes
         default: return -1;
     }
@@ -659,32 +661,62 @@ static int lw_fused_crossover_taps(int channels) {
     }
 }
 
-static int lw_choose(const aw_spatializer *sp, int64_t frames, bool for_reserve = false) {
-    if (sp->lw_mode == 0 || sp->n_channels > 16) return 0;
-    if (sp->path == 0 && sp->lw_mode < 0 && sp->taps < lw_fused_crossover_taps(sp->n_channels)) return 0;
+// A call runs as at most two groups of windows: `n` windows of R_a rows, then one window of R_b rows for what is left (either may be
+// absent).  Window lengths R = 8 RA, RA = 4 .. 16 without 11 and 13: the padded length sum(N) stays close to frames + windows x
+// history for every call length — the reference's cost per frame does not depend on the stream length (uniform partitions,
+// ConvolutionEngine.swift:93,232-367), and with three window lengths and one length per call this path's did (x 1.49 at 11 s).
+struct LwGroup { int R; int n_windows; long long frame0, frame_end; };
+struct LwCallPlan { int n_groups; LwGroup g[2]; double cost; };
+
+static const int kLwRowChoices[] = {32, 40, 48, 56, 64, 72, 80, 96, 112, 120, 128};
+
+static LwCallPlan lw_choose(const aw_spatializer *sp, int64_t frames, bool for_reserve = false) {
+    LwCallPlan none{};
+    if (sp->lw_mode == 0 || sp->n_channels > 16) return none;
+    if (sp->path == 0 && sp->lw_mode < 0 && sp->taps < lw_fused_crossover_taps(sp->n_channels)) return none;
     // calls inside what aw_spatializer_reserve() sized never build tables: only window lengths whose tables exist are candidates
     const bool existing_only = !for_reserve && frames <= sp->reserved_frames;
     auto have = [&](int R) { for (const auto &pl : sp->lw_plans) if (pl.R == R) return true; return false; };
-    const int C = sp->n_channels;
-    int best = 0;
-    double best_cost = 0.0;
-    for (int R : {32, 64, 128}) {
+    auto usable = [&](int R) {
         const long long N = (long long)R * awk::kLwM, hop = N - sp->hist_len;
-        if (hop < N / 4) continue;                                      // the window must be mostly new frames
-        if (sp->lw_mode > 0 && sp->lw_mode != R) continue;
-        if (existing_only && !have(R)) continue;
-        const long long windows = (frames + hop - 1) / hop;
-        const double cost = (double)windows * (double)N * (12.0 * C + 24.0);
-        if (!best || cost < best_cost) { best = R; best_cost = cost; }
+        if (hop < N / 4) return false;                                  // the window must be mostly new frames
+        if (sp->lw_mode > 0 && sp->lw_mode != R) return false;
+        if (existing_only && !have(R)) return false;
+        return true;
+    };
+    const int C = sp->n_channels;
+    const double per_frame = 12.0 * C + 24.0;
+    // a second group costs three more launches and their ramps: ~40 us of the device's time, in the cost's currency (bytes at ~5 TB/s)
+    const double group_penalty = 2.0e8 / (double)std::max(1, sp->n_streams);
+    LwCallPlan best{};
+    for (int Ra : kLwRowChoices) {
+        if (!usable(Ra)) continue;
+        const long long Na = (long long)Ra * awk::kLwM, hopa = Na - sp->hist_len;
+        {   // one group
+            const long long n = (frames + hopa - 1) / hopa;
+            const double cost = (double)n * (double)Na * per_frame;
+            if (!best.n_groups || cost < best.cost) { best = LwCallPlan{1, {{Ra, (int)n, 0, frames}, {}}, cost}; }
+        }
+        if (sp->lw_mode > 0) continue;                                  // a forced window length: one group
+        for (int Rb : kLwRowChoices) {
+            if (Rb >= Ra || !usable(Rb)) continue;
+            const long long Nb = (long long)Rb * awk::kLwM, hopb = Nb - sp->hist_len;
+            const long long n = frames > hopb ? (frames - hopb + hopa - 1) / hopa : 0;
+            if (n < 1) continue;                                        // (the remainder window alone: the one-group case of Rb)
+            const long long rest = frames - n * hopa;
+            if (rest <= 0) continue;
+            const double cost = ((double)n * (double)Na + (double)Nb) * per_frame + group_penalty;
+            if (cost < best.cost) best = LwCallPlan{2, {{Ra, (int)n, 0, n * hopa}, {Rb, 1, n * hopa, frames}}, cost};
+        }
     }
-    if (!best || sp->lw_mode > 0) return best;
-    const long long N = (long long)best * awk::kLwM, hop = N - sp->hist_len;
-    const long long row_tiles = (long long)sp->n_streams * ((frames + hop - 1) / hop) * (best / 2);
-    if (row_tiles < 32) return 0;        // (measured down to ONE stream x 10 s, 64 row tiles: 7 channels x 32768 taps 8.2 against 3.9 G frames/s partitioned)
+    if (!best.n_groups || sp->lw_mode > 0) return best;
+    long long row_tiles = 0;
+    for (int i = 0; i < best.n_groups; ++i) row_tiles += (long long)sp->n_streams * best.g[i].n_windows * (best.g[i].R / 2);
+    if (row_tiles < 32) return none;     // (measured down to ONE stream x 10 s, 64 row tiles: 7 channels x 32768 taps 8.2 against 3.9 G frames/s partitioned)
     double other_cost;
     if (sp->path == 0) {
         // past the measured crossover (above) the long call only has to fill its windows to 80 %
-        other_cost = 1.25 * (double)frames * (12.0 * C + 24.0);
+        other_cost = 1.25 * (double)frames * per_frame;
     } else {
         // Partitioned kernels, in the same currency (fabric-byte equivalents at the rate both kernel sets reach): a long call costs
         // ~110 + 13 C bytes per output frame up to eight channels (measured 20-23 G frames/s for C = 7, 29 for C = 2; the one-pair
@@ -696,7 +728,7 @@ static int lw_choose(const aw_spatializer *sp, int64_t frames, bool for_reserve 
         const long long blocks = (frames + sp->hop - 1) / sp->hop;
         other_cost = (double)sp->hop * b_part * (0.86 * (double)(blocks + sp->partitions - 1) + 0.14 * (double)blocks);
     }
-    return best_cost < other_cost ? best : 0;
+    return best.cost < other_cost ? best : none;
 }
 
 static aw_status lw_get_plan(aw_spatializer *sp, int R, const aw_spatializer::LwPlan **out) {
@@ -736,11 +768,11 @@ static aw_status lw_get_plan(aw_spatializer *sp, int R, const aw_spatializer::Lw
 
 // scratch of one stream chunk: rows of every (stream, window) + s1/s2
 struct LwScratch { long long n_windows; size_t per_stream; long long chunk; size_t need; long long spec_per_sw; };
-static LwScratch lw_scratch(const aw_spatializer *sp, int R, int64_t frames, size_t budget_bytes, size_t held_elems) {
+static LwScratch lw_scratch(const aw_spatializer *sp, int R, long long n_windows, size_t budget_bytes, size_t held_elems) {
     LwScratch r{};
-    const long long N = (long long)R * awk::kLwM, hop = N - sp->hist_len;
+    const long long N = (long long)R * awk::kLwM;
     const int real_last = sp->n_channels & 1;
-    r.n_windows = (frames + hop - 1) / hop;
+    r.n_windows = n_windows;
     const int n_pairs = (sp->n_channels + 1) / 2;                         // (a fused2 spatializer's n_pairs counts pseudo-pairs)
     r.spec_per_sw = (long long)(n_pairs - real_last) * N + (real_last ? N / 2 : 0);
     r.per_stream = (size_t)r.n_windows * (size_t)(r.spec_per_sw + N);
@@ -752,40 +784,32 @@ static LwScratch lw_scratch(const aw_spatializer *sp, int R, int64_t frames, siz
     r.need = r.per_stream * (size_t)r.chunk;
     return r;
 }
+// the stream chunk and scratch of a whole call plan: every group of the plan runs on the same chunk of streams
+static LwScratch lw_plan_scratch(const aw_spatializer *sp, const LwCallPlan &plan, size_t budget_bytes, size_t held_elems, LwScratch (&per_group)[2]) {
+    LwScratch all{};
+    all.chunk = sp->n_streams;
+    for (int i = 0; i < plan.n_groups; ++i) {
+        per_group[i] = lw_scratch(sp, plan.g[i].R, plan.g[i].n_windows, budget_bytes, held_elems);
+        all.chunk = std::min(all.chunk, per_group[i].chunk);
+    }
+    for (int i = 0; i < plan.n_groups; ++i) all.need = std::max(all.need, per_group[i].per_stream * (size_t)all.chunk);
+    return all;
+}
 
-static aw_status sp_process_longwin(aw_spatializer *sp, int R, const float *in, float *out, int64_t frames) {
-    const aw_spatializer::LwPlan *plan = nullptr;
-    aw_status st = lw_get_plan(sp, R, &plan);
+static aw_status sp_process_longwin(aw_spatializer *sp, const LwCallPlan &call, const float *in, float *out, int64_t frames) {
+    const aw_spatializer::LwPlan *tables[2] = {nullptr, nullptr};
+    for (int i = 0; i < call.n_groups; ++i) {
+        aw_status st = lw_get_plan(sp, call.g[i].R, &tables[i]);
+        if (st != AW_OK) return st;
+    }
+    for (int i = 0; i < call.n_groups; ++i) (void)lw_get_plan(sp, call.g[i].R, &tables[i]);     // (the second build may have moved the first plan)
+    LwScratch per_group[2];
+    const LwScratch sc = lw_plan_scratch(sp, call, part_budget(sp), frames <= sp->reserved_frames ? sp->spec_capacity : 0, per_group);
+    aw_status st = part_ensure_scratch(sp, sc.need);
     if (st != AW_OK) return st;
-    const LwScratch sc = lw_scratch(sp, R, frames, part_budget(sp), frames <= sp->reserved_frames ? sp->spec_capacity : 0);
-    st = part_ensure_scratch(sp, sc.need);
-    if (st != AW_OK) return st;
-    const long long N = (long long)R * awk::kLwM;
     sp->dominant_frames = 0;
     for (long long s0 = 0; s0 < sp->n_streams; s0 += sc.chunk) {
         const int ns = (int)std::min<long long>(sc.chunk, sp->n_streams - s0);
-        awk::LwParams p{};
-        p.in = in + (size_t)s0 * frames * sp->n_channels;
-        p.out = out + (size_t)s0 * frames * 2;
-        p.hist = sp->d_hist[sp->hist_cur] + (size_t)s0 * sp->hist_len * sp->n_channels;
-        p.hist_out = sp->d_hist[sp->hist_cur ^ 1] + (size_t)s0 * sp->hist_len * sp->n_channels;      // the tail carry rides along in the split kernel
-        p.zeros = sp->ctx->d_zeros;
-        p.frames = frames; p.n_channels = sp->n_channels; p.n_pairs = (sp->n_channels + 1) / 2; p.real_last = sp->n_channels & 1;
-        p.hist_len = sp->hist_len; p.hop = (int)(N - sp->hist_len); p.n_windows = (int)sc.n_windows;
-        p.R = R; p.N = (int)N;
-        p.spec = sp->d_spec; p.spec_per_sw = sc.spec_per_sw;
-        p.wrows = sp->d_spec + (size_t)sc.chunk * sc.n_windows * sc.spec_per_sw;
-        p.tab = plan->d_tab; p.tw_coarse = plan->d_coarse; p.tw_fine = plan->d_fine; p.tw_step = plan->d_step; p.tw_r = plan->d_tw_r; p.tw1m = plan->d_tw1m;
-        p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb;
-        p.persistent_wgs = sp->ctx->cfg.persistent_wgs;
-        p.rows_pairs_per_batch = sp->ctx->cfg.lw_rows_pb;
-        p.rows_form = plan->d_tab16 ? 16 : 8; p.tab16 = plan->d_tab16; p.tw2 = plan->d_tw2; p.rows16_wgs = sp->ctx->cfg.lw_rows16_wgs;
-        p.n_streams = ns;
-        if (sp->n_channels > 8) {        // the wide split kernel reads the last frame of the last stream from a padded copy (allocated at create)
-            AW_HIP_TRY(hipMemcpyAsync(sp->d_tail, p.in + ((size_t)ns * frames - 1) * sp->n_channels, sp->n_channels * sizeof(float),
-                                      hipMemcpyDeviceToDevice, sp->ctx->stream));
-            p.tail = sp->d_tail;
-        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (sp->profiling) {
             e0 = sp_get_event(sp); e1 = sp_get_event(sp);
@@ -793,9 +817,37 @@ static aw_status sp_process_longwin(aw_spatializer *sp, int R, const float *in, 
         }
         SpStageTimer tm(sp);
         awk::StageTimer *tmp = sp->profiling ? &tm : nullptr;
-        AW_HIP_TRY(awk::launch_lw_split(p, ns, sp->ctx->stream, tmp));
-        AW_HIP_TRY(awk::launch_lw_rows(p, ns, sp->ctx->stream, tmp));
-        AW_HIP_TRY(awk::launch_lw_merge(p, ns, sp->ctx->stream, tmp));
+        if (sp->n_channels > 8)          // the wide split kernel reads the last frame of the last stream from a padded copy (allocated at create)
+            AW_HIP_TRY(hipMemcpyAsync(sp->d_tail, in + ((size_t)(s0 + ns) * frames - 1) * sp->n_channels, sp->n_channels * sizeof(float),
+                                      hipMemcpyDeviceToDevice, sp->ctx->stream));
+        for (int gi = 0; gi < call.n_groups; ++gi) {
+            const LwGroup &g = call.g[gi];
+            const aw_spatializer::LwPlan *plan = tables[gi];
+            const long long N = (long long)g.R * awk::kLwM;
+            awk::LwParams p{};
+            p.in = in + (size_t)s0 * frames * sp->n_channels;
+            p.out = out + (size_t)s0 * frames * 2;
+            p.hist = sp->d_hist[sp->hist_cur] + (size_t)s0 * sp->hist_len * sp->n_channels;
+            // the tail carry rides along in the split kernel of the LAST group: its last window spans the last hist_len frames of the call
+            p.hist_out = gi == call.n_groups - 1 ? sp->d_hist[sp->hist_cur ^ 1] + (size_t)s0 * sp->hist_len * sp->n_channels : nullptr;
+            p.zeros = sp->ctx->d_zeros;
+            p.frames = frames; p.frame0 = g.frame0; p.frame_end = g.frame_end;
+            p.n_channels = sp->n_channels; p.n_pairs = (sp->n_channels + 1) / 2; p.real_last = sp->n_channels & 1;
+            p.hist_len = sp->hist_len; p.hop = (int)(N - sp->hist_len); p.n_windows = g.n_windows;
+            p.R = g.R; p.N = (int)N;
+            p.spec = sp->d_spec; p.spec_per_sw = per_group[gi].spec_per_sw;
+            p.wrows = sp->d_spec + (size_t)sc.chunk * g.n_windows * per_group[gi].spec_per_sw;
+            p.tab = plan->d_tab; p.tw_coarse = plan->d_coarse; p.tw_fine = plan->d_fine; p.tw_step = plan->d_step; p.tw_r = plan->d_tw_r; p.tw1m = plan->d_tw1m;
+            p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb;
+            p.persistent_wgs = sp->ctx->cfg.persistent_wgs;
+            p.rows_pairs_per_batch = sp->ctx->cfg.lw_rows_pb;
+            p.rows_form = plan->d_tab16 ? 16 : 8; p.tab16 = plan->d_tab16; p.tw2 = plan->d_tw2; p.rows16_wgs = sp->ctx->cfg.lw_rows16_wgs;
+            p.n_streams = ns;
+            p.tail = sp->n_channels > 8 ? sp->d_tail : nullptr;
+            AW_HIP_TRY(awk::launch_lw_split(p, ns, sp->ctx->stream, tmp));
+            AW_HIP_TRY(awk::launch_lw_rows(p, ns, sp->ctx->stream, tmp));
+            AW_HIP_TRY(awk::launch_lw_merge(p, ns, sp->ctx->stream, tmp));
+        }
         if (sp->profiling) {
             AW_HIP_TRY(hipEventRecord(e1, sp->ctx->stream));
             sp->pending.emplace_back(e0, e1);
@@ -813,17 +865,19 @@ aw_status aw_spatializer_reserve(aw_spatializer *sp, int64_t max_frames) {
     if (!sp) return fail(AW_ERR_INVALID_ARGUMENT, "sp is NULL");
     if (max_frames <= 0) return fail(AW_ERR_INVALID_ARGUMENT, "max_frames must be positive");
     AW_HIP_TRY(hipSetDevice(sp->ctx->device));
-    const int lw_R_res = lw_choose(sp, max_frames, true);
-    if (sp->path == 1 || lw_R_res) {
+    const LwCallPlan lw_res = lw_choose(sp, max_frames, true);
+    if (sp->path == 1 || lw_res.n_groups) {
         // shorter calls than max_frames may run on the partitioned kernels or on a smaller window: size for both kernel sets
         size_t need = 0;
         if (sp->path == 1) need = part_plan(sp, max_frames, part_budget(sp)).need;
-        const int lw_R = lw_R_res;
-        if (lw_R) {
+        for (int i = 0; i < lw_res.n_groups; ++i) {
             const aw_spatializer::LwPlan *plan = nullptr;
-            aw_status st = lw_get_plan(sp, lw_R, &plan);
+            aw_status st = lw_get_plan(sp, lw_res.g[i].R, &plan);
             if (st != AW_OK) return st;
-            need = std::max(need, lw_scratch(sp, lw_R, max_frames, part_budget(sp), 0).need);
+        }
+        if (lw_res.n_groups) {
+            LwScratch per_group[2];
+            need = std::max(need, lw_plan_scratch(sp, lw_res, part_budget(sp), 0, per_group).need);
         }
         aw_status st = part_ensure_scratch(sp, need);
         if (st != AW_OK) return st;
@@ -843,14 +897,26 @@ aw_status aw_spatializer_process(aw_spatializer *sp, const float *in, float *out
     if (frames <= 0) return frames == 0 ? AW_OK : fail(AW_ERR_INVALID_ARGUMENT, "frames must be >= 0");
     AW_HIP_TRY(hipSetDevice(sp->ctx->device));
     aw_status st = AW_OK;
-    const int lw_R = lw_choose(sp, frames);
+    const LwCallPlan lw = lw_choose(sp, frames);
+    const int lw_R = lw.n_groups ? lw.g[0].R : 0;
     sp->last_lw_R = lw_R;
-    if (lw_R) st = sp_process_longwin(sp, lw_R, in, out, frames);
-    else if (sp->path == 0) st = sp_process_fused(sp, in, out, frames);
-    else st = sp_process_partitioned(sp, in, out, frames);
+    sp->last_lw_R2 = lw.n_groups > 1 ? lw.g[1].R : 0;
+    bool lw_ran = false;
+    if (lw_R) {
+        st = sp_process_longwin(sp, lw, in, out, frames);
+        lw_ran = st == AW_OK;
+        if (st == AW_ERR_OUT_OF_MEMORY) {
+            // the long-window kernels are an optimisation: without memory for their tables or scratch the call takes the kernels
+            // that have always served this spatializer (nothing has been launched yet: allocation comes first)
+            (void)hipGetLastError();
+            sp->last_lw_R = 0; sp->last_lw_R2 = 0;
+            st = AW_OK;
+        }
+    }
+    if (st == AW_OK && !lw_ran) st = sp->path == 0 ? sp_process_fused(sp, in, out, frames) : sp_process_partitioned(sp, in, out, frames);
     if (st != AW_OK) return st;
     // carry the convolution tail: next call's history = last hist_len frames of (history ++ input)
-    if (!lw_R) {      // (the long-window split kernel has written it on the way)
+    if (!lw_ran) {    // (the long-window split kernel has written it on the way)
         float *h_old = sp->d_hist[sp->hist_cur], *h_new = sp->d_hist[sp->hist_cur ^ 1];
         SpStageTimer tm(sp);
         if (sp->profiling) tm.begin();

@@ -67,7 +67,8 @@ struct aw_spatializer {
     std::vector<int32_t> lw_left, lw_right;
     int lw_n_tracks = 0;
     float *d_tail = nullptr;            // 32 floats: the last frame of the last stream of a call + zeros (wide split kernel, tile_lw.hpp)
-    int last_lw_R = 0;                  // R of the last call (0: the partitioned kernels ran)
+    int last_lw_R = 0;                  // R of the last call's (first group of) windows (0: the partitioned kernels ran)
+    int last_lw_R2 = 0;                 // R of its remainder window when the call ran as two groups
     int64_t reserved_frames = 0;        // aw_spatializer_reserve(): buffers are sized for calls up to this many frames
     // host-entry staging (grow-only)
     float *d_stage_in = nullptr, *d_stage_out = nullptr;

@@ -9,9 +9,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _DEFS = os.environ.get("AW_EMU_DEFINES", "").split()          # e.g. "-DAW_SUBFFT_SKEW=1": emulate a tuning variant
 _LIB = os.path.join(_HERE, "libemu.so" if not _DEFS else "libemu_variant.so")
-_SRCS = [os.path.join(_HERE, "emu_harness.cpp"), os.path.join(_ROOT, "airwave_amd/csrc/host/tables.cpp"),
+_SRCS = [os.path.join(_HERE, "emu_harness.cpp"), os.path.join(_HERE, "emu_lw.cpp"), os.path.join(_ROOT, "airwave_amd/csrc/host/tables.cpp"),
          os.path.join(_ROOT, "airwave_amd/csrc/host/eq.cpp")]
-_DEPS = _SRCS + [os.path.join(_ROOT, "airwave_amd/csrc/device", f) for f in ("tile_ols.hpp", "tile_ols2.hpp", "tile_march.hpp", "tile_lw.hpp", "tile_lw16.hpp", "cplx.hpp", "eq_cascade.hpp")] + [
+_DEPS = _SRCS + [os.path.join(_HERE, "emu_ctx.hpp")] + [os.path.join(_ROOT, "airwave_amd/csrc/device", f) for f in ("tile_ols.hpp", "tile_ols2.hpp", "tile_march.hpp", "tile_lw.hpp", "tile_lw16.hpp", "cplx.hpp", "eq_cascade.hpp")] + [
     os.path.join(_ROOT, "airwave_amd/csrc/host/tables.hpp"), os.path.join(_ROOT, "airwave_amd/csrc/host/eq.hpp")]
 _lib = None
 
@@ -23,7 +23,15 @@ def lib():
     global _lib
     if _lib is None:
         if _DEFS or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(d) for d in _DEPS):
-            subprocess.run(["g++", "-std=c++20", "-O2", "-pthread", "-shared", "-fPIC"] + _DEFS + ["-o", _LIB] + _SRCS, check=True)
+            # the translation units compile side by side (the long-window kernels alone are 176 template instantiations)
+            units = [(src, []) for src in _SRCS] + [(os.path.join(_HERE, "emu_lw.cpp"), [f"-DEMU_LW_PART={k}"]) for k in (1, 2, 3)]
+            objs = [f"{_LIB}.{i}.o" for i in range(len(units))]
+            procs = [subprocess.Popen(["g++", "-std=c++20", "-O2", "-pthread", "-fPIC"] + _DEFS + extra + ["-c", src, "-o", o]) for (src, extra), o in zip(units, objs)]
+            if any(p.wait() != 0 for p in procs):
+                raise RuntimeError("emulation harness failed to compile")
+            subprocess.run(["g++", "-shared", "-pthread", "-o", _LIB] + objs, check=True)
+            for o in objs:
+                os.remove(o)
         _lib = ctypes.CDLL(_LIB)
         _lib.emu_fused_ols.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
                                        ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -32,6 +40,7 @@ def lib():
         _lib.emu_longwin.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
                                      ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
         _lib.emu_fft_small.argtypes = [fp, ctypes.c_int, ctypes.c_int]
+        _lib.emu_lw_dft.argtypes = [fp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _lib.emu_eq_process.argtypes = [fp, fp, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_longlong, ctypes.c_double,
                                         ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int]
     return _lib
@@ -95,6 +104,13 @@ def longwin(x, tracks, left_track, right_track, R=32, hop=None, hist=None, rows_
                            F, S, R, hop, rows_pb, None if hist_out is None else hist_out.ctypes.data_as(fp))
     assert rc == 0, rc
     return out
+
+
+def lw_dft(v, inverse=False, odd=False):
+    """The split / merge kernels' in-register DFT of len(v) points (n = 2^a q); odd: sampled at k + 1/2."""
+    a = np.ascontiguousarray(np.asarray(v, dtype=np.complex64)).view(np.float32).copy()
+    assert lib().emu_lw_dft(a.ctypes.data_as(fp), a.size // 2, int(inverse), int(odd)) == 0
+    return a.view(np.complex64)
 
 
 def fft_small(v, inverse=False):

@@ -1,96 +1,5 @@
-// emu_harness.cpp — TEST-ONLY thread emulation of the HIP tile kernel.
-//
-// Compiles airwave_amd/csrc/device/tile_ols.hpp (the exact code the GPU runs) with g++ and
-// executes one workgroup as 512 std::threads: workgroup barriers are std::barrier(512),
-// wave-level syncs are std::barrier(64).  It exists so index math, twiddles and LDS hazards can
-// be checked on the CPU-only build container before spending GPU minutes.  It is NOT part of the
-// product library and nothing under airwave_amd/ links it.
-#include <barrier>
-#include <cmath>
-#include <cstdint>
-#include <cstdlib>
-#include <cstring>
-#include <memory>
-#include <thread>
-#include <vector>
-
-#include "../../airwave_amd/csrc/device/tile_ols.hpp"
-#include "../../airwave_amd/csrc/device/tile_march.hpp"
-#include "../../airwave_amd/csrc/device/tile_lw.hpp"
-#include "../../airwave_amd/csrc/device/tile_lw16.hpp"
-#include "../../airwave_amd/csrc/device/eq_cascade.hpp"
-#include "../../airwave_amd/csrc/host/eq.hpp"
-#include "../../airwave_amd/csrc/host/tables.hpp"
-
-namespace {
-
-alignas(16) float g_zeros[1024] = {0};
-
-struct EmuShared {
-    std::barrier<> wg;
-    std::vector<std::unique_ptr<std::barrier<>>> wave;
-    std::vector<awk::cf> lds;
-    std::vector<awk::cf> xs;      // cross-lane swap mailbox: [thread][2]
-    explicit EmuShared(int threads = awk::kThreads, size_t lds_elems = (size_t)awk::kLdsElems) : wg(threads), lds(lds_elems), xs((size_t)threads * 2) {
-        for (int w = 0; w < threads / 64; ++w) wave.emplace_back(new std::barrier<>(64));
-    }
-};
-
-struct EmuCtx {
-    int tid_;
-    EmuShared *sh;
-    int tid() const { return tid_; }
-    int lane() const { return tid_ & 63; }
-    int wave() const { return tid_ >> 6; }
-    awk::cf *lds() const { return sh->lds.data(); }
-    awk::cf opaque(awk::cf v) const { return v; }
-    int opaque_i(int v) const { return v; }
-    void stamp(int) const {}
-    void sched_fence() const {}
-    void sched_fence_hard() const {}
-    void flush_stamps() const {}
-    awk::cf ld(const awk::cf *p) const { return *p; }
-    void stagger(int, int) const {}
-    void barrier() const { sh->wg.arrive_and_wait(); }
-    // lanes with bit b = 0: hi' = partner.lo ; lanes with bit b = 1: lo' = partner.hi ; partner = lane ^ (1 << b)
-    void xswap(awk::cf &lo, awk::cf &hi, int bit) const {
-        sh->xs[(size_t)tid_ * 2] = lo; sh->xs[(size_t)tid_ * 2 + 1] = hi;
-        sh->wave[tid_ >> 6]->arrive_and_wait();
-        const int p = tid_ ^ (1 << bit);
-        if ((tid_ >> bit) & 1) lo = sh->xs[(size_t)p * 2 + 1]; else hi = sh->xs[(size_t)p * 2];
-        sh->wave[tid_ >> 6]->arrive_and_wait();
-    }
-    void wave_sync() const { sh->wave[tid_ >> 6]->arrive_and_wait(); }
-    template <int STRIDE> void ld8x2(awk::cf (&a)[8], const awk::cf *p0, awk::cf (&b)[8], const awk::cf *p1) const {
-        for (int i = 0; i < 8; ++i) { a[i] = p0[i * STRIDE]; b[i] = p1[i * STRIDE]; }
-    }
-    void st_stream(awk::cf *q, awk::cf v) const { *q = v; }
-    awk::cf ld_stream(const awk::cf *q) const { return *q; }
-    void st_stream4(float *q, float a, float b, float c, float d) const { q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
-    awk::cf xchg1(awk::cf v) const {          // value of lane ^ 1
-        sh->xs[(size_t)tid_ * 2] = v;
-        sh->wave[tid_ >> 6]->arrive_and_wait();
-        const awk::cf r = sh->xs[(size_t)(tid_ ^ 1) * 2];
-        sh->wave[tid_ >> 6]->arrive_and_wait();
-        return r;
-    }
-    // in-register scan moves of eq_cascade.hpp (DPP on the GPU): value of another lane of the wave, or zero / fill
-    double lane_value(double v, int src_lane, double otherwise) const {     // src_lane < 0: no source
-        double *box = reinterpret_cast<double *>(&sh->xs[(size_t)tid_ * 2]);
-        *box = v;
-        sh->wave[tid_ >> 6]->arrive_and_wait();
-        const double r = src_lane < 0 ? otherwise : *reinterpret_cast<const double *>(&sh->xs[(size_t)((tid_ & ~63) + src_lane) * 2]);
-        sh->wave[tid_ >> 6]->arrive_and_wait();
-        return r;
-    }
-    void fma_in_place(double &x, double a, double c, double, double) const { x = __builtin_fma(a, x, c); }
-    template <int D> double row_shr(double v) const { const int l = tid_ & 63; return lane_value(v, (l & 15) >= D ? l - D : -1, 0.0); }
-    double row_bcast15(double v) const { const int l = tid_ & 63; return lane_value(v, ((l >> 4) & 1) ? (l & ~15) - 1 : -1, 0.0); }
-    double row_bcast31(double v) const { const int l = tid_ & 63; return lane_value(v, l >= 32 ? 31 : -1, 0.0); }
-    double wave_shr1(double v, double fill) const { const int l = tid_ & 63; return lane_value(v, l > 0 ? l - 1 : -1, fill); }
-};
-
-}  // namespace
+// emu_harness.cpp — TEST-ONLY thread emulation of the HIP tile kernels (fused, partitioned, EQ); the long-window kernels: emu_lw.cpp.
+#include "emu_ctx.hpp"
 
 extern "C" {
 
@@ -348,115 +257,6 @@ int emu_partitioned(const float *in, float *out, const float *hist, const float 
                     }
     }
     run([&](EmuCtx &ctx, int s, int b) { tile_part_inverse<EmuCtx>(ctx, p, s, b); }, p.n_blocks);
-    return 0;
-}
-
-// The long-window path (tile_lw.hpp): split -> rows -> merge on windows of N = R x 4096 frames, R in {32, 64, 128}.
-// hist: [stream][hist_len][C] or NULL; hist_len = N - hop must be >= taps - 1 (hop given by the caller).
-int emu_longwin(const float *in, float *out, const float *hist, const float *tracks, int n_tracks, int taps, int n_channels,
-                const int32_t *left_track, const int32_t *right_track, long long frames, int n_streams, int R, int hop, int rows_pb, float *hist_out) {
-    using namespace awk;
-    if (R != 32 && R != 64 && R != 128) return -1;
-    const long long N = (long long)R * kLwM;
-    if (hop <= 0 || N - hop < taps - 1 || n_channels < 1 || n_channels > 16) return -2;
-    awh::Twiddles tw;
-    awh::build_twiddles(tw);
-    awh::LwTables lt;
-    const bool form16 = rows_pb == 16;                   // the 16-points-per-thread rows kernel (tile_lw16.hpp)
-    awh::build_lw_tables(tracks, n_tracks, taps, n_channels, left_track, right_track, R, lt, form16 ? 16 : 8);
-    LwParams p{};
-    p.rows_form = form16 ? 16 : 8; p.tab16 = lt.tab16.data(); p.tw2 = lt.tw2.data();
-    p.in = in; p.out = out; p.zeros = g_zeros; p.frames = frames;
-    p.n_channels = n_channels; p.n_pairs = (n_channels + 1) / 2; p.real_last = n_channels & 1;
-    p.hop = hop; p.hist_len = (int)(N - hop); p.n_windows = (int)((frames + hop - 1) / hop);
-    p.R = R; p.N = (int)N;
-    std::vector<float> hist_pad((size_t)n_streams * p.hist_len * n_channels + 4, 0.f);
-    if (hist) std::memcpy(hist_pad.data(), hist, ((size_t)n_streams * p.hist_len * n_channels) * sizeof(float));
-    p.hist = hist_pad.data();
-    p.hist_out = hist_out;
-    p.spec_per_sw = (long long)(p.n_pairs - p.real_last) * N + (p.real_last ? N / 2 : 0);
-    const long long n_sw = (long long)n_streams * p.n_windows;
-    std::vector<cf> spec((size_t)(n_sw * p.spec_per_sw), mk(NAN, NAN)), wrows((size_t)(n_sw * N), mk(NAN, NAN));
-    p.spec = spec.data(); p.wrows = wrows.data();
-    p.tab = lt.tab.data(); p.tw_coarse = lt.coarse.data(); p.tw_fine = lt.fine.data(); p.tw_step = lt.step.data(); p.tw_r = lt.tw_r.data(); p.tw1m = lt.tw1m.data();
-    p.twa = tw.twa.data(); p.twb = tw.twb.data();
-    EmuShared sh;
-    auto run = [&](auto fn) {            // one emulated persistent workgroup walks every tile
-        std::vector<std::thread> th;
-        th.reserve(kThreads);
-        for (int t = 0; t < kThreads; ++t) th.emplace_back([&, t]() { EmuCtx ctx{t, &sh}; fn(ctx); });
-        for (auto &x : th) x.join();
-    };
-    const long long n_st = n_sw * kLwChunks;
-    std::vector<float> tail(32, 0.f);
-    std::memcpy(tail.data(), in + ((size_t)n_streams * frames - 1) * n_channels, n_channels * sizeof(float));
-    p.tail = tail.data(); p.n_streams = n_streams;
-    auto split = [&](auto RA) {
-        constexpr int ra = decltype(RA)::value;
-        if (n_channels > 8) {              // one launch: both channel halves of a frame in one wave
-            const long long n_stw = n_sw * kLwChunksW;
-            run([&](EmuCtx &ctx) {
-                switch (n_channels - 8) {
-                    case 1: lw_split_wide_tiles<EmuCtx, ra, 1>(ctx, p, 0, 1, n_stw); break; case 2: lw_split_wide_tiles<EmuCtx, ra, 2>(ctx, p, 0, 1, n_stw); break;
-                    case 3: lw_split_wide_tiles<EmuCtx, ra, 3>(ctx, p, 0, 1, n_stw); break; case 4: lw_split_wide_tiles<EmuCtx, ra, 4>(ctx, p, 0, 1, n_stw); break;
-                    case 5: lw_split_wide_tiles<EmuCtx, ra, 5>(ctx, p, 0, 1, n_stw); break; case 6: lw_split_wide_tiles<EmuCtx, ra, 6>(ctx, p, 0, 1, n_stw); break;
-                    case 7: lw_split_wide_tiles<EmuCtx, ra, 7>(ctx, p, 0, 1, n_stw); break; default: lw_split_wide_tiles<EmuCtx, ra, 8>(ctx, p, 0, 1, n_stw); break;
-                }
-            });
-            return;
-        }
-        run([&](EmuCtx &ctx) {
-            switch (n_channels) {
-                case 1: lw_split_tiles<EmuCtx, ra, 1>(ctx, p, 0, 1, n_st); break; case 2: lw_split_tiles<EmuCtx, ra, 2>(ctx, p, 0, 1, n_st); break;
-                case 3: lw_split_tiles<EmuCtx, ra, 3>(ctx, p, 0, 1, n_st); break; case 4: lw_split_tiles<EmuCtx, ra, 4>(ctx, p, 0, 1, n_st); break;
-                case 5: lw_split_tiles<EmuCtx, ra, 5>(ctx, p, 0, 1, n_st); break; case 6: lw_split_tiles<EmuCtx, ra, 6>(ctx, p, 0, 1, n_st); break;
-                case 7: lw_split_tiles<EmuCtx, ra, 7>(ctx, p, 0, 1, n_st); break; default: lw_split_tiles<EmuCtx, ra, 8>(ctx, p, 0, 1, n_st); break;
-            }
-        });
-    };
-    if (R == 32) split(LwIdx<4>{}); else if (R == 64) split(LwIdx<8>{}); else split(LwIdx<16>{});
-    const long long n_rt = n_sw * (R / 2);
-    auto rows = [&](auto PBB) {
-        constexpr int pb = decltype(PBB)::value;
-        run([&](EmuCtx &ctx) {
-            auto go = [&](auto NPP, auto REAL) {
-                lw_rows_tiles<EmuCtx, decltype(NPP)::value, (decltype(REAL)::value != 0), (decltype(NPP)::value > 4 ? 1 : pb)>(ctx, p, 0, 1, n_rt, n_sw, 0, 1);
-            };
-            const int np = p.n_pairs;
-            auto go_np = [&](auto REAL) {
-                switch (np) {
-                    case 1: go(LwIdx<1>{}, REAL); break; case 2: go(LwIdx<2>{}, REAL); break; case 3: go(LwIdx<3>{}, REAL); break; case 4: go(LwIdx<4>{}, REAL); break;
-                    case 5: go(LwIdx<5>{}, REAL); break; case 6: go(LwIdx<6>{}, REAL); break; case 7: go(LwIdx<7>{}, REAL); break; default: go(LwIdx<8>{}, REAL); break;
-                }
-            };
-            if (p.real_last) go_np(LwIdx<1>{}); else go_np(LwIdx<0>{});
-        });
-    };
-    if (form16) {
-        EmuShared sh16(kR16Threads, (size_t)kR16LdsElems);
-        std::vector<std::thread> th;
-        th.reserve(kR16Threads);
-        for (int t = 0; t < kR16Threads; ++t)
-            th.emplace_back([&, t]() {
-                EmuCtx ctx{t, &sh16};
-                auto go = [&](auto NPP, auto REAL) {
-                    lw_rows16_tiles<EmuCtx, decltype(NPP)::value, (decltype(REAL)::value != 0)>(ctx, p, 0, 1, n_rt, n_sw, 0, 1);
-                };
-                auto go_np = [&](auto REAL) {
-                    switch (p.n_pairs) {
-                        case 1: go(LwIdx<1>{}, REAL); break; case 2: go(LwIdx<2>{}, REAL); break; case 3: go(LwIdx<3>{}, REAL); break; case 4: go(LwIdx<4>{}, REAL); break;
-                        case 5: go(LwIdx<5>{}, REAL); break; case 6: go(LwIdx<6>{}, REAL); break; case 7: go(LwIdx<7>{}, REAL); break; default: go(LwIdx<8>{}, REAL); break;
-                    }
-                };
-                if (p.real_last) go_np(LwIdx<1>{}); else go_np(LwIdx<0>{});
-            });
-        for (auto &x : th) x.join();
-    } else if (rows_pb == 1) rows(LwIdx<1>{}); else rows(LwIdx<2>{});
-    run([&](EmuCtx &ctx) {
-        if (R == 32) lw_merge_tiles<EmuCtx, 4>(ctx, p, 0, 1, n_st);
-        else if (R == 64) lw_merge_tiles<EmuCtx, 8>(ctx, p, 0, 1, n_st);
-        else lw_merge_tiles<EmuCtx, 16>(ctx, p, 0, 1, n_st);
-    });
     return 0;
 }
 

@@ -23,7 +23,7 @@ def _case(oracle, channels, taps, frames, R, seed=5, hop=None, hist_frames=0):
 
 
 @pytest.mark.parametrize("channels,rows_pb", [(7, 2), (8, 2), (1, 2), (2, 2), (5, 2), (7, 1), (6, 1), (1, 1), (14, 1), (9, 1), (13, 2), (16, 1), (12, 1), (11, 1),
-                                              (7, 16), (8, 16), (1, 16), (2, 16), (5, 16), (14, 16), (13, 16)])
+                                              (7, 16), (8, 16), (1, 16), (14, 16), (13, 16)])
 def test_emulated_long_window_matches_truth(oracle, channels, rows_pb):
     # one window of 32 x 4096 frames holds the whole call: history (zeros), input, zero fill past the end;
     # rows_pb = channel pairs per batch of the rows kernel (1: the two-workgroups-per-CU form; 16: the 16-points-per-thread
@@ -54,6 +54,34 @@ def test_emulated_long_window_two_windows_and_history(oracle, rows_pb):
     assert np.array_equal(hist_out, x[:, -hist_len:])          # the split kernel carried the convolution tail
     for ear in range(2):
         assert oracle.peak_rel_error(y[0, :, ear], ref[hist_len:, ear]) < TOL
+
+
+@pytest.mark.parametrize("n", range(2, 17))
+def test_in_register_dfts_of_every_size(n):
+    # the split / merge kernels' DFT over the register index (tile_lw.hpp lw_fft / lw_odd_dft): powers of two, odd primes (direct),
+    # mixed sizes (Cooley-Tukey with compile-time twiddles)
+    rng = np.random.default_rng(n)
+    v = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    j = np.arange(n)
+    for inv in (False, True):
+        for odd in (False, True):
+            h = 0.5 if odd else 0.0
+            # forward: out[k] = sum_j v[j] w^{j (k + h)};  inverse: out[j] = sum_k v[k] conj(w)^{j (k + h)}
+            M = np.exp(-2j * np.pi * (j[:, None] + h) * j[None, :] / n) if not inv else np.exp(2j * np.pi * j[:, None] * (j[None, :] + h) / n)
+            ref = M @ v.astype(np.complex128)
+            got = emu.lw_dft(v, inv, odd)
+            assert np.abs(got - ref).max() < 2e-6 * np.abs(ref).max(), (n, inv, odd)
+
+
+@pytest.mark.parametrize("R,channels,rows_pb", [(40, 3, 16), (48, 7, 16), (56, 2, 1), (72, 3, 16), (80, 5, 16), (96, 1, 16), (112, 9, 1), (120, 2, 16), (40, 13, 16)])
+def test_emulated_window_lengths_that_are_not_powers_of_two(oracle, R, channels, rows_pb):
+    # R = 8 RA, RA = 5, 6, 7, 9, 10, 12, 14, 15: the same three kernels, tables from the mixed-radix host transform
+    taps, frames = 9000, 30000
+    h, lt, rt, x, ref = _case(oracle, channels, taps, frames, R)
+    y = emu.longwin(x, h, lt, rt, R=R, rows_pb=rows_pb)
+    assert not np.isnan(y).any()
+    for ear in range(2):
+        assert oracle.peak_rel_error(y[0, :, ear], ref[:, ear]) < TOL
 
 
 @pytest.mark.parametrize("R,rows_pb", [(64, 2), (128, 2), (64, 16), (128, 16)])

@@ -40,6 +40,118 @@ def test_long_window_kernels_match_truth(aw, oracle, monkeypatch, rows, channels
         assert oracle.peak_rel_error(y[s], oracle.spatialize_f64(x[s], h, lt, rt)) < TOL
 
 
+@pytest.mark.parametrize("rows,channels", [(40, 7), (48, 2), (56, 5), (72, 4), (80, 8), (96, 14), (112, 3), (120, 2), (40, 13), (56, 1), (120, 16), (72, 7)])
+def test_window_lengths_that_are_not_powers_of_two(aw, oracle, monkeypatch, rows, channels):
+    """R = 8 RA with RA = 5, 6, 7, 9, 10, 12, 14, 15: odd-prime in-register DFTs in the split / merge kernels, host tables from a
+    mixed-radix transform.  Two windows per call."""
+    monkeypatch.setenv("AW_LW", str(rows))
+    taps, S = 20000, 2
+    hop = rows * 4096 - 5 * 4096                              # history of a 20000-tap path-1 spatializer: 5 partitions of 4096
+    F = hop + 30000
+    h = oracle.synth_hrir(14, taps, seed=21)
+    lt, rt = _maps(channels)
+    x = oracle.synth_input(S, F, channels, seed=6)
+    sp = aw.Spatializer(aw.HRIR(h), lt, rt, n_streams=S)
+    assert sp.info()["path"] == 1 and sp.info()["history"] == 5 * 4096
+    y = sp.process(x)
+    assert sp.info()["long_window_rows"] == rows and sp.info()["long_window_rows_rest"] == 0
+    assert not np.isnan(y).any()
+    for s in range(S):
+        assert oracle.peak_rel_error(y[s], oracle.spatialize_f64(x[s], h, lt, rt)) < TOL
+
+
+def test_one_call_mixes_window_lengths(aw, oracle):
+    """The automatic choice (lw_choose): a call a little longer than what the largest window holds runs as two groups of windows of
+    different lengths that it fills, instead of two half-empty 128-row ones; the split of the timeline into calls still does not matter."""
+    taps, S, C = 32768, 2, 7
+    h = oracle.synth_hrir(14, taps, seed=31)
+    lt, rt = _maps(C)
+    hop128 = 128 * 4096 - 8 * 4096
+    F = hop128 + 50000                                        # 11.3 s at 48 kHz
+    x = oracle.synth_input(S, F, C, seed=8)
+    sp = aw.Spatializer(aw.HRIR(h), lt, rt, n_streams=S)
+    y = sp.process(x)
+    info = sp.info()
+    Ra, Rb = info["long_window_rows"], info["long_window_rows_rest"]
+    assert 0 < Ra < 128 and Rb < Ra, info                    # (two 128-row windows would be 1.94 x the call)
+    hopa, hopb = Ra * 4096 - 32768, (Rb * 4096 - 32768 if Rb else 0)
+    n = -(-(F - hopb) // hopa)
+    assert (n * Ra + Rb) * 4096 < 1.25 * F, info
+    for s in range(S):
+        assert oracle.peak_rel_error(y[s], oracle.spatialize_f64(x[s], h, lt, rt)) < TOL
+    # the carried state after a two-group call: a second call continues the convolution
+    x2 = oracle.synth_input(S, 70000, C, seed=9)
+    y2 = sp.process(x2)
+    both = np.concatenate([x, x2], axis=1)
+    for s in range(S):
+        ref = oracle.spatialize_f64(both[s], h, lt, rt)[F:]
+        assert oracle.peak_rel_error(y2[s], ref) < TOL
+
+
+def test_two_window_groups_on_a_batch(aw, oracle):
+    """With a batch that amortises the second group's launches (lw_choose's group penalty) a 14 s call takes two window lengths; parity
+    of streams from both ends of the batch, linearity over the whole batch."""
+    import torch
+    taps, S, C = 32768, 96, 7
+    h = oracle.synth_hrir(14, taps, seed=33)
+    lt, rt = _maps(C)
+    F = 14 * 48000
+    ctx = aw.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    sp = aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=S, ctx=ctx)
+    x = torch.empty((S, F, C), dtype=torch.float32, device="cuda")
+    ctx.synth_fill(x.data_ptr(), S, F, C, seed=oracle.SYNTH_SEED)
+    y = torch.empty((S, F, 2), dtype=torch.float32, device="cuda")
+    sp.process_device(x.data_ptr(), y.data_ptr(), F)
+    torch.cuda.synchronize()
+    info = sp.info()
+    assert info["long_window_rows"] > 0 and info["long_window_rows_rest"] > 0, info
+    edge = info["long_window_rows"] * 4096 - 32768           # first frame of the second group (one window in the first)
+    for s in (0, S - 1):
+        xs = x[s].cpu().numpy()
+        ref = oracle.spatialize_f64(xs[:60000], h, lt, rt)
+        assert oracle.peak_rel_error(y[s, :60000].cpu().numpy(), ref) < TOL
+        lo = edge - 3000 - (taps - 1)
+        seg = oracle.spatialize_f64(xs[lo:edge + 3000], h, lt, rt)[taps - 1:]          # across the seam of the two groups
+        assert oracle.peak_rel_error(y[s, edge - 3000:edge + 3000].cpu().numpy(), seg) < TOL
+        tail = oracle.spatialize_f64(xs[F - 3000 - (taps - 1):], h, lt, rt)[taps - 1:]
+        assert oracle.peak_rel_error(y[s, F - 3000:].cpu().numpy(), tail) < TOL
+    sp.reset()
+    x.mul_(-0.5)
+    y2 = torch.empty_like(y)
+    sp.process_device(x.data_ptr(), y2.data_ptr(), F)
+    torch.cuda.synchronize()
+    assert float((y2 + 0.5 * y).abs().max()) <= 2e-6 * float(y.abs().max())
+
+
+def test_window_fill_does_not_depend_on_the_call_length(aw, oracle):
+    """Policy pin: for every call length from 5 s to 30 s (48 kHz, 32768 taps) the padded length of the chosen windows stays within
+    30 % of the frames processed (one window length per call and three lengths: up to 1.64)."""
+    taps, C = 32768, 7
+    h = oracle.synth_hrir(14, taps, seed=31)
+    lt, rt = _maps(C)
+    import torch
+    ctx = aw.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    sp = aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=64, ctx=ctx)
+    hist = sp.info()["history"]
+    worst = 0.0
+    for sec in range(5, 31):
+        F = sec * 48000
+        x = torch.zeros((64, F, C), dtype=torch.float32, device="cuda")
+        y = torch.empty((64, F, 2), dtype=torch.float32, device="cuda")
+        sp.process_device(x.data_ptr(), y.data_ptr(), F)
+        torch.cuda.synchronize()
+        i = sp.info()
+        R, Rb = i["long_window_rows"], i["long_window_rows_rest"]
+        assert R > 0, (sec, i)
+        hop = R * 4096 - hist
+        n = -(-F // hop) if Rb == 0 else -(-(F - (Rb * 4096 - hist)) // hop)
+        padded = n * R * 4096 + Rb * 4096
+        assert n * hop + (Rb * 4096 - hist if Rb else 0) >= F
+        worst = max(worst, padded / F)
+        del x, y
+    assert worst < 1.30, worst
+
+
 def test_long_window_state_carries_across_calls_and_kernel_sets(aw, oracle, monkeypatch):
     """Any split of the timeline into calls gives the same samples — also when short calls run on the partitioned kernels
     (4096-frame blocks) and long ones on the long-window kernels: both keep the same history (reset clears it)."""
