@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(kR16Threads, AW_R16_MIN_WAVES) aw_lw_rows16_ke
 }
 
 template <int RA>
-__global__ void __launch_bounds__(kThreads, RA > 8 ? 2 : 4) aw_lw_merge_kernel(LwParams p, long long n_tiles) {
+__global__ void __launch_bounds__(kThreads, 4) aw_lw_merge_kernel(LwParams p, long long n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
     lw_merge_tiles<GpuCtx, RA>(ctx, p, (long long)blockIdx.x, (long long)gridDim.x, n_tiles);
@@ -189,7 +189,7 @@ hipError_t launch_lw_merge(const LwParams &p, int n_streams, hipStream_t stream,
     if (n_tiles > 0x7fffffffLL) return hipErrorInvalidValue;
     if (tm) tm->begin();
     switch (p.R / 8) {
-#define AW_CASE(RA) case RA: hipLaunchKernelGGL((aw_lw_merge_kernel<RA>), dim3(lw_grid(n_tiles, p, RA > 8 ? 1 : 2)), dim3(kThreads), lw_merge_lds_bytes<RA>(), stream, p, n_tiles); break;
+#define AW_CASE(RA) case RA: hipLaunchKernelGGL((aw_lw_merge_kernel<RA>), dim3(lw_grid(n_tiles, p, 2)), dim3(kThreads), lw_merge_lds_bytes<RA>(), stream, p, n_tiles); break;
         AW_LW_FOR_RA(AW_CASE)
 #undef AW_CASE
         default: return hipErrorInvalidValue;

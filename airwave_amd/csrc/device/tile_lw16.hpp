@@ -26,6 +26,7 @@
 // instead of two 8-wave ones.  The inverse is the mirror image (conjugate twiddles, passes in reverse), so the s1 / s2 rows leave
 // in natural order as 512-byte runs per wave, exactly where lw_merge_tiles reads them.
 #pragma once
+#include <type_traits>
 #include "tile_lw.hpp"
 
 namespace awk {
@@ -62,6 +63,11 @@ AW_HD void r16_pow_apply(cf (&v)[16], cf w) {
     const cf p7 = cmul(p4, p3);
     v[7] = cmul(v[7], p7);   v[15] = cmul(v[15], cmul(p8, p7));
     v[8] = cmul(v[8], p8);
+}
+
+// uniform pointer + 32-bit per-lane byte offset: the form the global_load / global_store saddr addressing mode takes (no vector address arithmetic)
+template <class T> AW_HD T *r16_at(T *uniform_base, unsigned lane_bytes) {
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<typename std::remove_const<T>::type *>(uniform_base)) + lane_bytes);
 }
 
 // Per-thread constants of the core
@@ -160,6 +166,9 @@ template <bool AFTER_INVERSE, class Ctx> AW_HD void r16_inverse(Ctx &ctx, cf (&v
 #ifndef AW_R16_TAB_DEPTH
 #define AW_R16_TAB_DEPTH 2      // batches in flight (1: issue, await, use)
 #endif
+#ifndef AW_R16_SADDR
+#define AW_R16_SADDR 0          // 1: global accesses as a uniform base plus one 32-bit lane offset (scalar address arithmetic)
+#endif
 #ifndef AW_R16_TAB_EARLY
 #define AW_R16_TAB_EARLY 0      // 1: the first table batches are requested before the transform's last pass
 #endif
@@ -175,6 +184,7 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
     if (first >= end) return;
     const int tid = ctx.tid(), lane = ctx.lane(), wave = ctx.wave();
     const int a = lane & 15, b = (lane >> 4) + 4 * wave, nth = tid;        // nth = a + 16 b
+    const unsigned nth_bytes = (unsigned)nth * 8u, tid_bytes16 = (unsigned)tid * 16u;
     cf *buf = ctx.lds();
     cf *tw2 = buf + kR16BufElems;
     tw2[tid] = p.tw2[tid];                                       // visible after the first transform's first barrier
@@ -193,7 +203,7 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
 #ifdef AW_R16_ABL_LINEAR_ROWS     // timing ablation only (wrong results): rows laid out [row pair][stream-window][row of the tile]
         return p.spec + (((long long)tl.rp * n_sw + tl.sw) * NROWS + idx) * kLwM + nth + 0 * (row + pair);
 #endif
-        return p.spec + tl.sw * p.spec_per_sw + (long long)pair * p.N + (long long)row * kLwM + nth;
+        return p.spec + tl.sw * p.spec_per_sw + (long long)pair * p.N + (long long)row * kLwM + (AW_R16_SADDR ? 0 : nth);     // AW_R16_SADDR: uniform
     };
     cf raw[16];
     auto load_row = [&](const cf *src, cf (&d)[16]) {
@@ -202,7 +212,7 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
 #ifdef AW_LW_ABL_ROWS_NOLOAD      // timing ablation only (wrong results)
             d[j] = mk(0.001f * tid, (float)(src == nullptr) + 0.002f * j);
 #else
-            d[j] = ctx.ld_stream(src + 256 * j);
+            d[j] = AW_R16_SADDR ? ctx.ld_stream(r16_at(src + 256 * j, nth_bytes)) : ctx.ld_stream(src + 256 * j);
 #endif
         }
     };
@@ -217,12 +227,12 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
             cf v[16];
             constexpr int SB = idx == (NROWS > 2 ? 2 : 0) ? 1 : -1;       // diagnostic builds stamp one row of the tile
             if constexpr (SB >= 0) ctx.stamp(0);
-            const LwTab2 *tb = p.tab16 + ((((long long)tl.rp * NP + pair) * 2 + r) * 16) * kR16Threads + tid;
+            const LwTab2 *tb = p.tab16 + ((((long long)tl.rp * NP + pair) * 2 + r) * 16) * kR16Threads + (AW_R16_SADDR ? 0 : tid);
             auto tab_entry = [&](int m1) -> LwTab2 {
 #ifdef AW_LW_ABL_ROWS_NOTAB       // timing ablation only (wrong results)
                 return LwTab2{mk(1.f, 0.5f * lane), mk(0.25f * m1, 1.f * wave + (float)(tb == nullptr))};
 #else
-                return tb[m1 * kR16Threads];
+                return AW_R16_SADDR ? *r16_at(tb + m1 * kR16Threads, tid_bytes16) : tb[m1 * kR16Threads];
 #endif
             };
             constexpr bool kTabEarly = AW_R16_ORDER == 3;             // all sixteen entries requested before the transform (64 registers)
@@ -300,7 +310,7 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
 #ifdef AW_R16_ABL_LINEAR_ROWS
         cf *dst = p.wrows + ((long long)tl.rp * n_sw + tl.sw) * (long long)(2 * kLwM) + nth;
 #else
-        cf *dst = p.wrows + (tl.sw * (R / 2) + tl.rp) * (long long)(2 * kLwM) + nth;
+        cf *dst = p.wrows + (tl.sw * (R / 2) + tl.rp) * (long long)(2 * kLwM) + (AW_R16_SADDR ? 0 : nth);
 #endif
         r16_inverse<false>(ctx, w1acc, th);
 #pragma unroll
@@ -308,7 +318,7 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
 #ifdef AW_LW_ABL_ROWS_NOSTORE     // timing ablation only (wrong results)
             if (w1acc[j].x != 1.2345e-30f) continue;
 #endif
-            ctx.st_stream(dst + 256 * j, w1acc[j]);
+            ctx.st_stream(AW_R16_SADDR ? r16_at(dst + 256 * j, nth_bytes) : dst + 256 * j, w1acc[j]);
         }
         r16_inverse<true>(ctx, w2acc, th);
 #pragma unroll
@@ -316,7 +326,7 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
 #ifdef AW_LW_ABL_ROWS_NOSTORE
             if (w2acc[j].x != 1.2345e-30f) continue;
 #endif
-            ctx.st_stream(dst + kLwM + 256 * j, w2acc[j]);
+            ctx.st_stream(AW_R16_SADDR ? r16_at(dst + kLwM + 256 * j, nth_bytes) : dst + kLwM + 256 * j, w2acc[j]);
         }
         ctx.stamp(13);
     }

@@ -638,26 +638,31 @@ static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, flo
 
 
 /* ---- long-window path (device/tile_lw.hpp) ---------------------------------------------------- */
-// Per call: windows of N = R x 4096 frames, R in {32, 64, 128}, hop = N - hist_len (hist_len = P x 4096 >= taps, the history the
-// partitioned kernels keep too, so both kernel sets serve the same spatializer and the choice is free per call).
+// Per call: windows of N = R x 4096 frames (R = 8 RA rows, lw_choose below), hop = N - hist_len; hist_len is the history the spatializer's
+// other kernel set keeps too (path 1: P x 4096 >= taps; path 0: the fused window minus its hop, any value >= taps - 1), so both kernel
+// sets serve the same spatializer and the choice is free per call.
 // Cost model (fabric bytes): the long-window kernels move 12 C + 24 bytes per WINDOW frame (input + rows
 // written, rows read + s1/s2 written, s1/s2 read + stereo out); what they are compared with: below.
 // Path-0 spatializers (HRIRs one fused window can hold): HRIR length from which the long-window kernels measure faster than
 // the fused 8192- / 16384-frame tiles on long calls (tools/lw_sweep.py, 128 streams x 10 s); 1 << 30 = never.
-//   G frames/s fused / long-window:  C=1  8640 taps 139 / 99, 12288: 80 / 107;   C=2  8640: 94 / 81, 12288: 55 / 81;   C=3  8640: 69 / 61, 12288: 41 / 61;
-//   C=4  4320: 70 / 55, 6145: 41 / 54;   C=5  6145: 51 / 45, 8640: 41 / 45;   C=6  4320: 47 / 40, 6145: 31 / 41;   C=7  4320: 40 / 37, 6145: 35 / 37, 8640: 29 / 36
-//   (512 streams: 6145: 39 / 42);   C=8  4320: 40 / 33, 6145: 25 / 34;   9-14 channels 4320: 30-20 / 26-18, 6145: 19-13 / 26-18;   C=16  4320: 16.4 / 16.2
-// (profiles/round3_v1/lw_sweep.txt).  The long-window kernels' rate does not depend on the HRIR length; the fused tiles' hop shrinks with it.
+// Round 4 (16-point rows kernel; profiles/round4_v1/lw_sweep.txt), G frames/s fused / long-window:
+//   C=1  8640 taps 147 / 113;   C=2  8640: 93 / 89;   C=3  6145: 85 / 70, 8640: 68 / 69;   C=4  4320: 70 / 60, 5300: 54 / 58;
+//   C=5  6145: 52 / 49, 8640: 41 / 48;   C=6  4320: 47 / 43, 5300: 38 / 43;   C=7  4320: 40.6 / 39.9, 5300: 37 / 40;   C=8  4320: 40 / 36, 5300: 32 / 36;
+//   C=9  4320: 30.2 / 29.4, 6145: 19 / 29;   C=10, 12  4320: 29 / 27, 26 / 24;   C=14  3000: 25.8 / 22.3, 4320: 20.5 / 22.3;   C=16  3000: 20.1 / 19.7, 4320: 16.4 / 19.6
+// The long-window kernels' rate does not depend on the HRIR length; the fused tiles' hop shrinks with it.
 static int lw_fused_crossover_taps(int channels) {
     switch (channels) {
         case 1: return 10500;
-        case 2: case 3: return 9800;
-        case 4: return 5300;
-        case 5: return 7500;
-        case 6: case 8: return 5100;
-        case 7: return 5500;
-        case 16: return 4400;
-        default: return 5300;
+        case 2: return 9000;
+        case 3: return 8600;
+        case 4: return 5000;
+        case 5: return 7300;
+        case 6: return 4800;
+        case 7: return 4500;
+        case 8: return 4800;
+        case 14: case 15: return 3900;
+        case 16: return 3100;
+        default: return 4500;       // 9 - 13 channels
     }
 }
 
@@ -713,6 +718,9 @@ static LwCallPlan lw_choose(const aw_spatializer *sp, int64_t frames, bool for_r
     long long row_tiles = 0;
     for (int i = 0; i < best.n_groups; ++i) row_tiles += (long long)sp->n_streams * best.g[i].n_windows * (best.g[i].R / 2);
     if (row_tiles < 32) return none;     // (measured down to ONE stream x 10 s, 64 row tiles: 7 channels x 32768 taps 8.2 against 3.9 G frames/s partitioned)
+    // path 0: the crossovers above were measured on batches that fill the chip; a small batch stays on the fused tiles, which serve
+    // a single stream well (cfg 1: 9.7 G frames/s), until its row tiles cover the CUs twice
+    if (sp->path == 0 && row_tiles < 2LL * sp->ctx->cfg.cus) return none;
     double other_cost;
     if (sp->path == 0) {
         // past the measured crossover (above) the long call only has to fill its windows to 80 %

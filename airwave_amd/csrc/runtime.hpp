@@ -58,8 +58,8 @@ struct aw_spatializer {
     bool cmac_group = false;            // partitioned path: block-group CMAC kernel instead of the marched one (> 8 pairs; AW_PART_CMAC=group)
     bool fwd_one_pair = false;          // partitioned path: forward kernel with one channel pair per workgroup (default for more than 4 pairs; AW_PART_FWD=1|2 forces either form)
     bool herm_ok = true;                // partitioned path, odd channel count: store/read only the non-redundant half of the last pair's spectrum
-    // long-window path (device/tile_lw.hpp): chosen per call for long calls of a path-1 spatializer; tables per window length, built on first use
-    // (aw_spatializer_reserve builds the one its max_frames implies)
+    // long-window path (device/tile_lw.hpp): chosen per call (lw_choose) for long calls of a path-1 spatializer and, past a measured HRIR length,
+    // of a path-0 one; tables per window length, built on first use (aw_spatializer_reserve builds those of the plan its max_frames implies)
     struct LwPlan { int R = 0; awk::LwTab *d_tab = nullptr; awk::LwTab2 *d_tab16 = nullptr; awk::cf *d_tw2 = nullptr; awk::cf *d_coarse = nullptr, *d_fine = nullptr, *d_step = nullptr, *d_tw_r = nullptr, *d_tw1m = nullptr; };
     std::vector<LwPlan> lw_plans;
     int lw_mode = -1;                   // AW_LW at create: -1 automatic (cost model), 0 never, 32/64/128 force that R where it fits

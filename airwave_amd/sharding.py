@@ -31,7 +31,7 @@ def aggregate_throughput(frames_done: float, elapsed_s: float, device=None):
     import torch.distributed as dist
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
     f = torch.tensor([frames_done], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():        # (also a one-rank group: bench.py's AW_BENCH_FORCE_PG debug run)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(f, op=dist.ReduceOp.SUM)
     return float(f.item()), float(t.item()), float(f.item()) / float(t.item())

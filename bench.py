@@ -89,8 +89,22 @@ def load_hrir(name, taps: int):
         w = aw.WAVLoader.load(path)
         return w.audio_data, f"fixture {name}"
     rng = np.random.default_rng(1234)
-    h = rng.standard_normal((14, taps)) * np.exp(-np.arange(taps) / (taps / 6.0))
-    return h.astype(np.float32), "synthetic 14-track exp-decay noise"
+    h = (rng.standard_normal((14, taps)) * np.exp(-np.arange(taps) / (taps / 6.0))).astype(np.float32)
+    # BASELINE cfg 3 reads "imported .wav HRIR (long tap)": the synthetic HRIR is written as a 14-track float32 WAV at setup and comes
+    # back through the product's RIFF reader, the import route of HRIRManager.activatePreset (HRIRManager.swift:347-446, WAVLoader.swift:26-99)
+    import struct, tempfile
+    data = np.ascontiguousarray(h.T).astype("<f4").tobytes()                      # [frame][track]
+    block = 14 * 4
+    body = b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 3, 14, 48000, 48000 * block, block, 32) + b"data" + struct.pack("<I", len(data)) + data
+    with tempfile.NamedTemporaryFile(suffix=".wav", delete=False) as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+        path = f.name
+    try:
+        w = aw.WAVLoader.load(path)
+    finally:
+        os.unlink(path)
+    assert w.audio_data.shape == (14, taps) and np.array_equal(np.asarray(w.audio_data), h)
+    return w.audio_data, "synthetic 14-track exp-decay noise, imported as a float32 .wav"
 
 
 def committed_traffic(workload: str, S: int, F: int, C: int):
@@ -223,12 +237,16 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
     if wl.get("eq"):
         eq_def = aw.EqualizerAPOParser.parse(open(os.path.join(ROOT, "tests", "golden", "eq", "CCA CRA ParametricEq.txt"), "rb").read(), "CCA CRA ParametricEq.txt")
     legs = []
+    activation_ms = []                # wall time of aw_spatializer_reserve per rate bucket: table build (host, float64) + upload + scratch
     for rate, b in batch.buckets.items():
         n, F = len(b.stream_ids), int(round(seconds * rate))
         x = torch.empty((n, F, C), dtype=torch.float32, device="cuda")
         y = torch.empty((n, F, 2), dtype=torch.float32, device="cuda")
         ctx.synth_fill(x.data_ptr(), n, F, C, seed=0xA17AE, first_stream=first_stream + b.stream_ids[0])
-        b.spatializer.reserve(F)      # every internal buffer is sized here: process never allocates
+        t_act = time.perf_counter()
+        b.spatializer.reserve(F)      # every internal buffer is sized here (and the long-window tables built): process never allocates
+        torch.cuda.synchronize()
+        activation_ms.append((time.perf_counter() - t_act) * 1e3)
         eq = aw.ParametricEqualizerState(eq_def, float(rate), n_streams=n, ctx=ctx) if eq_def is not None else None
         legs.append(dict(rate=rate, n=n, F=F, x=x, y=y, sp=b.spatializer, eq=eq, taps=b.hrir_taps))
     torch.cuda.synchronize()
@@ -251,7 +269,7 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
     torch.cuda.synchronize()
     for g in legs:
         g["sp"].set_profiling(True)   # HIP events around every kernel launch, on the launch stream
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)     # torch's current stream IS the context stream
@@ -261,7 +279,7 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
         step(timed=True)
     ev1.record()
     torch.cuda.synchronize()
-    if world > 1:                     # the timed region ends, like it starts, with a barrier + synchronize on every rank
+    if world > 1 or dist.is_initialized():        # the timed region ends, like it starts, with a barrier + synchronize on every rank
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -329,6 +347,9 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
                 "convolutions_per_stream": int((lt >= 0).sum() + (rt >= 0).sum()), "parallelism": f"streams sharded x{world}, no data-path collective",
                 "fft": paths[0]["fft"], "hop": paths[0]["hop"], "path": paths[0]["path"], "legs": paths,
                 "outputs_finite": finite,
+                # creation-time cost (not in the timed region; the reference does its HRIR partition FFTs at engine init too,
+                # ConvolutionEngine.swift:143-182): aw_spatializer_reserve = table build in float64 on host threads + upload + scratch
+                "activation_ms": [round(v, 1) for v in activation_ms],
             },
             "roofline": {
                 "bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -447,7 +468,14 @@ def main() -> int:
         local_rank = int(os.environ["AW_BENCH_DEVICE"])
     backend = os.environ.get("AW_BENCH_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # AW_BENCH_FORCE_PG=1 (debug, one GPU): a ONE-rank process group on the chosen backend, so that the RCCL branch below — group
+    # creation with device_id, the all-reduce on device tensors — executes on hardware that has a single GPU.  No scaling claim.
+    force_pg = world == 1 and os.environ.get("AW_BENCH_FORCE_PG") == "1"
+    if force_pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1 or force_pg:
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -456,7 +484,8 @@ def main() -> int:
             raise SystemExit(f"rendezvous produced {dist.get_world_size()} ranks for --gpus {args.gpus}")
 
     import airwave_amd as aw
-    print(f"[bench rank {rank}/{world}] device {local_rank}: {torch.cuda.get_device_name(local_rank)}, backend {backend if world > 1 else 'none'}", file=sys.stderr, flush=True)
+    print(f"[bench rank {rank}/{world}] device {local_rank}: {torch.cuda.get_device_name(local_rank)}, backend {backend if world > 1 or force_pg else 'none'}"
+          + (" (forced one-rank process group)" if force_pg else ""), file=sys.stderr, flush=True)
     ctx = aw.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
     result = run_workload(args.workload, args, ctx, world, rank, backend, with_cpu=not args.no_cpu_baseline)
     sec = SECONDARY.get(args.workload)
@@ -472,7 +501,7 @@ def main() -> int:
         if any(not (e < 1e-5) for e in errs):
             print(f"bench.py: parity spot check FAILED: {errs} (tolerance 1e-5)", file=sys.stderr)
             rc = 3
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
     return rc
 

@@ -117,9 +117,17 @@ public final class HIPEqualizerEffect /* : AudioEqualizerEffect */ {
     }
 
     /// Control thread: destroys the processors the render thread has let go of (their deinit runs here, not in `process`).
+    /// Only boxes nobody else references are destroyed: the render thread may still hold a handed-over box in a local for the rest of its
+    /// callback (after it has released the try-lock), and the last release must not happen there — `EqualizerBox.deinit` frees device memory
+    /// and synchronises the stream.  Such a box waits for the next drain.
     public func drainRetiredProcessors() {
-        let dead = retiredLock.withLock { list -> [EqualizerBox] in let d = list; list.removeAll(keepingCapacity: true); return d }
-        _ = dead
+        var taken = retiredLock.withLock { list -> [EqualizerBox] in let d = list; list.removeAll(keepingCapacity: true); return d }
+        var stillShared: [EqualizerBox] = []
+        while var box = taken.popLast() {
+            if !isKnownUniquelyReferenced(&box) { stillShared.append(box) }
+            // else: `box` is the last reference and ends here, on the control thread
+        }
+        if !stillShared.isEmpty { retiredLock.withLock { $0.append(contentsOf: stillShared) } }
     }
 
     /// StereoAudioProcessing.process   EqualizerRuntimeEffect.swift:50-78

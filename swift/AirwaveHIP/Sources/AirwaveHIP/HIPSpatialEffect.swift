@@ -89,9 +89,17 @@ public final class HIPSpatialEffect /* : AudioSpatialEffect */ {
     }
 
     /// Control thread: destroys the states the render thread has let go of (their deinit runs here, not in `process`).
+    /// Only boxes nobody else references are destroyed here: the render thread may still hold a handed-over box in a local for the rest
+    /// of its callback, and the last release — `SpatializerBox.deinit` frees device memory and synchronises — must not happen there.
+    /// Such a box waits for the next drain.
     public func drainRetiredStates() {
-        let dead = retiredLock.withLock { list -> [SpatializerBox] in let d = list; list.removeAll(keepingCapacity: true); return d }
-        _ = dead          // the boxes die at the end of this scope, on the calling (control) thread
+        var taken = retiredLock.withLock { list -> [SpatializerBox] in let d = list; list.removeAll(keepingCapacity: true); return d }
+        var stillShared: [SpatializerBox] = []
+        while var box = taken.popLast() {
+            if !isKnownUniquelyReferenced(&box) { stillShared.append(box) }
+            // else: `box` is the last reference and ends here, on the calling (control) thread
+        }
+        if !stillShared.isEmpty { retiredLock.withLock { $0.append(contentsOf: stillShared) } }
     }
 
     /// StereoAudioProcessing.process(inputLeft:inputRight:outputLeft:outputRight:frameCount:)

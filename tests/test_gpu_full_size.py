@@ -18,6 +18,19 @@ def aw():
     return airwave_amd
 
 
+def _pin_long_window_plan(sp, F):
+    """The long-window kernels ran the last call (tile_lw.hpp / tile_lw16.hpp), on windows that the call fills: returns the rows of
+    the window groups.  (Which kernel set a full-size test exercises is asserted, not inferred from the policy.)"""
+    i = sp.info()
+    Ra, Rb, hist = i["long_window_rows"], i["long_window_rows_rest"], i["history"]
+    assert Ra > 0, i
+    hopa, hopb = Ra * 4096 - hist, (Rb * 4096 - hist if Rb else 0)
+    n = -(-(F - hopb) // hopa)
+    assert n >= 1 and n * hopa + hopb >= F, i
+    assert (n * Ra + Rb) * 4096 <= 1.15 * F, i               # padded length of the windows against the frames of the call
+    return Ra, Rb
+
+
 def _energies_distinct(y, S):
     e = (y.double() ** 2).sum(dim=(1, 2))
     assert float(e.min()) > 0.25 * float(e.max())
@@ -117,8 +130,9 @@ def test_full_size_properties_cfg3_14_channel_input(aw, oracle, golden_dir):
 
 
 def test_full_size_properties_cfg4(aw, oracle, golden_dir):
-    """cfg 4 per GPU: 512 streams x 10 s at 96 kHz, StageSH1.0 resampled x2 (8640 taps, 16384-frame windows), then the
-    10-band parametric EQ fixture in place — the spatial -> EQ order of the effect graph."""
+    """cfg 4 per GPU: 512 streams x 10 s at 96 kHz, StageSH1.0 resampled x2 (8640 taps: a layout whose short calls run on 16384-frame
+    fused windows and whose long calls — this one, reserved like bench.py does — on the long-window kernels), then the 10-band
+    parametric EQ fixture in place — the spatial -> EQ order of the effect graph."""
     import torch
     S, fs, C = 512, 96000.0, 7
     F = int(10 * fs)
@@ -128,7 +142,8 @@ def test_full_size_properties_cfg4(aw, oracle, golden_dir):
     layout = aw.InputLayout(SPEAKERS7, "7 speakers")
     batch = aw.MixedRateBatch(np.asarray(w.audio_data), 48000.0, layout, [fs] * S, ctx=ctx)
     b = batch.buckets[fs]
-    assert b.hrir_taps == 8640 and b.spatializer.info()["path"] == 0 and b.spatializer.info()["fft"] == 16384
+    assert b.hrir_taps == 8640 and b.spatializer.info()["path"] == 0 and b.spatializer.info()["fft"] == 16384      # the fused window short calls take
+    b.spatializer.reserve(F)
     d = aw.EqualizerAPOParser.parse(open(os.path.join(golden_dir, "eq", "CCA CRA ParametricEq.txt"), "rb").read(), "f.txt")
     od = oracle.EqualizerDefinition(d.preampDB, [oracle.EqualizerFilter(f.sourceLine, f.sourceNumber, f.isEnabled, f.type, f.frequencyHz, f.gainDB, f.q) for f in d.filters])
     eq = aw.ParametricEqualizerState(d, fs, n_streams=S, ctx=ctx)
@@ -136,6 +151,7 @@ def test_full_size_properties_cfg4(aw, oracle, golden_dir):
     ctx.synth_fill(x.data_ptr(), S, F, C, seed=oracle.SYNTH_SEED)
     y = torch.empty((S, F, 2), dtype=torch.float32, device="cuda")
     b.spatializer.process_device(x.data_ptr(), y.data_ptr(), F)
+    _pin_long_window_plan(b.spatializer, F)
     ysp_tail = {s: y[s, F - 3000:].cpu().numpy() for s in (0, 255, 511)}               # spatializer output before the in-place EQ
     eq.process_device(y.data_ptr(), y.data_ptr(), F)
     torch.cuda.synchronize()
@@ -164,7 +180,8 @@ def test_full_size_properties_cfg4(aw, oracle, golden_dir):
 
 def test_full_size_properties_cfg5(aw, oracle, golden_dir):
     """cfg 5 per GPU: 1024 streams split evenly over 44.1 / 48 / 96 kHz, 10 s each, StageSH1.0 resampled per rate; every
-    rate bucket has its own renderer network (8192-frame windows at 44.1/48 kHz, 16384 at 96 kHz)."""
+    rate bucket has its own renderer network: fused 8192-frame windows at 44.1 / 48 kHz (3969 / 4320 taps), the long-window kernels
+    for the 96 kHz bucket (8640 taps) — asserted per bucket."""
     import torch
     S, C = 1024, 7
     rates = [44100.0, 48000.0, 96000.0]
@@ -183,9 +200,14 @@ def test_full_size_properties_cfg5(aw, oracle, golden_dir):
         x = torch.empty((n, F, C), dtype=torch.float32, device="cuda")
         ctx.synth_fill(x.data_ptr(), n, F, C, seed=oracle.SYNTH_SEED, first_stream=b.stream_ids[0])      # global stream ids
         y = torch.empty((n, F, 2), dtype=torch.float32, device="cuda")
+        b.spatializer.reserve(F)
         b.spatializer.process_device(x.data_ptr(), y.data_ptr(), F)
         torch.cuda.synchronize()
         assert torch.isfinite(y).all()
+        if rate == 96000.0:
+            _pin_long_window_plan(b.spatializer, F)
+        else:
+            assert b.spatializer.info()["long_window_rows"] == 0 and b.spatializer.info()["fft"] == 8192, b.spatializer.info()
         for k in (0, n // 2, n - 1):
             xs = x[k, :12000].cpu().numpy()
             assert np.array_equal(xs, oracle.synth_input(1, 12000, C, first_stream=b.stream_ids[k])[0])
