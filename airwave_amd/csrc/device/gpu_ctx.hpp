@@ -203,6 +203,8 @@ struct GpuCtx {
         r.y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.y), 0xB1, 0xf, 0xf, true));
         return r;
     }
+    // issue priority of this wave among the waves of its SIMD (s_setprio 0..3)
+    template <int P> __device__ __forceinline__ void prio() const { __builtin_amdgcn_s_setprio(P); }
     // unconditional scheduling fence (bounds how far loads are hoisted)
     __device__ __forceinline__ void sched_fence_hard() const {
         asm volatile("" ::: "memory");

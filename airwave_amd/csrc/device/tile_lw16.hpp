@@ -31,6 +31,9 @@
 
 namespace awk {
 
+#ifndef AW_R16_PRIO
+#define AW_R16_PRIO 3           // s_setprio: 1 = raised while the next row's loads are issued, 2 = during the table / multiply-accumulate phase (4.31 -> 4.16 ms), 4 / 8 = during the E1 / E2 exchanges
+#endif
 constexpr int kR16Threads = 256;
 // E1 through LDS as [register of the contiguous side][thread], row stride 272: the contiguous side (forward stores, inverse loads) is a
 // 512-byte run per wave; on the strided side lane (a, x = lane >> 4) touches 272 (x + 4 wave) + a + 16 bb — 16 consecutive slots per
@@ -40,8 +43,14 @@ constexpr int kR16Threads = 256;
 constexpr int kR16Stride = 272;
 constexpr int kR16BufElems = 16 * kR16Stride;
 constexpr int kR16Tw2Elems = 256;
-constexpr int kR16LdsElems = kR16BufElems + kR16Tw2Elems;
-constexpr int kR16LdsBytes = kR16LdsElems * 8;          // 36 864 B: four workgroups per CU
+#ifndef AW_R16_T1_LDS
+#define AW_R16_T1_LDS 0         // 1: every thread's pass-1 twiddle powers w^1 .. w^8 live in LDS (16 KB per workgroup), w^9 .. w^15 = w^8 w^k: 22 instead of 29 complex
+                                // multiplies per transform (-3.6 % vector instructions).  Measured +-0 (4.19 against 4.15 ms): the core is held by the LDS
+                                // and vector pipes together, not by the instruction count; off
+#endif
+constexpr int kR16Tw1Elems = AW_R16_T1_LDS ? 8 * 256 : 0;
+constexpr int kR16LdsElems = kR16BufElems + kR16Tw2Elems + kR16Tw1Elems;
+constexpr int kR16LdsBytes = kR16LdsElems * 8;          // 36 864 B (53 248 B with the pass-1 powers in LDS): three workgroups per CU fit either way
 
 struct alignas(16) LwTab2 { cf u, w; };
 
@@ -65,6 +74,17 @@ AW_HD void r16_pow_apply(cf (&v)[16], cf w) {
     v[8] = cmul(v[8], p8);
 }
 
+// v[k] *= w^k (CONJ: conj(w)^k) with w^1 .. w^8 read from the thread's column of an LDS table (t1[256 (k - 1)]) and w^9 .. w^15 = w^8 w^(k-8)
+template <bool CONJ, class Ctx> AW_HD void r16_pow_apply_lds(Ctx &ctx, cf (&v)[16], const cf *t1) {
+    cf p[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = ctx.ld(t1 + 256 * k);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k + 1] = twmul<CONJ>(v[k + 1], p[k]);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k + 9] = twmul<CONJ>(v[k + 9], cmul(p[7], p[k]));
+}
+
 // uniform pointer + 32-bit per-lane byte offset: the form the global_load / global_store saddr addressing mode takes (no vector address arithmetic)
 template <class T> AW_HD T *r16_at(T *uniform_base, unsigned lane_bytes) {
     return reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<typename std::remove_const<T>::type *>(uniform_base)) + lane_bytes);
@@ -78,6 +98,7 @@ struct R16Thread {
     cf *e2w;          // E2 store base: quarter + 272 (lane >> 4) + a           (+ 17 m0)
     cf *e2r;          // E2 load base:  quarter + 272 (lane >> 4) + 17 alpha    (+ rho)
     const cf *tw2;    // w_256^{a m0} at tw2[16 m0]
+    const cf *tw1;    // AW_R16_T1_LDS: w1^(k+1) at tw1[256 k], k < 8
 };
 
 // E2: 16 x 16 transpose between the register index and the lane field a, through the wave's own quarter of the E1 buffer
@@ -120,8 +141,10 @@ template <int SB = -1, class Ctx, class Hook> AW_HD void r16_forward(Ctx &ctx, c
     };
     fft16<false>(v);
     stamp(0);
-    r16_pow_apply(v, ctx.opaque(th.w1));
+    if constexpr (AW_R16_T1_LDS) r16_pow_apply_lds<false>(ctx, v, th.tw1);
+    else r16_pow_apply(v, ctx.opaque(th.w1));
     stamp(1);
+    if constexpr (AW_R16_PRIO & 4) ctx.template prio<1>();
     ctx.barrier();                                   // every wave has read the previous transform's exchange
     stamp(2);
 #pragma unroll
@@ -131,11 +154,14 @@ template <int SB = -1, class Ctx, class Hook> AW_HD void r16_forward(Ctx &ctx, c
     stamp(4);
 #pragma unroll
     for (int bb = 0; bb < 16; ++bb) v[bb] = ctx.ld(th.str + 16 * bb);
+    if constexpr (AW_R16_PRIO & 4) ctx.template prio<0>();
     fft16<false>(v);
     stamp(5);
     r16_tw2_apply<false>(ctx, v, th.tw2);
     stamp(6);
+    if constexpr (AW_R16_PRIO & 8) ctx.template prio<1>();
     r16_lane_transpose(ctx, v, th);
+    if constexpr (AW_R16_PRIO & 8) ctx.template prio<0>();
     stamp(7);
     before_pass3();                                  // the caller's first table requests travel under the last pass
     fft16<false>(v);
@@ -156,7 +182,8 @@ template <bool AFTER_INVERSE, class Ctx> AW_HD void r16_inverse(Ctx &ctx, cf (&v
     ctx.barrier();
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) v[k2] = ctx.ld(th.lin + kR16Stride * k2);
-    r16_pow_apply(v, conj(ctx.opaque(th.w1)));
+    if constexpr (AW_R16_T1_LDS) r16_pow_apply_lds<true>(ctx, v, th.tw1);
+    else r16_pow_apply(v, conj(ctx.opaque(th.w1)));
     fft16<true>(v);
 }
 
@@ -195,6 +222,14 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
     th.e2w = buf + kR16Stride * (4 * wave + (lane >> 4)) + a;
     th.e2r = buf + kR16Stride * (4 * wave + (lane >> 4)) + 17 * a;
     th.tw2 = tw2 + a;
+    th.tw1 = tw2 + kR16Tw2Elems + tid;
+    if constexpr (AW_R16_T1_LDS) {               // this thread's own column: written and read by this thread only
+        cf *t1 = tw2 + kR16Tw2Elems + tid;
+        cf pw = th.w1;
+        t1[0] = pw;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { pw = k == 1 ? cmul(th.w1, th.w1) : k == 3 ? cmul(t1[256], t1[256]) : k == 7 ? cmul(t1[3 * 256], t1[3 * 256]) : cmul(pw, th.w1); t1[256 * k] = pw; }
+    }
     const int R = p.R;
 
     auto row_src = [&](const LwRowTile &tl, int idx) -> const cf * {     // idx = 2 pair + (0: row ra, 1: row rb)
@@ -258,7 +293,9 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
                     for (int m1 = 0; m1 < 16; ++m1) T[m1] = tab_entry(m1);
                     ctx.sched_fence_hard();
                 }
+                if constexpr (AW_R16_PRIO & 1) ctx.template prio<3>();
                 prefetch_next();
+                if constexpr (AW_R16_PRIO & 1) ctx.template prio<0>();
                 ctx.sched_fence_hard();
             }
             // Table entries in batches of K, DEPTH batches in flight, fenced: left in one loop hipcc emits load, s_waitcnt vmcnt(0),
@@ -286,6 +323,7 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
                     w2acc[m1] = cfma(v[m1], T[kTabEarly ? m1 : 0].w, w2acc[m1]);
                 }
             } else {
+                if constexpr (AW_R16_PRIO & 2) ctx.template prio<2>();
                 if constexpr (!AW_R16_TAB_EARLY) issue_first();
 #pragma unroll
                 for (int bi = 0; bi < NBATCH; ++bi) {
@@ -300,6 +338,7 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
                     ctx.sched_fence_hard();
                 }
             }
+            if constexpr (AW_R16_PRIO & 2) ctx.template prio<0>();
             // pins the multiply-accumulates here: left free, hipcc sinks every row's to the end of the tile and keeps the rows' spectra
             // and table values in scratch until then (2 KB per thread)
 #pragma unroll

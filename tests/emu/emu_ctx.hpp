@@ -49,6 +49,7 @@ struct EmuCtx {
     void stamp(int) const {}
     void sched_fence() const {}
     void sched_fence_hard() const {}
+    template <int P> void prio() const {}
     void flush_stamps() const {}
     awk::cf ld(const awk::cf *p) const { return *p; }
     void stagger(int, int) const {}

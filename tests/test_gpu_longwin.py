@@ -195,13 +195,13 @@ def test_long_window_stream_chunks(aw, oracle, monkeypatch):
 
 
 def test_path0_spatializer_takes_the_long_window_kernels_by_itself(aw, oracle, monkeypatch):
-    """An HRIR one fused window could hold (8 channels x 8640 taps: path 0), AW_LW unset: the policy sends a long call of a batch to the
+    """An HRIR one fused window could hold (7 channels x 8640 taps: path 0, cfg 4's layout), AW_LW unset: the policy sends a long call of a batch to the
     long-window kernels and a single stream to the fused tiles; a small scratch budget (AW_SPEC_SCRATCH_MB now applies to every
     spatializer that can take the long-window kernels) runs the batch as several stream chunks; any split of the timeline into calls
     gives the same samples."""
     monkeypatch.delenv("AW_LW", raising=False)
     monkeypatch.setenv("AW_SPEC_SCRATCH_MB", "96")
-    taps, S, C, F = 8640, 24, 8, 300000
+    taps, S, C, F = 8640, 24, 7, 300000
     h = oracle.synth_hrir(14, taps, seed=12)
     lt, rt = _maps(C)
     x = oracle.synth_input(S, F, C, seed=13)
@@ -210,7 +210,7 @@ def test_path0_spatializer_takes_the_long_window_kernels_by_itself(aw, oracle, m
     y = sp.process(x)
     i = sp.info()
     assert i["long_window_rows"] > 0, i
-    per_stream = (i["long_window_rows"] + i["long_window_rows_rest"]) * 4096 * (4 + 1) * 8           # rows of 4 pairs + s1/s2, bytes
+    per_stream = (i["long_window_rows"] + i["long_window_rows_rest"]) * 4096 * 9 // 2 * 8            # rows of 3.5 pairs + s1/s2, bytes
     assert per_stream * S > (96 << 20)                       # more than the budget: several stream chunks
     for s in (0, 11, S - 1):
         assert oracle.peak_rel_error(y[s], oracle.spatialize_f64(x[s], h, lt, rt)) < TOL
