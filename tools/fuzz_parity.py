@@ -35,11 +35,15 @@ while time.time() < t_end:
     if rng.random() < 0.15: env["AW_SPEC_SCRATCH_MB"] = str(int(rng.choice([1, 3, 16])))      # several stream chunks
     r3 = rng.random()                            # long-window kernels (tile_lw.hpp): forced window length, forced off, or the policy
     if r3 < 0.3:
-        env["AW_LW"] = str(int(rng.choice([32, 64, 128])))
-        if rng.random() < 0.5: env["AW_LW_ROWS_PB"] = "2"
+        env["AW_LW"] = str(int(rng.choice([32, 40, 48, 56, 64, 72, 80, 96, 112, 120, 128])))
+        r4 = rng.random()                        # rows kernel: the 16-point form (default) or the 8-point forms of round 3
+        if r4 < 0.2: env["AW_LW_ROWS_FORM"], env["AW_LW_ROWS_PB"] = "8", "2"
+        elif r4 < 0.4: env["AW_LW_ROWS_FORM"] = "8"
         if rng.random() < 0.6: total = int(rng.integers(30000, 330000))          # calls that fill a window or more
     elif r3 < 0.4: env["AW_LW"] = "0"
-    for k in ("AW_WINDOW", "AW_PART_FWD", "AW_PART_CMAC", "AW_PART_HERM", "AW_SPEC_SCRATCH_MB", "AW_LW", "AW_LW_ROWS_PB"):
+    elif r3 < 0.6 and taps >= 8000:              # the policy's own choice on calls long enough for one or two window lengths
+        total = int(rng.integers(150000, 700000)); S = int(rng.choice([1, 2, 6]))
+    for k in ("AW_WINDOW", "AW_PART_FWD", "AW_PART_CMAC", "AW_PART_HERM", "AW_SPEC_SCRATCH_MB", "AW_LW", "AW_LW_ROWS_PB", "AW_LW_ROWS_FORM"):
         os.environ.pop(k, None)
     os.environ.update(env)
     n_tracks = int(rng.choice([2, 7, 14]))
@@ -55,7 +59,7 @@ while time.time() < t_end:
     if os.environ.get("AW_FUZZ_TRACE"):
         print("CASE", C, taps, S, total, bounds, env, n_tracks, flush=True)
     try:
-        ctx = aw.Context(0) if "AW_LW_ROWS_PB" in env else None        # (that knob is read when a context is created)
+        ctx = aw.Context(0) if ("AW_LW_ROWS_PB" in env or "AW_LW_ROWS_FORM" in env) else None        # (those knobs are read when a context is created)
         sp = aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=S, ctx=ctx) if ctx else aw.Spatializer(aw.HRIR(h), lt, rt, n_streams=S)
         info = sp.info()
         y = np.concatenate([sp.process(x[:, a:b]) for a, b in zip(bounds[:-1], bounds[1:])], axis=1)

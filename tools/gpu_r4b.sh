@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r4b
 {
-for v in plain not1 new core new; do echo $v; ./tools/ubench/rb_$v; done
-} 2>&1 | tee gpurun_out/r4b/out13.txt
+for v in 0 1 2 3 5 7 0; do echo "prio $v"; ./tools/ubench/tb_p$v; done
+} 2>&1 | tee gpurun_out/r4b/out14.txt
