@@ -131,7 +131,7 @@ template <bool INV, class Ctx> AW_HD void r16_tw2_apply(Ctx &ctx, cf (&v)[16], c
 }
 
 // forward: v[j] = row[a + 16 b + 256 j]  ->  v[m1] = X[kappa + 16 alpha + 256 m1].  SB >= 0: phase stamps SB.. (diagnostic builds)
-template <int SB = -1, class Ctx, class Hook> AW_HD void r16_forward(Ctx &ctx, cf (&v)[16], const R16Thread &th, Hook &&before_pass3) {
+template <int SB = -1, class Ctx, class Hook> AW_HD void r16_forward(Ctx &ctx, cf (&v)[16], const R16Thread &th, Hook &&hook) {
     auto stamp = [&](int i) {              // (the values pass through an opaque asm first: arithmetic does not float across the stamp)
         if constexpr (SB >= 0) {
 #pragma unroll
@@ -144,6 +144,7 @@ template <int SB = -1, class Ctx, class Hook> AW_HD void r16_forward(Ctx &ctx, c
     if constexpr (AW_R16_T1_LDS) r16_pow_apply_lds<false>(ctx, v, th.tw1);
     else r16_pow_apply(v, ctx.opaque(th.w1));
     stamp(1);
+    hook(LwIdx<0>{});                                // caller's memory requests between the phases (phase 0: after pass 1)
     if constexpr (AW_R16_PRIO & 4) ctx.template prio<1>();
     ctx.barrier();                                   // every wave has read the previous transform's exchange
     stamp(2);
@@ -155,15 +156,17 @@ template <int SB = -1, class Ctx, class Hook> AW_HD void r16_forward(Ctx &ctx, c
 #pragma unroll
     for (int bb = 0; bb < 16; ++bb) v[bb] = ctx.ld(th.str + 16 * bb);
     if constexpr (AW_R16_PRIO & 4) ctx.template prio<0>();
+    hook(LwIdx<1>{});                                // phase 1: E1 loads issued
     fft16<false>(v);
     stamp(5);
     r16_tw2_apply<false>(ctx, v, th.tw2);
     stamp(6);
+    hook(LwIdx<2>{});                                // phase 2: after pass 2
     if constexpr (AW_R16_PRIO & 8) ctx.template prio<1>();
     r16_lane_transpose(ctx, v, th);
     if constexpr (AW_R16_PRIO & 8) ctx.template prio<0>();
     stamp(7);
-    before_pass3();                                  // the caller's first table requests travel under the last pass
+    hook(LwIdx<3>{});                                // phase 3: before the last pass
     fft16<false>(v);
     stamp(8);
 }
@@ -192,6 +195,9 @@ template <bool AFTER_INVERSE, class Ctx> AW_HD void r16_inverse(Ctx &ctx, cf (&v
 #endif
 #ifndef AW_R16_TAB_DEPTH
 #define AW_R16_TAB_DEPTH 2      // batches in flight (1: issue, await, use)
+#endif
+#ifndef AW_R16_SPREAD
+#define AW_R16_SPREAD 1         // 2 / 4: the next row's sixteen requests leave in that many groups spread over this row's transform
 #endif
 #ifndef AW_R16_SADDR
 #define AW_R16_SADDR 0          // 1: global accesses as a uniform base plus one 32-bit lane offset (scalar address arithmetic)
@@ -241,9 +247,22 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
         return p.spec + tl.sw * p.spec_per_sw + (long long)pair * p.N + (long long)row * kLwM + (AW_R16_SADDR ? 0 : nth);     // AW_R16_SADDR: uniform
     };
     cf raw[16];
-    auto load_row = [&](const cf *src, cf (&d)[16]) {
+    auto load_row = [&](const cf *src, cf (&d)[16], int j0 = 0, int j1 = 16) {
+#ifdef AW_R16_ABL_LOAD16          // timing ablation only (wrong results): eight 16-byte loads per row and thread instead of sixteen 8-byte ones
+        {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const cf *s16 = src - nth + 2 * nth;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(s16 + 512 * j));
+                d[2 * j] = mk(q.x, q.y); d[2 * j + 1] = mk(q.z, q.w);
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
+            if (j < j0 || j >= j1) continue;
 #ifdef AW_LW_ABL_ROWS_NOLOAD      // timing ablation only (wrong results)
             d[j] = mk(0.001f * tid, (float)(src == nullptr) + 0.002f * j);
 #else
@@ -272,11 +291,11 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
             };
             constexpr bool kTabEarly = AW_R16_ORDER == 3;             // all sixteen entries requested before the transform (64 registers)
             LwTab2 T[kTabEarly ? 16 : 1];
-            auto prefetch_next = [&]() {
-                // the next row (of this tile, or the first one of the next tile; the last tile re-reads its own)
-                if constexpr (idx + 1 < NROWS) load_row(row_src(tl, idx + 1), raw);
-                else load_row(row_src(lw_row_tile(vid + step < end ? vid + step : vid, n_sw, rp0, rp_step), 0), raw);
-            };
+            // the next row (of this tile, or the first one of the next tile; the last tile re-reads its own)
+            const cf *next_src = idx + 1 < NROWS ? row_src(tl, idx + 1) : row_src(lw_row_tile(vid + step < end ? vid + step : vid, n_sw, rp0, rp_step), 0);
+            auto prefetch_next = [&](int j0 = 0, int j1 = 16) { load_row(next_src, raw, j0, j1); };
+            // AW_R16_SPREAD = n > 1: the sixteen requests of the next row leave in n groups between the phases of this row's transform
+            constexpr int NSPREAD = AW_R16_SPREAD > 1 ? AW_R16_SPREAD : 1;
             // Vector-memory results return in issue order: a wait for the table entries also waits for every load issued before
             // them.  AW_R16_ORDER picks what is issued when:
             //   0  next row at the start of this row's transform, tables after the transform
@@ -294,7 +313,7 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
                     ctx.sched_fence_hard();
                 }
                 if constexpr (AW_R16_PRIO & 1) ctx.template prio<3>();
-                prefetch_next();
+                prefetch_next(0, 16 / NSPREAD);
                 if constexpr (AW_R16_PRIO & 1) ctx.template prio<0>();
                 ctx.sched_fence_hard();
             }
@@ -313,7 +332,23 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
                     for (int bi = 0; bi < DEPTH - 1 && bi < NBATCH; ++bi) issue(bi);
                 }
             };
-            r16_forward<SB>(ctx, v, th, [&]() { if constexpr (AW_R16_TAB_EARLY) { ctx.sched_fence_hard(); issue_first(); ctx.sched_fence_hard(); } });
+#ifdef AW_R16_ABL_LOADONLY        // timing ablation only (wrong results): the row loads alone, no transform, no tables
+            if constexpr (NSPREAD > 1) prefetch_next(16 / NSPREAD, 16);
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) w1acc[m1] = w1acc[m1] + v[m1];
+            return;
+#endif
+            r16_forward<SB>(ctx, v, th, [&](auto PH) {
+                constexpr int ph = decltype(PH)::value;
+                if constexpr (ph < 3 && ph + 1 < NSPREAD) {          // groups 1 .. NSPREAD-1 after phases 0, 1, 2
+                    ctx.sched_fence_hard();
+                    if constexpr (AW_R16_PRIO & 1) ctx.template prio<3>();
+                    prefetch_next((ph + 1) * (16 / NSPREAD), (ph + 2) * (16 / NSPREAD));
+                    if constexpr (AW_R16_PRIO & 1) ctx.template prio<0>();
+                    ctx.sched_fence_hard();
+                }
+                if constexpr (ph == 3 && AW_R16_TAB_EARLY) { ctx.sched_fence_hard(); issue_first(); ctx.sched_fence_hard(); }
+            });
             ctx.sched_fence_hard();               // (table loads hoisted above the transform end up in scratch)
             if constexpr (SB >= 0) ctx.stamp(10);
             if constexpr (kTabEarly) {
@@ -350,6 +385,15 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
         cf *dst = p.wrows + ((long long)tl.rp * n_sw + tl.sw) * (long long)(2 * kLwM) + nth;
 #else
         cf *dst = p.wrows + (tl.sw * (R / 2) + tl.rp) * (long long)(2 * kLwM) + (AW_R16_SADDR ? 0 : nth);
+#endif
+#ifdef AW_R16_ABL_LOADONLY
+        {
+            cf sum = mk(0.f, 0.f);
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) sum = sum + w1acc[m1];
+            if (sum.x == 1.2345e-30f) dst[0] = sum;
+        }
+        continue;
 #endif
         r16_inverse<false>(ctx, w1acc, th);
 #pragma unroll

@@ -45,9 +45,10 @@ WORKLOADS = {
     "cfg2-14ch": dict(streams=128, channels=14, hrir="RoomSH1.0.wav", taps=4320, seconds=10.0, steps=20, warmup=3, text_map="hesuvi14_custom_map.txt",
                       desc="cfg2, 14-ch-input reading (north_star's literal case): InputLayout.detect(14) custom channels through the committed "
                            "parseHeSuViFormat text map -> RoomSH1.0 14-track HeSuVi HRIR (4320 taps), 128-stream batch x 10 s"),
-    "cfg3": dict(streams=1024, channels=7, hrir=None, taps=32768, seconds=10.0, steps=10, warmup=2,
+    # (cfg 3: 10 warm-up steps — the chip's clock governor needs ~30 ms of this load to settle: 1.6 -> 1.84 GHz over the first launches)
+    "cfg3": dict(streams=1024, channels=7, hrir=None, taps=32768, seconds=10.0, steps=30, warmup=10,
                  desc="cfg3: 7 speakers [FL,FR,FC,BL,BR,SL,SR] 48 kHz -> synthetic 14 x 32768-tap HeSuVi HRIR (seed 1234), 1024-stream batch x 10 s"),
-    "cfg3-14ch": dict(streams=1024, channels=14, hrir=None, taps=32768, seconds=10.0, steps=5, warmup=1, text_map="hesuvi14_custom_map.txt",
+    "cfg3-14ch": dict(streams=1024, channels=14, hrir=None, taps=32768, seconds=10.0, steps=10, warmup=3, text_map="hesuvi14_custom_map.txt",
                       desc="cfg3, 14-ch-input reading: InputLayout.detect(14) custom channels through the committed parseHeSuViFormat "
                            "text map -> synthetic 14 x 32768-tap HRIR (seed 1234), 1024-stream batch x 10 s"),
     "cfg4": dict(streams=512, channels=7, hrir="StageSH1.0.wav", taps=4320, seconds=10.0, steps=5, warmup=1, rates=[96000], eq=True,
