@@ -327,7 +327,8 @@ class Spatializer:
         g = lambda i: int(self._lib.aw_spatializer_info(self._h, i))
         return {"fft": g(0), "hop": g(1), "partitions": g(2), "path": g(3), "history": g(4), "dominant_frames": g(5), "scratch_bytes": g(6),
                 "long_window_rows": g(7),       # long-window kernels ran in the last call on windows of rows x 4096 frames (0: they did not)
-                "long_window_rows_rest": g(8)}  # ... and a last, shorter window of this many rows for the remainder (0: one window length)
+                "long_window_rows_rest": g(8),  # ... and a last, shorter window of this many rows for the remainder (0: one window length)
+                "long_window_table_sets": g(9)} # table sets built so far (one per window length)
 
     def process_device(self, in_ptr: int, out_ptr: int, frames: int) -> None:
         _check(self._lib.aw_spatializer_process(self._h, ctypes.c_void_p(in_ptr), ctypes.c_void_p(out_ptr), frames))

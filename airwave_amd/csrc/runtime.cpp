@@ -401,6 +401,7 @@ int64_t aw_spatializer_info(const aw_spatializer *sp, int32_t what) {
         case 5: return sp->dominant_frames;   // output frames covered by the launch aw_spatializer_kernel_time() times (last call)
         case 7: return sp->last_lw_R;         // long-window path: rows R of the last call's windows (N = R x 4096); 0 = the partitioned kernels ran
         case 8: return sp->last_lw_R2;        // rows of the last call's remainder window when it ran as two groups of windows (0: one group)
+        case 9: return (int64_t)sp->lw_plans.size();   // long-window table sets built so far (one per window length; reserve builds those of its plan)
         case 6: return (int64_t)(sp->spec_capacity * sizeof(awk::cf) + (sp->stage_in_cap + sp->stage_out_cap) * sizeof(float));   // grow-only device buffers, bytes
         default: return -1;
     }

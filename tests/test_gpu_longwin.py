@@ -194,6 +194,42 @@ def test_long_window_stream_chunks(aw, oracle, monkeypatch):
         assert oracle.peak_rel_error(y[s], oracle.spatialize_f64(x[s], h, lt, rt)) < TOL
 
 
+def test_reserve_builds_the_tables_and_process_builds_none(aw, oracle):
+    """aw_spatializer_reserve(max) builds the long-window tables of the plan max implies (creation may block, process must not
+    allocate: ConvolutionEngine allocates everything in init, ConvolutionEngine.swift:97-138); calls within the reserved length then
+    choose among the window lengths whose tables exist — no table set and no scratch is added on the process path (device-buffer
+    entry; the host-buffer entry's staging is reserved for single-stream, plug-in shaped spatializers only).  A spatializer that was
+    never reserved builds them inside its first long call and gives the same samples."""
+    import torch
+    taps, S, C = 32768, 2, 7
+    h = oracle.synth_hrir(14, taps, seed=41)
+    lt, rt = _maps(C)
+    F = 14 * 48000
+    ctx = aw.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    x = torch.empty((S, F, C), dtype=torch.float32, device="cuda")
+    ctx.synth_fill(x.data_ptr(), S, F, C, seed=oracle.SYNTH_SEED)
+    sp = aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=S, ctx=ctx)
+    assert sp.info()["long_window_table_sets"] == 0
+    sp.reserve(F)
+    built, held = sp.info()["long_window_table_sets"], sp.info()["scratch_bytes"]
+    assert built >= 1 and held > 0
+    y = torch.empty((S, F, 2), dtype=torch.float32, device="cuda")
+    for n in (F, 200000, 4096, F):                           # long, shorter (an existing window length or the partitioned kernels), short, long
+        sp.reset()
+        sp.process_device(x.data_ptr(), y.data_ptr(), n)     # (a call of n frames reads the streams packed with stride n)
+        torch.cuda.synchronize()
+        assert sp.info()["long_window_table_sets"] == built and sp.info()["scratch_bytes"] == held, (n, sp.info())
+    assert sp.info()["long_window_rows"] > 0
+    xs = x[1].cpu().numpy()
+    assert oracle.peak_rel_error(y[1].cpu().numpy()[:50000], oracle.spatialize_f64(xs[:50000], h, lt, rt)) < TOL
+    lazy = aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=S, ctx=ctx)
+    y2 = torch.empty_like(y)
+    lazy.process_device(x.data_ptr(), y2.data_ptr(), F)      # never reserved: the first long call builds what it needs
+    torch.cuda.synchronize()
+    assert lazy.info()["long_window_table_sets"] >= 1
+    assert float((y2 - y).abs().max()) <= 3e-6 * float(y.abs().max())
+
+
 def test_path0_spatializer_takes_the_long_window_kernels_by_itself(aw, oracle, monkeypatch):
     """An HRIR one fused window could hold (7 channels x 8640 taps: path 0, cfg 4's layout), AW_LW unset: the policy sends a long call of a batch to the
     long-window kernels and a single stream to the fused tiles; a small scratch budget (AW_SPEC_SCRATCH_MB now applies to every
