@@ -123,6 +123,34 @@ def test_two_window_groups_on_a_batch(aw, oracle):
     assert float((y2 + 0.5 * y).abs().max()) <= 2e-6 * float(y.abs().max())
 
 
+def test_two_windows_then_a_shorter_one(aw, oracle):
+    """25 s: two windows of one length, then one of another (the first group has more than one window); parity at the head, across
+    both seams and at the tail."""
+    import torch
+    taps, S, C = 32768, 40, 7
+    h = oracle.synth_hrir(14, taps, seed=35)
+    lt, rt = _maps(C)
+    F = 25 * 48000
+    ctx = aw.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    sp = aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=S, ctx=ctx)
+    x = torch.empty((S, F, C), dtype=torch.float32, device="cuda")
+    ctx.synth_fill(x.data_ptr(), S, F, C, seed=oracle.SYNTH_SEED)
+    y = torch.empty((S, F, 2), dtype=torch.float32, device="cuda")
+    sp.process_device(x.data_ptr(), y.data_ptr(), F)
+    torch.cuda.synchronize()
+    i = sp.info()
+    Ra, Rb = i["long_window_rows"], i["long_window_rows_rest"]
+    hopa = Ra * 4096 - 32768
+    assert Ra > 0 and Rb > 0 and 2 * hopa < F <= 2 * hopa + Rb * 4096 - 32768, i      # two windows of Ra rows, one of Rb
+    for s in (0, S - 1):
+        xs = x[s].cpu().numpy()
+        assert oracle.peak_rel_error(y[s, :30000].cpu().numpy(), oracle.spatialize_f64(xs[:30000], h, lt, rt)) < TOL
+        for edge in (hopa, 2 * hopa, F - 2000):
+            lo, hi = edge - 2000, min(F, edge + 2000)
+            seg = oracle.spatialize_f64(xs[lo - (taps - 1):hi], h, lt, rt)[taps - 1:]
+            assert oracle.peak_rel_error(y[s, lo:hi].cpu().numpy(), seg) < TOL, (s, edge)
+
+
 def test_window_fill_does_not_depend_on_the_call_length(aw, oracle):
     """Policy pin: for every call length from 5 s to 30 s (48 kHz, 32768 taps) the padded length of the chosen windows stays within
     30 % of the frames processed (one window length per call and three lengths: up to 1.64)."""
