@@ -313,6 +313,7 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
     }
     // Long calls may run on the long-window kernels (device/tile_lw.hpp) whatever the path above — chosen per call, see lw_choose();
     // they use the same history buffer.  AW_LW: 0 never, 32/64/128 force that window, unset = the measured policy.
+    sp->lw_plans.reserve(16);                                                            // one entry per window length: pointers into it stay valid
     if (const char *e = getenv("AW_LW")) sp->lw_mode = atoi(e);
     if (n_in > 16) sp->lw_mode = 0;                                                      // up to eight channel pairs
     // scratch budget per stream chunk: of the partitioned kernels and of the long-window ones, which also serve path-0 layouts
@@ -811,7 +812,6 @@ static aw_status sp_process_longwin(aw_spatializer *sp, const LwCallPlan &call, 
         aw_status st = lw_get_plan(sp, call.g[i].R, &tables[i]);
         if (st != AW_OK) return st;
     }
-    for (int i = 0; i < call.n_groups; ++i) (void)lw_get_plan(sp, call.g[i].R, &tables[i]);     // (the second build may have moved the first plan)
     LwScratch per_group[2];
     const LwScratch sc = lw_plan_scratch(sp, call, part_budget(sp), frames <= sp->reserved_frames ? sp->spec_capacity : 0, per_group);
     aw_status st = part_ensure_scratch(sp, sc.need);
