@@ -248,18 +248,6 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
     };
     cf raw[16];
     auto load_row = [&](const cf *src, cf (&d)[16], int j0 = 0, int j1 = 16) {
-#ifdef AW_R16_ABL_LOAD16          // timing ablation only (wrong results): eight 16-byte loads per row and thread instead of sixteen 8-byte ones
-        {
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            const cf *s16 = src - nth + 2 * nth;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(s16 + 512 * j));
-                d[2 * j] = mk(q.x, q.y); d[2 * j + 1] = mk(q.z, q.w);
-            }
-            return;
-        }
-#endif
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             if (j < j0 || j >= j1) continue;
@@ -332,12 +320,6 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
                     for (int bi = 0; bi < DEPTH - 1 && bi < NBATCH; ++bi) issue(bi);
                 }
             };
-#ifdef AW_R16_ABL_LOADONLY        // timing ablation only (wrong results): the row loads alone, no transform, no tables
-            if constexpr (NSPREAD > 1) prefetch_next(16 / NSPREAD, 16);
-#pragma unroll
-            for (int m1 = 0; m1 < 16; ++m1) w1acc[m1] = w1acc[m1] + v[m1];
-            return;
-#endif
             r16_forward<SB>(ctx, v, th, [&](auto PH) {
                 constexpr int ph = decltype(PH)::value;
                 if constexpr (ph < 3 && ph + 1 < NSPREAD) {          // groups 1 .. NSPREAD-1 after phases 0, 1, 2
@@ -385,15 +367,6 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
         cf *dst = p.wrows + ((long long)tl.rp * n_sw + tl.sw) * (long long)(2 * kLwM) + nth;
 #else
         cf *dst = p.wrows + (tl.sw * (R / 2) + tl.rp) * (long long)(2 * kLwM) + (AW_R16_SADDR ? 0 : nth);
-#endif
-#ifdef AW_R16_ABL_LOADONLY
-        {
-            cf sum = mk(0.f, 0.f);
-#pragma unroll
-            for (int m1 = 0; m1 < 16; ++m1) sum = sum + w1acc[m1];
-            if (sum.x == 1.2345e-30f) dst[0] = sum;
-        }
-        continue;
 #endif
         r16_inverse<false>(ctx, w1acc, th);
 #pragma unroll
