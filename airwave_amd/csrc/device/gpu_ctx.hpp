@@ -33,12 +33,13 @@ struct GpuCtx {
 #elif AW_STAMPS
         unsigned long long tm;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm)::"memory");
-        st_[i] = tm;
+        if (stamp_on_) st_[i] = tm;
 #else
         (void)i;
 #endif
     }
     int stamp_thread_ = 0;
+    bool stamp_on_ = true;        // diagnostic builds: a persistent kernel records ONE of its tiles (a mid-kernel one: the last tile runs on a draining chip)
     __device__ __forceinline__ void flush_stamps() {
 #if AW_STAMPS
         if ((int)threadIdx.x == stamp_thread_ && dbg_)

@@ -59,6 +59,7 @@ AW_HD int r16_bin(int thread, int m1) { return (thread >> 4) + 16 * (thread & 15
 
 // v[k] *= w^k, k = 1..15; the powers by a depth-4 product tree, each used as soon as it exists (about seven live at a time)
 AW_HD void r16_pow_apply(cf (&v)[16], cf w) {
+
     const cf p2 = cmul(w, w), p4 = cmul(p2, p2), p8 = cmul(p4, p4);
     v[1] = cmul(v[1], w);    v[9] = cmul(v[9], cmul(p8, w));
     v[2] = cmul(v[2], p2);   v[10] = cmul(v[10], cmul(p8, p2));
@@ -196,6 +197,9 @@ template <bool AFTER_INVERSE, class Ctx> AW_HD void r16_inverse(Ctx &ctx, cf (&v
 #ifndef AW_R16_TAB_DEPTH
 #define AW_R16_TAB_DEPTH 2      // batches in flight (1: issue, await, use)
 #endif
+#ifndef AW_R16_STAMP_TILE
+#define AW_R16_STAMP_TILE 40    // diagnostic builds (-DAW_STAMPS=1): the tile of every workgroup whose phases are recorded
+#endif
 #ifndef AW_R16_SPREAD
 #define AW_R16_SPREAD 1         // 2 / 4: the next row's sixteen requests leave in that many groups spread over this row's transform
 #endif
@@ -261,6 +265,9 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
     if (AW_R16_ORDER != 2) load_row(row_src(lw_row_tile(first, n_sw, rp0, rp_step), 0), raw);
     for (long long vid = first; vid < end; vid += step) {
         const LwRowTile tl = lw_row_tile(vid, n_sw, rp0, rp_step);
+#if defined(AW_STAMPS) && AW_STAMPS
+        ctx.stamp_on_ = (vid - first) / step == AW_R16_STAMP_TILE;       // diagnostic builds: one mid-kernel tile
+#endif
         cf w1acc[16], w2acc[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) { w1acc[i] = mk(0.f, 0.f); w2acc[i] = mk(0.f, 0.f); }
