@@ -57,24 +57,6 @@ struct alignas(16) LwTab2 { cf u, w; };
 // FFT_4096 output bin held by (thread, register m1) of the 16-point core
 AW_HD int r16_bin(int thread, int m1) { return (thread >> 4) + 16 * (thread & 15) + 256 * m1; }
 
-// v[k] *= w^k, k = 1..15; the powers by a depth-4 product tree, each used as soon as it exists (about seven live at a time)
-AW_HD void r16_pow_apply(cf (&v)[16], cf w) {
-
-    const cf p2 = cmul(w, w), p4 = cmul(p2, p2), p8 = cmul(p4, p4);
-    v[1] = cmul(v[1], w);    v[9] = cmul(v[9], cmul(p8, w));
-    v[2] = cmul(v[2], p2);   v[10] = cmul(v[10], cmul(p8, p2));
-    const cf p3 = cmul(p2, w);
-    v[3] = cmul(v[3], p3);   v[11] = cmul(v[11], cmul(p8, p3));
-    v[4] = cmul(v[4], p4);   v[12] = cmul(v[12], cmul(p8, p4));
-    const cf p5 = cmul(p4, w);
-    v[5] = cmul(v[5], p5);   v[13] = cmul(v[13], cmul(p8, p5));
-    const cf p6 = cmul(p4, p2);
-    v[6] = cmul(v[6], p6);   v[14] = cmul(v[14], cmul(p8, p6));
-    const cf p7 = cmul(p4, p3);
-    v[7] = cmul(v[7], p7);   v[15] = cmul(v[15], cmul(p8, p7));
-    v[8] = cmul(v[8], p8);
-}
-
 // v[k] *= w^k (CONJ: conj(w)^k) with w^1 .. w^8 read from the thread's column of an LDS table (t1[256 (k - 1)]) and w^9 .. w^15 = w^8 w^(k-8)
 template <bool CONJ, class Ctx> AW_HD void r16_pow_apply_lds(Ctx &ctx, cf (&v)[16], const cf *t1) {
     cf p[8];

@@ -201,6 +201,105 @@ AW_HD void sub_fft512x2(Ctx &ctx, cf (&a)[2][8], cf *scr0, cf *scr1, const cf *t
     ctx.stamp(SB + 5);
 }
 
+// ---- the same row transforms on the 16-point core (round 4): a HALF-wave per row ------------------
+// Lanes 0-31 of a wave own its first row, lanes 32-63 its second; a lane holds SIXTEEN values of its row.  512 = 16 x 2 x 16:
+//   radix 16 over j (x[h + 32 j], h = lane & 31) -> ka, twiddle w_512^{h ka} (a [16][32] table in LDS),
+//   radix 2 over lane bit 4 as a register<->lane swap (v_permlane16_swap: registers ka, ka + 8) + an in-lane butterfly,
+//   twiddle w_32^{h0} on the odd half (h0 = lane & 15), ONE wave-private 16 x 16 LDS transpose (17-element pitch, 272 per group of
+//   16 lanes: conflict-free both ways), radix 16 over h0 -> kb.
+// One LDS exchange per row instead of two (63 LDS instructions per lane and row pair against 94):
+// tools/ubench/fft_core.hip 2.99 -> 2.50 us per pair transform per CU.
+// Bin order: on return a[kb] = X[hl_col(lane) + 32 kb].
+#ifndef AW_OLS_H
+#define AW_OLS_H 1        // 0: the fused 8192-frame tile on the 8 x 8 x 8 row transforms of rounds 1-3
+#endif
+AW_HD int hl_col(int lane) { return (lane & 7) + 8 * ((lane >> 4) & 1) + 16 * ((lane >> 3) & 1); }   // lane & 31 with bits 3 and 4 exchanged
+struct HLane {
+    cf *row;        // the lane's row of the exchange buffer (also its half-wave's transpose scratch: 2 x 272 <= 576 elements)
+    cf *prow;       // the row holding the conjugate partners of this row's bins: (16 - k1) & 15
+    const cf *twh;  // w_512^{h ka} at twh[32 ka]
+    int h, e2w, e2r, col, pidx;
+    cf w32;
+};
+// The row twiddles of this form, [ka][h] = w_512^{h ka} (16 x 32), take the place of the 8 x 8 x 8 form's [8][64] table in LDS; one
+// entry per thread, formed once per launch from two entries of that table: w_512^m = w_512^{m & 63} w_8^{m >> 6}.
+AW_HD cf hl_twiddle(const cf *twa_g, int t) {
+    const int m = (t >> 5) * (t & 31), j = m >> 6;
+    const cf lo = twa_g[64 + (m & 63)];                 // twa_g[ka][lane] = w_512^{lane ka}
+    cf hi = twa_g[2 * (j & 3) * 64 + 32];               // w_512^{64 (j & 3)}
+    if (j & 4) hi = mk(-hi.x, -hi.y);
+    return cmul(lo, hi);
+}
+template <class Ctx> AW_HD HLane hl_make(Ctx &ctx, cf *buf, const cf *twh, int lane, int wave) {
+    HLane L;
+    const int s = lane >> 5, g = (lane >> 4) & 1, h0 = lane & 15;
+    L.h = lane & 31;
+    L.row = buf + wave_row(wave, s) * kRowStride;
+    L.prow = buf + wave_row(wave, wave == 0 ? s : 1 - s) * kRowStride;
+    L.twh = twh + L.h;
+    L.e2w = 272 * g + h0;
+    L.e2r = 272 * g + 17 * h0;
+    L.col = hl_col(lane);
+    L.pidx = 511 - L.col + ((wave == 0 && s == 0) ? 1 : 0);          // column (512 - k2) & 511 on row 0, 511 - k2 elsewhere
+    L.w32 = ctx.ld(twh + 8 * 32 + 2 * h0);                           // w_32^{h0} = w_512^{8 (2 h0)}
+    return L;
+}
+// a[ka] *= w_512^{h ka} (INV: conjugate); the entries are requested eight at a time before their multiplies
+template <bool INV, class Ctx> AW_HD void hl_tw_apply(Ctx &ctx, cf (&a)[16], const HLane &L) {
+#pragma unroll
+    for (int m = 1; m < 16; m += 8) {
+        cf w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (m + i < 16) w[i] = ctx.ld(L.twh + 32 * (m + i));
+        ctx.sched_fence();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (m + i < 16) a[m + i] = twmul<INV>(a[m + i], w[i]);
+    }
+}
+// forward: a[j] = x[h + 32 j]  ->  a[kb] = X[col + 32 kb]
+template <class Ctx> AW_HD void sub_fft512h_fwd(Ctx &ctx, cf (&a)[16], const HLane &L) {
+    fft16<false>(a);
+    hl_tw_apply<false>(ctx, a, L);
+    const cf w32 = ctx.opaque(L.w32);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        ctx.xswap(a[q], a[q + 8], 4);        // lanes with bit 4 clear now hold ka = q of both halves h1 = 0, 1; the others ka = q + 8
+        const cf e = a[q] + a[q + 8], o = a[q] - a[q + 8];
+        a[q] = e;
+        a[q + 8] = cmul(o, w32);
+    }
+    ctx.wave_sync();                         // the half-wave's loads of its row have returned
+#pragma unroll
+    for (int r = 0; r < 16; ++r) L.row[L.e2w + 17 * r] = a[r];
+    ctx.wave_sync();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = ctx.ld(L.row + L.e2r + r);
+    ctx.wave_sync();
+    fft16<false>(a);
+}
+// inverse (unnormalised), the mirror image: a[kb] = X[col + 32 kb]  ->  a[j] = x[h + 32 j]
+template <class Ctx> AW_HD void sub_fft512h_inv(Ctx &ctx, cf (&a)[16], const HLane &L) {
+    fft16<true>(a);
+    ctx.wave_sync();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) L.row[L.e2r + r] = a[r];
+    ctx.wave_sync();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = ctx.ld(L.row + L.e2w + 17 * r);
+    ctx.wave_sync();
+    const cf w32 = ctx.opaque(L.w32);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const cf o = cmulc(a[q + 8], w32);
+        const cf e = a[q];
+        a[q] = e + o;
+        a[q + 8] = e - o;
+        ctx.xswap(a[q], a[q + 8], 4);
+    }
+    hl_tw_apply<true>(ctx, a, L);
+    fft16<true>(a);
+}
+
 // ---- the tile ----------------------------------------------------------------------------------
 struct alignas(16) f4 { float x, y, z, w; };
 struct alignas(8) f2 { float x, y; };
@@ -473,6 +572,47 @@ AW_HD void tile_inverse_rows(Ctx &ctx, cf (&wacc)[2][8], cf *buf0, const cf *twa
     for (int kc = 0; kc < 8; ++kc) { row0[lane + 64 * kc] = wacc[0][kc]; row1[lane + 64 * kc] = wacc[1][kc]; }
 }
 
+// The same three steps on the half-wave row transforms (AW_OLS_H): a lane holds 16 bins of ONE row.
+AW_HD void load_tab_h(const TileParams &p, int pair, int wave, int lane, cf2 (&tab)[16]) {
+    const cf2 *row = p.tab + ((long long)pair * kN + wave_row(wave, lane >> 5) * kSub + hl_col(lane));
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) tab[kb] = row[32 * kb];          // per half-wave 512 contiguous bytes (whole 128-byte lines per 8 lanes)
+}
+template <class Ctx>
+AW_HD void pair_subfft_cmac_h(Ctx &ctx, const TileParams &p, int pair, cf *buf, const cf *twa, cf2 (&tab)[16], int lane, int wave,
+                              cf (&wacc)[16], bool tab_loaded) {
+    const HLane L = hl_make(ctx, buf, twa, lane, wave);
+    cf z[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) z[j] = ctx.ld(L.row + L.h + 32 * j);
+    sub_fft512h_fwd(ctx, z, L);
+    if (!tab_loaded) load_tab_h(p, pair, wave, lane, tab);
+    ctx.stamp(22);
+    // publish Z in natural column order inside the wave, then multiply-accumulate against the partner bins
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) L.row[L.col + 32 * kb] = z[kb];
+    ctx.wave_sync();
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+        int idx = L.pidx - 32 * kb;
+        if (kb == 0) idx &= 511;                               // only (row 0, column 0) wraps: 512 -> 0
+        const cf zp = ctx.ld(L.prow + idx);
+        wacc[kb] = cfma(z[kb], tab[kb].a, wacc[kb]);
+        wacc[kb] = cfmac(zp, tab[kb].b, wacc[kb]);
+    }
+    ctx.wave_sync();    // partner reads done before this wave reuses its rows as scratch
+    ctx.stamp(23);
+}
+template <class Ctx>
+AW_HD void tile_inverse_rows_h(Ctx &ctx, cf (&wacc)[16], cf *buf0, const cf *twa) {
+    const int lane = ctx.lane(), wave = ctx.wave();
+    const HLane L = hl_make(ctx, buf0, twa, lane, wave);
+    sub_fft512h_inv(ctx, wacc, L);
+    ctx.wave_sync();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) L.row[L.h + 32 * j] = wacc[j];
+}
+
 // Part 2: barrier, radix-16 across rows, then store window positions m >= first_valid whose
 // frame f0 + m lies inside the call.
 template <class Ctx>
@@ -555,8 +695,13 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
     const int Cn = CS > 0 ? CS : p.n_channels;
     if (first >= end) return;
     const cf w1 = p.tw1[t];
+#if AW_OLS_H
+    twa[t] = hl_twiddle(p.twa, t);                       // [16][32] row twiddles of the half-wave form, one per thread
+    (void)twb;
+#else
     twa[t] = p.twa[t];                                   // 512 entries, one per thread
     if (t < kTwbElems) twb[t] = p.twb[t];                // visible after the first barrier below
+#endif
 
     // whole-frame mode: both batches of a tile are loaded together (load_batch2), batch 1 waits in raw_b
     // kWide (9-16 channels in ONE pass, 5-8 compile-time pairs): two groups of eight channels; the second group is fetched
@@ -585,11 +730,17 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
     const long long f0 = (long long)cur.tile * p.hop - p.hist_len;     // frame of window position 0
     ctx.stamp(0);
 
+#if AW_OLS_H
+    cf wacc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wacc[i] = mk(0.f, 0.f);
+#else
     cf wacc[2][8];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int i = 0; i < 8; ++i) wacc[s][i] = mk(0.f, 0.f);
+#endif
 
     // Schedule per batch of two pairs:
     //   pass 1 of both pairs -> buf0, buf1 ; issue pair 0's table loads ; barrier ;
@@ -632,21 +783,29 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
             }
             }
         }
+#if AW_OLS_H
+        cf2 tab[16];
+        auto load_tab_ = [&](int pr) { load_tab_h(p, pr, wave, lane, tab); };
+        auto subfft_cmac_ = [&](int pr, cf *bf, bool loaded) { pair_subfft_cmac_h(ctx, p, pr, bf, twa, tab, lane, wave, wacc, loaded); };
+#else
         cf2 tab[2][8];
-        if (kTabEarly0) load_tab(p, pair0, wave, lane, tab);
+        auto load_tab_ = [&](int pr) { load_tab(p, pr, wave, lane, tab); };
+        auto subfft_cmac_ = [&](int pr, cf *bf, bool loaded) { pair_subfft_cmac(ctx, p, pr, bf, twa, twb, tab, lane, wave, wacc, loaded); };
+#endif
+        if (kTabEarly0) load_tab_(pair0);
         ctx.stamp(pair0 > 0 ? 7 : 2);
         ctx.barrier();
         ctx.stagger(wave, p.stagger);
         ctx.stamp(pair0 > 0 ? 8 : 3);
-        pair_subfft_cmac(ctx, p, pair0, buf0, twa, twb, tab, lane, wave, wacc, kTabEarly0);
+        subfft_cmac_(pair0, buf0, kTabEarly0);
         ctx.stamp(pair0 > 0 ? 9 : 4);
         const int pair1 = pair0 + 1;     // a phantom second pair (odd pair count, runtime loop) lands on the zero pair after the last one
-        if (two && kTabEarly1) load_tab(p, pair1, wave, lane, tab);
+        if (two && kTabEarly1) load_tab_(pair1);
         if constexpr (kWide) {
             if (pair0 == 2) load_batch2<CS, (NP == 8 && !AW_WIDE_LATE_B ? 4 : NP == 7 && !AW_WIDE_LATE_B ? 2 : 0)>(in_s + 8, f0, t, raw, raw_b);      // channels 8-15 (a 9-12 channel layout: 8-11 only)
         }
         if (!kWhole && kPrefetchRawEarly && more) load_batch<CS, INTERIOR>(p, in_s, hist_s, f0, t, 2 * (pair0 + 2), raw);
-        if (two) pair_subfft_cmac(ctx, p, pair1, buf1, twa, twb, tab, lane, wave, wacc, kTabEarly1);
+        if (two) subfft_cmac_(pair1, buf1, kTabEarly1);
         if constexpr (kWide && AW_WIDE_LATE_B != 0 && NP >= 7) {      // the group's second batch one pair later (an L2 hit): fewer values live through the CMAC
             if (pair0 == 2) load_batch2<CS, (NP == 8 ? 4 : 2), false>(in_s + 8, f0, t, raw, raw_b);
         }
@@ -664,7 +823,11 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
             batch(pair0, (kSkipPhantom && !kEvenPairs) ? pair0 + 1 < n_pairs : true, pair0 + 2 < n_pairs);
     }
 
+#if AW_OLS_H
+    tile_inverse_rows_h(ctx, wacc, buf0, twa);
+#else
     tile_inverse_rows(ctx, wacc, buf0, twa, twb);
+#endif
     {   // prefetch the next tile's first batch here, where few registers are live (unconditional:
         // the last iteration re-reads its own batch; a branch would put phis on 64 registers)
         const TileId nx = tile_of<INTERIOR>(p, id + step < end ? id + step : id);

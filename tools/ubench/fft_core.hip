@@ -4,6 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -Iairwave_amd/csrc -Iinclude tools/ubench/fft_core.hip -o tools/ubench/fft_core
 #include "device/tile_ols.hpp"
 #include "device/gpu_ctx.hpp"
+#include "device/tile_lw16.hpp"
 #include <cstdio>
 #include <vector>
 namespace awk {
@@ -94,6 +95,53 @@ __global__ void __launch_bounds__(kThreads, 4) k_core1(const cf *tw1, const cf *
     sink[blockIdx.x * kThreads + t] = acc;
 }
 }
+
+namespace awk {
+// The same 512-point row transforms on the 16-point core (tile_ols.hpp, sub_fft512h_fwd): a HALF-wave per row, 16 values per lane.
+template <int VARIANT>
+__global__ void __launch_bounds__(kThreads) k_core16(const cf *tw1, const cf *tw512, const cf *tw32, cf *sink, int reps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
+    const int t = ctx.tid(), lane = ctx.lane(), wave = ctx.wave();
+    cf *buf0 = ctx.lds(), *buf1 = buf0 + kBufElems, *twh = buf1 + kBufElems;
+    const cf w1 = tw1[t];
+    twh[t] = hl_twiddle(tw512, t);
+    (void)tw32;
+    cf x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = mk(0.001f * (t + j), 0.002f * (t - j));
+    cf acc = mk(0.f, 0.f);
+    for (int r = 0; r < reps; ++r) {
+        if (r > 0) ctx.barrier();
+        {
+            cf pw[16];
+            tw_powers(ctx.opaque(w1), pw);
+            cf y[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) y[j] = x[j];
+            pair_pass1(y, pw, buf0, t);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) y[j] = mk(x[j].y, x[j].x);
+            pair_pass1(y, pw, buf1, t);
+        }
+        ctx.barrier();
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            cf *buf = hh == 0 ? buf0 : buf1;
+            const HLane L = hl_make(ctx, buf, twh, lane, wave);
+            cf z[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) z[j] = ctx.ld(L.row + L.h + 32 * j);
+            sub_fft512h_fwd(ctx, z, L);
+#pragma unroll
+            for (int kc = 0; kc < 16; ++kc) acc = acc + z[kc];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j].x += 1e-6f * acc.x;
+    }
+    sink[blockIdx.x * kThreads + t] = acc;
+}
+}
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 int main() {
     using namespace awk;
@@ -132,6 +180,20 @@ int main() {
             }
             printf("one pair per interval, %d workgroups (%d per CU): %.3f us per pair transform per CU\n", wgs, wgs / 256, best * 1e3 / (reps * (wgs / 256.0)));
         }
+    }
+    {
+        cf *d512 = da, *d32 = db;
+        auto k = k_core16<0>;
+        (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        float best = 1e9f;
+        for (int it = 0; it < 3; ++it) {
+            (void)hipEventRecord(e0);
+            hipLaunchKernelGGL(k, dim3(256), dim3(kThreads), kLdsBytes, 0, d1, d512, d32, sink, reps);
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+            best = ms < best ? ms : best;
+        }
+        printf("%-44s %.3f us per pair transform per CU\n", "16-point core: half-wave per row", best * 1e3 / (2.0 * reps));
     }
     run(k_core<1>, "pass 1 without its LDS scatter");
     run(k_core<2>, "no sub-FFTs (pass 1 + barriers only)");
