@@ -213,6 +213,7 @@ AW_HD void sub_fft512x2(Ctx &ctx, cf (&a)[2][8], cf *scr0, cf *scr1, const cf *t
 #ifndef AW_OLS_H
 #define AW_OLS_H 1        // 0: the fused 8192-frame tile on the 8 x 8 x 8 row transforms of rounds 1-3
 #endif
+
 AW_HD int hl_col(int lane) { return (lane & 7) + 8 * ((lane >> 4) & 1) + 16 * ((lane >> 3) & 1); }   // lane & 31 with bits 3 and 4 exchanged
 struct HLane {
     cf *row;        // the lane's row of the exchange buffer (also its half-wave's transpose scratch: 2 x 272 <= 576 elements)
@@ -258,8 +259,11 @@ template <bool INV, class Ctx> AW_HD void hl_tw_apply(Ctx &ctx, cf (&a)[16], con
 }
 // forward: a[j] = x[h + 32 j]  ->  a[kb] = X[col + 32 kb]
 template <class Ctx> AW_HD void sub_fft512h_fwd(Ctx &ctx, cf (&a)[16], const HLane &L) {
+    ctx.stamp(16);
     fft16<false>(a);
+    ctx.stamp(17);
     hl_tw_apply<false>(ctx, a, L);
+    ctx.stamp(18);
     const cf w32 = ctx.opaque(L.w32);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -268,6 +272,7 @@ template <class Ctx> AW_HD void sub_fft512h_fwd(Ctx &ctx, cf (&a)[16], const HLa
         a[q] = e;
         a[q + 8] = cmul(o, w32);
     }
+    ctx.stamp(19);
     ctx.wave_sync();                         // the half-wave's loads of its row have returned
 #pragma unroll
     for (int r = 0; r < 16; ++r) L.row[L.e2w + 17 * r] = a[r];
@@ -275,7 +280,9 @@ template <class Ctx> AW_HD void sub_fft512h_fwd(Ctx &ctx, cf (&a)[16], const HLa
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = ctx.ld(L.row + L.e2r + r);
     ctx.wave_sync();
+    ctx.stamp(20);
     fft16<false>(a);
+    ctx.stamp(21);
 }
 // inverse (unnormalised), the mirror image: a[kb] = X[col + 32 kb]  ->  a[j] = x[h + 32 j]
 template <class Ctx> AW_HD void sub_fft512h_inv(Ctx &ctx, cf (&a)[16], const HLane &L) {
@@ -574,6 +581,11 @@ AW_HD void tile_inverse_rows(Ctx &ctx, cf (&wacc)[2][8], cf *buf0, const cf *twa
 
 // The same three steps on the half-wave row transforms (AW_OLS_H): a lane holds 16 bins of ONE row.
 AW_HD void load_tab_h(const TileParams &p, int pair, int wave, int lane, cf2 (&tab)[16]) {
+#ifdef AW_ABL_NOTAB      // timing ablation only (wrong results): no table traffic
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) { tab[kb].a = mk(1.0f + pair, 0.5f * lane); tab[kb].b = mk(0.25f * kb, 1.0f * wave); }
+    return;
+#endif
     const cf2 *row = p.tab + ((long long)pair * kN + wave_row(wave, lane >> 5) * kSub + hl_col(lane));
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) tab[kb] = row[32 * kb];          // per half-wave 512 contiguous bytes (whole 128-byte lines per 8 lanes)

@@ -44,7 +44,6 @@ inner = ["fwd: z read (before stamp16 not shown)", "fwd passA fft8x2+tw", "fwd e
 def seg(a, b, name):
     d2 = t[:, b] - t[:, a]
     print(f"  [{a:2d}->{b:2d}] {name:40s} median {np.median(d2):8.0f}")
-print("last forward pair (p3) and inverse, detail:")
-seg(16, 17, "fwd pass A (2x fft8 + twiddles)"); seg(17, 18, "fwd exchange A"); seg(18, 19, "fwd pass B"); seg(19, 20, "fwd exchange B")
-seg(20, 21, "fwd pass C"); seg(21, 22, "table loads issue (+wait?)"); seg(22, 23, "publish + partner read + CMAC")
-seg(24, 25, "inv pass A"); seg(25, 26, "inv exchange A"); seg(26, 27, "inv pass B"); seg(27, 28, "inv exchange B"); seg(28, 29, "inv pass C")
+print("last forward pair (p3), detail (half-wave form: 16 -> fft16 -> 17 -> row twiddles -> 18 -> radix 2 -> 19 -> transpose -> 20 -> fft16 -> 21):")
+seg(16, 17, "fwd radix 16 (waits for the row reads)"); seg(17, 18, "fwd row twiddles (15 LDS reads)"); seg(18, 19, "fwd radix 2 across lane bit 4")
+seg(19, 20, "fwd 16 x 16 transpose through LDS"); seg(20, 21, "fwd radix 16"); seg(21, 22, "table loads issue (+wait?)"); seg(22, 23, "publish + partner read + CMAC")
