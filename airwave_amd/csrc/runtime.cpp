@@ -653,18 +653,18 @@ static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, flo
 //   C=9  4320: 30.2 / 29.4, 6145: 19 / 29;   C=10, 12  4320: 29 / 27, 26 / 24;   C=14  3000: 25.8 / 22.3, 4320: 20.5 / 22.3;   C=16  3000: 20.1 / 19.7, 4320: 16.4 / 19.6
 // The long-window kernels' rate does not depend on the HRIR length; the fused tiles' hop shrinks with it.
 static int lw_fused_crossover_taps(int channels) {
-    switch (channels) {
+    switch (channels) {          // profiles/round4_v2/lw_sweep.txt (the fused 8192-frame tile on the 16-point core); 1, 2, 3, 5: round4_v1
         case 1: return 10500;
         case 2: return 9000;
         case 3: return 8600;
-        case 4: return 5000;
+        case 4: return 5400;
         case 5: return 7300;
-        case 6: return 4800;
+        case 6: return 5200;
         case 7: return 4500;
-        case 8: return 4800;
-        case 14: case 15: return 3900;
-        case 16: return 3100;
-        default: return 4500;       // 9 - 13 channels
+        case 8: return 5200;
+        case 14: case 15: return 4000;
+        case 16: return 3200;
+        default: return 4900;       // 9 - 13 channels
     }
 }
 
