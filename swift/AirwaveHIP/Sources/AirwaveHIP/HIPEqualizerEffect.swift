@@ -43,13 +43,14 @@ public final class HIPEqualizerEffect /* : AudioEqualizerEffect */ {
     private var audioThreadProcessor: EqualizerBox?              // render thread only
     // `aw_eq_destroy` frees device memory and synchronises a stream: never on the render thread.  A processor the render
     // thread lets go of is parked (try-lock) and destroyed by the next control-side call, as in HIPSpatialEffect.
+    private let kRetireCapacity = 64       // boxes in flight between a publish and the next drain; the render thread never grows these arrays
     private let retiredLock = TryLock<[EqualizerBox]>(initialState: [])
     private var awaitingRetirement: [EqualizerBox] = []          // render thread only; capacity reserved in init
 
     public init(context: HIPContext) {
         self.context = context
-        awaitingRetirement.reserveCapacity(8)
-        retiredLock.withLock { $0.reserveCapacity(8) }
+        awaitingRetirement.reserveCapacity(kRetireCapacity)
+        retiredLock.withLock { $0.reserveCapacity(kRetireCapacity) }
     }
 
     /// EqualizerAPOParser.parse(data:filename:) -> definition handle (caller destroys with aw_eq_definition_destroy).
@@ -159,10 +160,13 @@ public final class HIPEqualizerEffect /* : AudioEqualizerEffect */ {
     }
 
     private func flushAwaitingRetirement() {
-        let moved: Bool? = retiredLock.withLockIfAvailable { list in
-            for b in awaitingRetirement { list.append(b) }
-            return true
+        // Never beyond the capacity reserved on the control side: an append that grows the array would allocate on the render thread.
+        // What does not fit stays in the render thread's own list for a later callback (after the control side has drained).
+        let moved: Int? = retiredLock.withLockIfAvailable { list in
+            var n = 0
+            while n < awaitingRetirement.count && list.count < list.capacity { list.append(awaitingRetirement[n]); n += 1 }
+            return n
         }
-        if moved != nil { awaitingRetirement.removeAll(keepingCapacity: true) }
+        if let n = moved, n > 0 { awaitingRetirement.removeFirst(n) }     // keeps the storage (no reallocation)
     }
 }

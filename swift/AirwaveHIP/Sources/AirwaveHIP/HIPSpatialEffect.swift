@@ -45,13 +45,14 @@ public final class HIPSpatialEffect /* : AudioSpatialEffect */ {
     // Destroying a handle frees device memory and synchronises a HIP stream: never on the render thread.  A state the
     // render thread lets go of is parked here (try-lock; kept one more callback under contention) and destroyed by the
     // next control-side call — the retirement scheme of ParametricEqualizerProcessor (ParametricEqualizerProcessor.swift:380-406).
+    private let kRetireCapacity = 64       // boxes in flight between a publish and the next drain; the render thread never grows these arrays
     private let retiredLock = TryLock<[SpatializerBox]>(initialState: [])
     private var awaitingRetirement: [SpatializerBox] = []                    // render thread only; capacity reserved in init
 
     public init(context: HIPContext) {
         self.context = context
-        awaitingRetirement.reserveCapacity(8)       // the render thread appends without allocating
-        retiredLock.withLock { $0.reserveCapacity(8) }
+        awaitingRetirement.reserveCapacity(kRetireCapacity)       // the render thread appends without allocating
+        retiredLock.withLock { $0.reserveCapacity(kRetireCapacity) }
     }
 
     /// AudioSpatialEffect.isReady
@@ -139,11 +140,14 @@ public final class HIPSpatialEffect /* : AudioSpatialEffect */ {
 
     private func flushAwaitingRetirement() {
         // try-lock only: under contention the states wait in the render thread's own list for a later callback
-        let moved: Bool? = retiredLock.withLockIfAvailable { list in
-            for b in awaitingRetirement { list.append(b) }
-            return true
+        // Never beyond the capacity reserved on the control side: an append that grows the array would allocate on the render thread.
+        // What does not fit stays in the render thread's own list for a later callback (after the control side has drained).
+        let moved: Int? = retiredLock.withLockIfAvailable { list in
+            var n = 0
+            while n < awaitingRetirement.count && list.count < list.capacity { list.append(awaitingRetirement[n]); n += 1 }
+            return n
         }
-        if moved != nil { awaitingRetirement.removeAll(keepingCapacity: true) }
+        if let n = moved, n > 0 { awaitingRetirement.removeFirst(n) }     // keeps the storage (no reallocation)
     }
 
     /// HRIRManager.resetConvolutionState(): the reference resets through the control side's reference to the state; the
