@@ -18,6 +18,9 @@
 #ifndef AW_OLS2_TABPRE
 #define AW_OLS2_TABPRE 2     // table sets of a pair's first row issued before its sub-FFTs (0, 1 or 2)
 #endif
+#ifndef AW_OLS2_H
+#define AW_OLS2_H AW_OLS_H   // mono and stereo: the row transforms on the 16-point core, a half-wave per row (tile_ols.hpp, sub_fft512h_*); 0: the 8 x 8 x 8 form everywhere
+#endif
 #ifndef AW_OLS2_SPLIT
 #define AW_OLS2_SPLIT 4      // measured (cfg 2 on 16384 windows / cfg 4 kernel ms): 16 -> 2.17 / 9.1, 8 -> 2.17 / 9.1, 4 -> 1.85 / 7.5, 0 -> 1.83 / 7.9
 #endif
@@ -156,6 +159,60 @@ AW_HD void pair_subfft_cmac2(Ctx &ctx, const TileParams &p, int pair, cf *buf, c
     ctx.stamp(23);
 }
 
+// The same on the half-wave row transforms (AW_OLS2_H): a lane holds 16 bins of ONE row, Z[col + 32 kb].  Tables in halves of
+// eight bins per output: 64 table VGPRs in flight at most, as above.
+AW_HD void load_tab2_h(const TileParams &p, int pair, int wave, int lane, int o, int half, cf2 (&tab)[8]) {
+#ifdef AW_ABL_NOTAB      // timing ablation only (wrong results): no table traffic
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { tab[i].a = mk(1.0f + pair, 0.5f * lane + o); tab[i].b = mk(0.25f * i + half, 1.0f * wave); }
+    return;
+#endif
+    const cf2 *row = p.tab + (((long long)pair * kN + wave_row(wave, lane >> 5) * kSub + hl_col(lane) + 256 * half) * 2 + o);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tab[i] = row[32 * i * 2];
+}
+template <class Ctx>
+AW_HD void pair_subfft_cmac2_h(Ctx &ctx, const TileParams &p, int pair, cf *buf, const cf *twh, int lane, int wave, cf (&we)[16], cf (&wo)[16]) {
+    const HLane L = hl_make(ctx, buf, twh, lane, wave);
+    cf z[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) z[j] = ctx.ld(L.row + L.h + 32 * j);
+    cf2 ta[8], tb[8];
+    if (AW_OLS2_TABPRE >= 1) load_tab2_h(p, pair, wave, lane, 0, 0, ta);
+    if (AW_OLS2_TABPRE >= 2) load_tab2_h(p, pair, wave, lane, 1, 0, tb);
+    sub_fft512h_fwd(ctx, z, L);
+    if (AW_OLS2_TABPRE < 1) load_tab2_h(p, pair, wave, lane, 0, 0, ta);
+    if (AW_OLS2_TABPRE < 2) load_tab2_h(p, pair, wave, lane, 1, 0, tb);
+    ctx.stamp(22);
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) L.row[L.col + 32 * kb] = z[kb];
+    ctx.wave_sync();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        cf zp[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int idx = L.pidx - 32 * (8 * half + i);
+            if (half == 0 && i == 0) idx &= 511;               // only (row 0, column 0) wraps: 512 -> 0
+            zp[i] = ctx.ld(L.prow + idx);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            we[8 * half + i] = cfma(z[8 * half + i], ta[i].a, we[8 * half + i]);
+            we[8 * half + i] = cfmac(zp[i], ta[i].b, we[8 * half + i]);
+        }
+        if (half == 0) load_tab2_h(p, pair, wave, lane, 0, 1, ta);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            wo[8 * half + i] = cfma(z[8 * half + i], tb[i].a, wo[8 * half + i]);
+            wo[8 * half + i] = cfmac(zp[i], tb[i].b, wo[8 * half + i]);
+        }
+        if (half == 0) load_tab2_h(p, pair, wave, lane, 1, 1, tb);
+    }
+    ctx.wave_sync();    // partner reads done before this wave reuses its rows as scratch
+    ctx.stamp(23);
+}
+
 // Final pass of both inverse transforms: radix-16 across the rows of buf0 (u_e) and buf1 (u_o), then the
 // half-rate results interleaved into full-rate frames: window position 2m (+1) = frame f0 + 2m (+1).
 template <class Ctx, bool INTERIOR>
@@ -202,8 +259,17 @@ AW_HD void tiles_fused_ols2(Ctx &ctx, const TileParams &p, long long first, long
     const int Cn = CS > 0 ? CS : p.n_channels;
     if (first >= end) return;
     const cf w1 = p.tw1[t];
-    twa[t] = p.twa[t];
-    if (t < kTwbElems) twb[t] = p.twb[t];
+    // Which row transform: measured per layout on 128 streams x 10 s, 4320 taps (tools/ols2_ab.py, G frames/s, 8 x 8 x 8 -> half-wave):
+    // mono 205 -> 230, stereo 135 -> 146; 3 / 5 / 7 channels 101 -> 95, 61 -> 57, 40.8 -> 40.0 (19-39 spilled VGPRs instead of 0-5:
+    // sixteen live values per transform on top of two accumulators); 4 / 6 / 8 channels 61 -> 60, 42 -> 42, 32 -> 32.5.
+    constexpr bool kH = AW_OLS2_H != 0 && (CS == 1 || CS == 2);
+    if constexpr (kH) {
+        twa[t] = hl_twiddle(p.twa, t);                   // [16][32] row twiddles of the half-wave form
+        (void)twb;
+    } else {
+        twa[t] = p.twa[t];
+        if (t < kTwbElems) twb[t] = p.twb[t];
+    }
 
     float raw[16][kBatchCh];
     {
@@ -220,11 +286,13 @@ AW_HD void tiles_fused_ols2(Ctx &ctx, const TileParams &p, long long first, long
         const float *hist_s = p.hist + stream * (long long)p.hist_len * Cn;
         const long long f0 = (long long)cur.tile * p.hop - p.hist_len;     // real frame of window position 0
 
-        cf we[2][8], wo[2][8];
+        cf we[16], wo[16];            // half-wave form: 16 bins of the lane's row; 8 x 8 x 8 form: [row][8 bins]
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { we[s][i] = mk(0.f, 0.f); wo[s][i] = mk(0.f, 0.f); }
+        for (int i = 0; i < 16; ++i) { we[i] = mk(0.f, 0.f); wo[i] = mk(0.f, 0.f); }
+        auto subfft_cmac_ = [&](int pr, cf *bf) {
+            if constexpr (kH) pair_subfft_cmac2_h(ctx, p, pr, bf, twa, lane, wave, we, wo);
+            else pair_subfft_cmac2(ctx, p, pr, bf, twa, twb, lane, wave, reinterpret_cast<cf (&)[2][8]>(we), reinterpret_cast<cf (&)[2][8]>(wo));
+        };
 
         const int n_batches = NB > 0 ? NB : (p.n_pairs + 1) / 2;
         auto batch = [&](int b, bool more) {
@@ -249,12 +317,12 @@ AW_HD void tiles_fused_ols2(Ctx &ctx, const TileParams &p, long long first, long
             ctx.stamp(4 * (b & 3) + 1);
             ctx.barrier();
             ctx.stamp(4 * (b & 3) + 2);
-            pair_subfft_cmac2(ctx, p, 2 * b, buf0, twa, twb, lane, wave, we, wo);
+            subfft_cmac_(2 * b, buf0);
             ctx.stamp(4 * (b & 3) + 3);
             // the next batch's frames travel under the second pair's sub-FFTs, in two halves: all 16 pseudo-frames
             // at once (64 VGPRs) on top of the 64 accumulator registers is what hipcc spills
             if (more) load_batch2<CS, INTERIOR, 0, AW_OLS2_SPLIT>(p, in_s, hist_s, f0, t, 4 * (b + 1), raw);
-            if (two) pair_subfft_cmac2(ctx, p, 2 * b + 1, buf1, twa, twb, lane, wave, we, wo);   // run-time layouts: a phantom pair hits the zero pair
+            if (two) subfft_cmac_(2 * b + 1, buf1);   // run-time layouts: a phantom pair hits the zero pair
             if (more) load_batch2<CS, INTERIOR, AW_OLS2_SPLIT, 16>(p, in_s, hist_s, f0, t, 4 * (b + 1), raw);
         };
         if constexpr (NB > 0) {
@@ -265,8 +333,13 @@ AW_HD void tiles_fused_ols2(Ctx &ctx, const TileParams &p, long long first, long
         }
 
         ctx.stamp(30);
-        tile_inverse_rows(ctx, we, buf0, twa, twb);
-        tile_inverse_rows(ctx, wo, buf1, twa, twb);
+        if constexpr (kH) {
+            tile_inverse_rows_h(ctx, we, buf0, twa);
+            tile_inverse_rows_h(ctx, wo, buf1, twa);
+        } else {
+            tile_inverse_rows(ctx, reinterpret_cast<cf (&)[2][8]>(we), buf0, twa, twb);
+            tile_inverse_rows(ctx, reinterpret_cast<cf (&)[2][8]>(wo), buf1, twa, twb);
+        }
         {   // next tile's first batch (unconditional, see tiles_fused_ols)
             const TileId nx = tile_of<INTERIOR>(p, id + step < end ? id + step : id);
             load_batch2<CS, INTERIOR>(p, p.in + nx.stream * p.frames * Cn, p.hist + nx.stream * (long long)p.hist_len * Cn,

@@ -271,7 +271,11 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
         //     end of the 8192-frame window's range (6 and 8 from ~6100: 26.4 / 27.5 and 21.1 / 21.2 at 6145; 4 never: 38.2 / 36.9).
         //     Odd counts cross early: the 8192-frame kernels pad them to whole pairs, the polyphase view has 2C pseudo-channels.
         const int c = n_in;
-        const int from = c == 1 ? 0 : c == 2 ? 2000 : c == 3 ? 1800 : c == 5 ? 3200 : c == 7 ? 4400 : (c == 6 || c == 8) ? 6100 : (1 << 30);
+        //     Round 4: the 8192-frame tile's row transforms moved to the 16-point core for every layout (+3 … +10 %), the 16384-frame
+        //     kernels' only for mono and stereo (tile_ols2.hpp), so the odd layouts cross later (profiles/round4_v2/window_sweep.txt):
+        //     3 channels from ~2400 (2300: 113.4 / 113.1; 2600: 107 / 111), 5 from ~3800 (3500: 62.0 / 56.5; 3800: 55.7 / 55.7),
+        //     7 from ~4850 (4700: 36.0 / 34.3; 5000: 32.4 / 33.3); stereo unchanged (1800: 174 / 174; 2000: 173 / 174).
+        const int from = c == 1 ? 0 : c == 2 ? 2000 : c == 3 ? 2400 : c == 5 ? 3800 : c == 7 ? 4850 : (c == 6 || c == 8) ? 6100 : (1 << 30);
         window = (hrir->taps >= from && fused2_ok) ? awk::kN2 : AW_DEFAULT_WINDOW;
         // (3) small batches cannot fill 256 CUs with 16384-frame tiles (a 10 s stream is 40 of them): the 8192-frame kernels give
         //     three times the tiles.  Crossover in streams (tools/small_batch_sweep.py, 4320 taps, 10 s per stream): mono 8
@@ -660,7 +664,7 @@ static int lw_fused_crossover_taps(int channels) {
         case 4: return 5400;
         case 5: return 7300;
         case 6: return 5200;
-        case 7: return 4500;
+        case 7: return 4700;
         case 8: return 5200;
         case 14: case 15: return 4000;
         case 16: return 3200;

@@ -106,8 +106,8 @@ def test_hrir_lengths_on_the_fused_path(aw, oracle, taps):
 
 @pytest.mark.parametrize("channels,taps,streams,fft", [(2, 4320, 1, 8192), (2, 4320, 23, 8192), (2, 4320, 24, 16384), (2, 1999, 64, 8192), (2, 2000, 64, 16384), (1, 4320, 7, 8192), (1, 4320, 8, 16384),
                                                        (8, 4320, 128, 8192), (8, 5900, 16, 8192), (8, 6100, 16, 16384), (8, 6100, 4, 8192), (2, 6146, 1, 16384), (4, 6145, 128, 8192), (4, 6146, 128, 16384),
-                                                       (1, 512, 16, 16384), (3, 1799, 128, 8192), (3, 1800, 128, 16384), (3, 4320, 128, 16384), (3, 4320, 11, 8192), (5, 4320, 32, 16384), (5, 3199, 128, 8192), (5, 3200, 128, 16384),
-                                                       (7, 4320, 128, 8192), (7, 4400, 16, 16384), (12, 6145, 16, 8192), (9, 6145, 16, 8192), (13, 6000, 16, 8192), (16, 5900, 16, 8192)])
+                                                       (1, 512, 16, 16384), (3, 2399, 128, 8192), (3, 2400, 128, 16384), (3, 4320, 128, 16384), (3, 4320, 11, 8192), (5, 4320, 32, 16384), (5, 3799, 128, 8192), (5, 3800, 128, 16384),
+                                                       (7, 4320, 128, 8192), (7, 4849, 16, 8192), (7, 4850, 16, 16384), (12, 6145, 16, 8192), (9, 6145, 16, 8192), (13, 6000, 16, 8192), (16, 5900, 16, 8192)])
 def test_window_policy(aw, oracle, channels, taps, streams, fft):
     """runtime.cpp: the measured crossover of the two fused kernels by layout and HRIR length, 8192-frame windows for
     batches too small to fill the chip with 16384-frame tiles, 16384 whenever one 8192-frame window cannot hold the HRIR."""

@@ -12,7 +12,7 @@ x = torch.empty((S, F, C), device="cuda"); y = torch.empty((S, F, 2), device="cu
 ctx.synth_fill(x.data_ptr(), S, F, C)
 lt = (np.arange(C) % 14).astype(np.int32); rt = ((np.arange(C) + 7) % 14).astype(np.int32)
 rng = np.random.default_rng(1)
-for taps in (512, 1024, 2048, 3000, 3600, 4320, 5000, 5600, 6145):
+for taps in [int(t) for t in os.environ.get("TAPS", "512,1024,2048,3000,3600,4320,5000,5600,6145").split(",")]:
     h = (rng.standard_normal((14, taps)) * np.exp(-np.arange(taps) / (taps / 6.0))).astype(np.float32)
     row = []
     for win in (8192, 16384):
