@@ -44,7 +44,10 @@ EXTRA_FLAGS = {"device/march_kernels.hip": [] if os.environ.get("AW_MARCH_SLP") 
                "device/lw_kernels.hip": ["-fno-slp-vectorize", "-DAW_XA_REG=1", "-DAW_LDS_ATOMIC_READS=1"],
                "device/lw_split_a.hip": ["-fno-slp-vectorize"], "device/lw_split_b.hip": ["-fno-slp-vectorize"], "device/lw_split_c.hip": ["-fno-slp-vectorize"],
                "device/lw_split_d.hip": ["-fno-slp-vectorize"], "device/lw_split_e.hip": ["-fno-slp-vectorize"],
-               "device/kernels.hip": [] if os.environ.get("AW_KERNELS_SLP") else ["-fno-slp-vectorize"]}
+               "device/kernels.hip": [] if os.environ.get("AW_KERNELS_SLP") else ["-fno-slp-vectorize"],
+               # the even 16384-frame layouts kept SLP through round 3 (their 8 x 8 x 8 form measured faster with it); on the half-wave row
+               # transform they do not: 4 / 6 / 8 channels 66.8 / 46.5 / 33.4 -> 68.8 / 52.9 / 35.4 G frames/s (tools/ols2_ab.py)
+               "device/ols2_even_kernels.hip": [] if os.environ.get("AW_OLS2_EVEN_SLP") else ["-fno-slp-vectorize"]}
 HEADERS = sorted(os.path.relpath(os.path.join(d, f), CSRC) for d, _, fs in os.walk(CSRC) for f in fs if f.endswith((".hpp", ".h"))) + [
     "../../include/airwave_hip.h",
 ]

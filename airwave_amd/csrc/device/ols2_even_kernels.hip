@@ -1,5 +1,6 @@
 // ols2_even_kernels.hip — the 16384-frame-window kernels of 4, 6 and 8 channels, in a translation unit of their
-// own because they keep hipcc's SLP vectoriser (see ols2_kernel.hpp); everything else about them is in kernels.hip.
+// own: through round 3 they kept hipcc's SLP vectoriser (see ols2_kernel.hpp; since the half-wave row transform of round 4 they are
+// built without it like everything else, build.py), and the unit builds beside kernels.hip.  Everything else about them is in kernels.hip.
 #include "ols2_kernel.hpp"
 
 namespace awk {

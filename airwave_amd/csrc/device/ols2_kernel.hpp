@@ -1,8 +1,8 @@
 // ols2_kernel.hpp — the 16384-frame-window tile kernel template, shared by the two translation units that instantiate it:
-// kernels.hip (1, 2, 3, 5, 7 channels, built with -fno-slp-vectorize) and ols2_even_kernels.hip (4, 6, 8 channels, built with
-// the SLP vectoriser: without it those layouts spill 212 instead of 96 VGPRs — tools/ubench/one_ols2.hip — and run 25-30 %
-// slower (8 channels, 4320 taps: 21.6 against 24.9 G frames/s), while the others drop from 36 spills to 3 and run 10-20 %
-// faster (stereo 6146 taps: 121 against 99)).
+// kernels.hip (1, 2, 3, 5, 7 channels) and ols2_even_kernels.hip (4, 6, 8 channels), both built with -fno-slp-vectorize.
+// History: on the 8 x 8 x 8 row transforms of rounds 1-3 the even layouts wanted the SLP vectoriser (without it they spilled 212
+// instead of 96 VGPRs — tools/ubench/one_ols2.hip — and ran 25-30 % slower) while the others dropped from 36 spills to 3 without it;
+// on the half-wave row transform of round 4 (tables in parts of four bins) nothing spills and every layout is faster without SLP.
 #pragma once
 #include "kernels.hpp"
 #include "gpu_ctx.hpp"

@@ -159,55 +159,58 @@ AW_HD void pair_subfft_cmac2(Ctx &ctx, const TileParams &p, int pair, cf *buf, c
     ctx.stamp(23);
 }
 
-// The same on the half-wave row transforms (AW_OLS2_H): a lane holds 16 bins of ONE row, Z[col + 32 kb].  Tables in halves of
-// eight bins per output: 64 table VGPRs in flight at most, as above.
-AW_HD void load_tab2_h(const TileParams &p, int pair, int wave, int lane, int o, int half, cf2 (&tab)[8]) {
+// The same on the half-wave row transforms (AW_OLS2_H): a lane holds 16 bins of ONE row, Z[col + 32 kb].  Tables in parts of
+// G bins per output (G = 8: 64 table VGPRs in flight at most, as above; G = 4: 32, for the layouts whose accumulators and frame
+// batch leave less room).
+template <int G>
+AW_HD void load_tab2_h(const TileParams &p, int pair, int wave, int lane, int o, int part, cf2 (&tab)[G]) {
 #ifdef AW_ABL_NOTAB      // timing ablation only (wrong results): no table traffic
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { tab[i].a = mk(1.0f + pair, 0.5f * lane + o); tab[i].b = mk(0.25f * i + half, 1.0f * wave); }
+    for (int i = 0; i < G; ++i) { tab[i].a = mk(1.0f + pair, 0.5f * lane + o); tab[i].b = mk(0.25f * i + part, 1.0f * wave); }
     return;
 #endif
-    const cf2 *row = p.tab + (((long long)pair * kN + wave_row(wave, lane >> 5) * kSub + hl_col(lane) + 256 * half) * 2 + o);
+    const cf2 *row = p.tab + (((long long)pair * kN + wave_row(wave, lane >> 5) * kSub + hl_col(lane) + 32 * G * part) * 2 + o);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) tab[i] = row[32 * i * 2];
+    for (int i = 0; i < G; ++i) tab[i] = row[32 * i * 2];
 }
-template <class Ctx>
+template <int G, class Ctx>
 AW_HD void pair_subfft_cmac2_h(Ctx &ctx, const TileParams &p, int pair, cf *buf, const cf *twh, int lane, int wave, cf (&we)[16], cf (&wo)[16]) {
+    constexpr int NPART = 16 / G;
     const HLane L = hl_make(ctx, buf, twh, lane, wave);
     cf z[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) z[j] = ctx.ld(L.row + L.h + 32 * j);
-    cf2 ta[8], tb[8];
-    if (AW_OLS2_TABPRE >= 1) load_tab2_h(p, pair, wave, lane, 0, 0, ta);
-    if (AW_OLS2_TABPRE >= 2) load_tab2_h(p, pair, wave, lane, 1, 0, tb);
+    cf2 ta[G], tb[G];
+    if (AW_OLS2_TABPRE >= 1) load_tab2_h<G>(p, pair, wave, lane, 0, 0, ta);
+    if (AW_OLS2_TABPRE >= 2) load_tab2_h<G>(p, pair, wave, lane, 1, 0, tb);
     sub_fft512h_fwd(ctx, z, L);
-    if (AW_OLS2_TABPRE < 1) load_tab2_h(p, pair, wave, lane, 0, 0, ta);
-    if (AW_OLS2_TABPRE < 2) load_tab2_h(p, pair, wave, lane, 1, 0, tb);
+    if (AW_OLS2_TABPRE < 1) load_tab2_h<G>(p, pair, wave, lane, 0, 0, ta);
+    if (AW_OLS2_TABPRE < 2) load_tab2_h<G>(p, pair, wave, lane, 1, 0, tb);
     ctx.stamp(22);
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) L.row[L.col + 32 * kb] = z[kb];
     ctx.wave_sync();
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        cf zp[8];
+    for (int part = 0; part < NPART; ++part) {
+        cf zp[G];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int idx = L.pidx - 32 * (8 * half + i);
-            if (half == 0 && i == 0) idx &= 511;               // only (row 0, column 0) wraps: 512 -> 0
+        for (int i = 0; i < G; ++i) {
+            int idx = L.pidx - 32 * (G * part + i);
+            if (part == 0 && i == 0) idx &= 511;               // only (row 0, column 0) wraps: 512 -> 0
             zp[i] = ctx.ld(L.prow + idx);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            we[8 * half + i] = cfma(z[8 * half + i], ta[i].a, we[8 * half + i]);
-            we[8 * half + i] = cfmac(zp[i], ta[i].b, we[8 * half + i]);
+        for (int i = 0; i < G; ++i) {
+            we[G * part + i] = cfma(z[G * part + i], ta[i].a, we[G * part + i]);
+            we[G * part + i] = cfmac(zp[i], ta[i].b, we[G * part + i]);
         }
-        if (half == 0) load_tab2_h(p, pair, wave, lane, 0, 1, ta);
+        if (part + 1 < NPART) load_tab2_h<G>(p, pair, wave, lane, 0, part + 1, ta);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            wo[8 * half + i] = cfma(z[8 * half + i], tb[i].a, wo[8 * half + i]);
-            wo[8 * half + i] = cfmac(zp[i], tb[i].b, wo[8 * half + i]);
+        for (int i = 0; i < G; ++i) {
+            wo[G * part + i] = cfma(z[G * part + i], tb[i].a, wo[G * part + i]);
+            wo[G * part + i] = cfmac(zp[i], tb[i].b, wo[G * part + i]);
         }
-        if (half == 0) load_tab2_h(p, pair, wave, lane, 1, 1, tb);
+        if (part + 1 < NPART) load_tab2_h<G>(p, pair, wave, lane, 1, part + 1, tb);
     }
     ctx.wave_sync();    // partner reads done before this wave reuses its rows as scratch
     ctx.stamp(23);
@@ -259,10 +262,12 @@ AW_HD void tiles_fused_ols2(Ctx &ctx, const TileParams &p, long long first, long
     const int Cn = CS > 0 ? CS : p.n_channels;
     if (first >= end) return;
     const cf w1 = p.tw1[t];
-    // Which row transform: measured per layout on 128 streams x 10 s, 4320 taps (tools/ols2_ab.py, G frames/s, 8 x 8 x 8 -> half-wave):
-    // mono 205 -> 230, stereo 135 -> 146; 3 / 5 / 7 channels 101 -> 95, 61 -> 57, 40.8 -> 40.0 (19-39 spilled VGPRs instead of 0-5:
-    // sixteen live values per transform on top of two accumulators); 4 / 6 / 8 channels 61 -> 60, 42 -> 42, 32 -> 32.5.
-    constexpr bool kH = AW_OLS2_H != 0 && (CS == 1 || CS == 2);
+    // Row transform: the half-wave form of tile_ols.hpp.  Measured per layout on 128 streams x 10 s, 4320 taps (tools/ols2_ab.py, G frames/s,
+    // 8 x 8 x 8 -> half-wave): mono 205 -> 230, stereo 135 -> 146 with the tables in parts of eight bins; with eight-bin parts 3 / 5 / 7 channels
+    // spill 19-39 VGPRs (sixteen live values per transform next to two accumulators and the frame batch) and lose 2-7 %, in parts of FOUR
+    // bins nothing spills and every layout gains: 3 / 4 / 5 / 6 / 7 / 8 channels 99 -> 104, 60.7 -> 68, 60.5 -> 64, 41.7 -> 47, 40.8 -> 43.4, 31.9 -> 33.9.
+    constexpr bool kH = AW_OLS2_H != 0;
+    constexpr int kHG = (CS == 1 || CS == 2) ? 8 : 4;     // table entries per part
     if constexpr (kH) {
         twa[t] = hl_twiddle(p.twa, t);                   // [16][32] row twiddles of the half-wave form
         (void)twb;
@@ -290,7 +295,7 @@ AW_HD void tiles_fused_ols2(Ctx &ctx, const TileParams &p, long long first, long
 #pragma unroll
         for (int i = 0; i < 16; ++i) { we[i] = mk(0.f, 0.f); wo[i] = mk(0.f, 0.f); }
         auto subfft_cmac_ = [&](int pr, cf *bf) {
-            if constexpr (kH) pair_subfft_cmac2_h(ctx, p, pr, bf, twa, lane, wave, we, wo);
+            if constexpr (kH) pair_subfft_cmac2_h<kHG>(ctx, p, pr, bf, twa, lane, wave, we, wo);
             else pair_subfft_cmac2(ctx, p, pr, bf, twa, twb, lane, wave, reinterpret_cast<cf (&)[2][8]>(we), reinterpret_cast<cf (&)[2][8]>(wo));
         };
 

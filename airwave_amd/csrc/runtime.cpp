@@ -261,7 +261,11 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
     //     kernels carry ~100 spilled VGPRs: 4 channels up to ~7000 (6146: 36.8 / 35.1; 8000: 30.7 / 35.4), 6 up to ~8500
     //     (8000: 23.5 / 21.8; 9000: 20.2 / 21.1), 8 up to ~7800 (6146: 20.6 / 17.6; 8000: 18.2 / 18.2).  9+ channels have no
     //     16384-frame vector kernels: partitioned as soon as one 8192-frame window cannot hold the HRIR.
-    const int upto = (n_in <= 3 || n_in == 5) ? 12289 : n_in == 4 ? 7000 : n_in == 6 ? 8500 : n_in == 8 ? 7800 : n_in == 7 ? 11800 : 0;
+    //     Round 4, the 16384-frame kernels on the half-wave row transform (no spills, 4 / 6 / 8 channels +12 / +27 / +11 %), re-measured
+    //     (profiles/round4_v2/policy_sweeps_final.txt, 16384 / partitioned): 4 channels up to ~10 500 (10 000: 36.7 / 33.2; 11 000: 32.7 / 35.8),
+    //     6 to the window's limit (12 289: 21.0 / 20.7), 7 up to ~11 500 (11 000: 21.1 / 19.1; 11 800: 18.2 / 19.0), 8 up to ~11 200
+    //     (11 000: 17.4 / 17.2; 11 800: 15.5 / 17.3).
+    const int upto = (n_in <= 3 || n_in == 5 || n_in == 6) ? 12289 : n_in == 4 ? 10500 : n_in == 8 ? 11200 : n_in == 7 ? 11500 : 0;
     const bool fused2_ok = fits2 && hrir->taps <= upto;
     if (window == 0) {
         // (2) 8192- against 16384-frame windows where both can hold the HRIR (8192 / 16384): mono always 16384 (4320 taps 93 / 202),
@@ -271,11 +275,12 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
         //     end of the 8192-frame window's range (6 and 8 from ~6100: 26.4 / 27.5 and 21.1 / 21.2 at 6145; 4 never: 38.2 / 36.9).
         //     Odd counts cross early: the 8192-frame kernels pad them to whole pairs, the polyphase view has 2C pseudo-channels.
         const int c = n_in;
-        //     Round 4: the 8192-frame tile's row transforms moved to the 16-point core for every layout (+3 … +10 %), the 16384-frame
-        //     kernels' only for mono and stereo (tile_ols2.hpp), so the odd layouts cross later (profiles/round4_v2/window_sweep.txt):
-        //     3 channels from ~2400 (2300: 113.4 / 113.1; 2600: 107 / 111), 5 from ~3800 (3500: 62.0 / 56.5; 3800: 55.7 / 55.7),
-        //     7 from ~4850 (4700: 36.0 / 34.3; 5000: 32.4 / 33.3); stereo unchanged (1800: 174 / 174; 2000: 173 / 174).
-        const int from = c == 1 ? 0 : c == 2 ? 2000 : c == 3 ? 2400 : c == 5 ? 3800 : c == 7 ? 4850 : (c == 6 || c == 8) ? 6100 : (1 << 30);
+        //     Round 4: both fused kernels moved to the half-wave row transform (tile_ols.hpp; the 16384-frame kernels with their tables in
+        //     parts of four bins and all of them without SLP), re-measured (profiles/round4_v2/policy_sweeps_final.txt, 128 streams x 4 s):
+        //     stereo from ~1800 (1500: 180 / 171; 1800: 171 / 172), 3 channels from ~1800 (1500: 123 / 119; 1800: 117 / 119), 5 from ~3400
+        //     (3200: 63.7 / 60.5; 3500: 59.9 / 61.4), 7 from ~4400 (4320: 38.9 / 38.8; 4500: 36.4 / 36.8), 4 from ~5300 (5000: 59.9 / 58.5;
+        //     5300: 57.9 / 58.0), 6 from ~4700 (4320: 47.2 / 45.9; 5000: 39.4 / 44.9), 8 from ~5500 (5300: 30.1 / 29.0; 5600: 27.4 / 28.4).
+        const int from = c == 1 ? 0 : c == 2 ? 1800 : c == 3 ? 1800 : c == 5 ? 3400 : c == 7 ? 4400 : c == 4 ? 5300 : c == 6 ? 4700 : c == 8 ? 5500 : (1 << 30);
         window = (hrir->taps >= from && fused2_ok) ? awk::kN2 : AW_DEFAULT_WINDOW;
         // (3) small batches cannot fill 256 CUs with 16384-frame tiles (a 10 s stream is 40 of them): the 8192-frame kernels give
         //     three times the tiles.  Crossover in streams (tools/small_batch_sweep.py, 4320 taps, 10 s per stream): mono 8
@@ -657,13 +662,13 @@ static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, flo
 //   C=9  4320: 30.2 / 29.4, 6145: 19 / 29;   C=10, 12  4320: 29 / 27, 26 / 24;   C=14  3000: 25.8 / 22.3, 4320: 20.5 / 22.3;   C=16  3000: 20.1 / 19.7, 4320: 16.4 / 19.6
 // The long-window kernels' rate does not depend on the HRIR length; the fused tiles' hop shrinks with it.
 static int lw_fused_crossover_taps(int channels) {
-    switch (channels) {          // profiles/round4_v2/lw_sweep.txt (the fused 8192-frame tile on the 16-point core); 1, 2, 3, 5: round4_v1
-        case 1: return 10500;
-        case 2: return 9000;
-        case 3: return 8600;
-        case 4: return 5400;
-        case 5: return 7300;
-        case 6: return 5200;
+    switch (channels) {          // profiles/round4_v2/policy_sweeps_final.txt and lw_sweep.txt (both fused kernels on the half-wave row transform)
+        case 1: return 10800;
+        case 2: return 9300;
+        case 3: return 9000;
+        case 4: return 5200;
+        case 5: return 7500;
+        case 6: return 5500;
         case 7: return 4700;
         case 8: return 5200;
         case 14: case 15: return 4000;

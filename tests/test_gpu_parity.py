@@ -104,10 +104,10 @@ def test_hrir_lengths_on_the_fused_path(aw, oracle, taps):
     assert oracle.peak_rel_error(y[0], ref) < TOL
 
 
-@pytest.mark.parametrize("channels,taps,streams,fft", [(2, 4320, 1, 8192), (2, 4320, 23, 8192), (2, 4320, 24, 16384), (2, 1999, 64, 8192), (2, 2000, 64, 16384), (1, 4320, 7, 8192), (1, 4320, 8, 16384),
-                                                       (8, 4320, 128, 8192), (8, 5900, 16, 8192), (8, 6100, 16, 16384), (8, 6100, 4, 8192), (2, 6146, 1, 16384), (4, 6145, 128, 8192), (4, 6146, 128, 16384),
-                                                       (1, 512, 16, 16384), (3, 2399, 128, 8192), (3, 2400, 128, 16384), (3, 4320, 128, 16384), (3, 4320, 11, 8192), (5, 4320, 32, 16384), (5, 3799, 128, 8192), (5, 3800, 128, 16384),
-                                                       (7, 4320, 128, 8192), (7, 4849, 16, 8192), (7, 4850, 16, 16384), (12, 6145, 16, 8192), (9, 6145, 16, 8192), (13, 6000, 16, 8192), (16, 5900, 16, 8192)])
+@pytest.mark.parametrize("channels,taps,streams,fft", [(2, 4320, 1, 8192), (2, 4320, 23, 8192), (2, 4320, 24, 16384), (2, 1799, 64, 8192), (2, 1800, 64, 16384), (1, 4320, 7, 8192), (1, 4320, 8, 16384),
+                                                       (8, 4320, 128, 8192), (8, 5499, 16, 8192), (8, 5500, 16, 16384), (8, 6100, 4, 8192), (2, 6146, 1, 16384), (4, 5299, 128, 8192), (4, 5300, 128, 16384), (6, 4699, 128, 8192), (6, 4700, 128, 16384),
+                                                       (1, 512, 16, 16384), (3, 1799, 128, 8192), (3, 1800, 128, 16384), (3, 4320, 128, 16384), (3, 4320, 11, 8192), (5, 4320, 32, 16384), (5, 3399, 128, 8192), (5, 3400, 128, 16384),
+                                                       (7, 4320, 128, 8192), (7, 4399, 16, 8192), (7, 4400, 16, 16384), (12, 6145, 16, 8192), (9, 6145, 16, 8192), (13, 6000, 16, 8192), (16, 5900, 16, 8192)])
 def test_window_policy(aw, oracle, channels, taps, streams, fft):
     """runtime.cpp: the measured crossover of the two fused kernels by layout and HRIR length, 8192-frame windows for
     batches too small to fill the chip with 16384-frame tiles, 16384 whenever one 8192-frame window cannot hold the HRIR."""
@@ -253,8 +253,8 @@ def test_long_tap_partitioned_path(aw, oracle, golden_dir):
     assert oracle.peak_rel_error(sp.process(x)[0], g["expected"]) < TOL
 
 
-@pytest.mark.parametrize("taps,channels,path,fft", [(6146, 2, 0, 16384), (7800, 8, 0, 16384), (8640, 8, 1, 8192), (8640, 7, 0, 16384), (11800, 7, 0, 16384), (12288, 5, 0, 16384), (8500, 6, 0, 16384),
-                                                    (12288, 7, 1, 8192), (7001, 4, 1, 8192), (8501, 6, 1, 8192), (12290, 5, 1, 8192), (6100, 12, 0, 8192), (6146, 12, 1, 8192), (6145, 9, 0, 8192), (6000, 16, 1, 8192), (20000, 3, 1, 8192),
+@pytest.mark.parametrize("taps,channels,path,fft", [(6146, 2, 0, 16384), (7800, 8, 0, 16384), (8640, 8, 0, 16384), (11200, 8, 0, 16384), (11201, 8, 1, 8192), (8640, 7, 0, 16384), (11500, 7, 0, 16384), (12288, 5, 0, 16384), (8500, 6, 0, 16384),
+                                                    (12288, 7, 1, 8192), (10500, 4, 0, 16384), (10501, 4, 1, 8192), (12288, 6, 0, 16384), (12290, 6, 1, 8192), (12290, 5, 1, 8192), (6100, 12, 0, 8192), (6146, 12, 1, 8192), (6145, 9, 0, 8192), (6000, 16, 1, 8192), (20000, 3, 1, 8192),
                                                     (20000, 1, 1, 8192), (40000, 2, 1, 8192), (70000, 7, 1, 8192)])
 def test_long_hrir_paths_chunks_and_state(aw, oracle, taps, channels, path, fft, monkeypatch):
     """HRIRs beyond one 8192-frame window: up to 12288 taps (cfg 4: 4320 taps resampled x2 = 8640) run fused on
