@@ -590,7 +590,20 @@ AW_HD void load_tab_h(const TileParams &p, int pair, int wave, int lane, cf2 (&t
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) tab[kb] = row[32 * kb];          // per half-wave 512 contiguous bytes (whole 128-byte lines per 8 lanes)
 }
-template <class Ctx>
+// G: table entries per part when the tables are fetched after the transform (G = 16: all at once, 64 VGPRs; G = 4: two parts of
+// four in flight, 32 VGPRs — the next part travels while the current one is consumed).
+template <int G>
+AW_HD void load_tab_part_h(const TileParams &p, int pair, int wave, int lane, int part, cf2 *tab) {
+#ifdef AW_ABL_NOTAB      // timing ablation only (wrong results): no table traffic
+#pragma unroll
+    for (int i = 0; i < G; ++i) { tab[i].a = mk(1.0f + pair, 0.5f * lane); tab[i].b = mk(0.25f * i + part, 1.0f * wave); }
+    return;
+#endif
+    const cf2 *row = p.tab + ((long long)pair * kN + wave_row(wave, lane >> 5) * kSub + hl_col(lane) + 32 * G * part);
+#pragma unroll
+    for (int i = 0; i < G; ++i) tab[i] = row[32 * i];
+}
+template <int G = 16, class Ctx>
 AW_HD void pair_subfft_cmac_h(Ctx &ctx, const TileParams &p, int pair, cf *buf, const cf *twa, cf2 (&tab)[16], int lane, int wave,
                               cf (&wacc)[16], bool tab_loaded) {
     const HLane L = hl_make(ctx, buf, twa, lane, wave);
@@ -598,19 +611,38 @@ AW_HD void pair_subfft_cmac_h(Ctx &ctx, const TileParams &p, int pair, cf *buf, 
 #pragma unroll
     for (int j = 0; j < 16; ++j) z[j] = ctx.ld(L.row + L.h + 32 * j);
     sub_fft512h_fwd(ctx, z, L);
-    if (!tab_loaded) load_tab_h(p, pair, wave, lane, tab);
+    if constexpr (G == 16) { if (!tab_loaded) load_tab_h(p, pair, wave, lane, tab); }
+    else load_tab_part_h<G>(p, pair, wave, lane, 0, tab);
     ctx.stamp(22);
     // publish Z in natural column order inside the wave, then multiply-accumulate against the partner bins
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) L.row[L.col + 32 * kb] = z[kb];
     ctx.wave_sync();
+    if constexpr (G == 16) {
 #pragma unroll
-    for (int kb = 0; kb < 16; ++kb) {
-        int idx = L.pidx - 32 * kb;
-        if (kb == 0) idx &= 511;                               // only (row 0, column 0) wraps: 512 -> 0
-        const cf zp = ctx.ld(L.prow + idx);
-        wacc[kb] = cfma(z[kb], tab[kb].a, wacc[kb]);
-        wacc[kb] = cfmac(zp, tab[kb].b, wacc[kb]);
+        for (int kb = 0; kb < 16; ++kb) {
+            int idx = L.pidx - 32 * kb;
+            if (kb == 0) idx &= 511;                               // only (row 0, column 0) wraps: 512 -> 0
+            const cf zp = ctx.ld(L.prow + idx);
+            wacc[kb] = cfma(z[kb], tab[kb].a, wacc[kb]);
+            wacc[kb] = cfmac(zp, tab[kb].b, wacc[kb]);
+        }
+    } else {
+        static_assert(2 * G <= 16, "two parts in flight inside tab[16]");
+#pragma unroll
+        for (int part = 0; part < 16 / G; ++part) {
+            cf2 *cur = tab + G * (part & 1);
+            if (part + 1 < 16 / G) load_tab_part_h<G>(p, pair, wave, lane, part + 1, tab + G * ((part + 1) & 1));
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int kb = G * part + i;
+                int idx = L.pidx - 32 * kb;
+                if (kb == 0) idx &= 511;
+                const cf zp = ctx.ld(L.prow + idx);
+                wacc[kb] = cfma(z[kb], cur[i].a, wacc[kb]);
+                wacc[kb] = cfmac(zp, cur[i].b, wacc[kb]);
+            }
+        }
     }
     ctx.wave_sync();    // partner reads done before this wave reuses its rows as scratch
     ctx.stamp(23);
@@ -798,7 +830,11 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
 #if AW_OLS_H
         cf2 tab[16];
         auto load_tab_ = [&](int pr) { load_tab_h(p, pr, wave, lane, tab); };
-        auto subfft_cmac_ = [&](int pr, cf *bf, bool loaded) { pair_subfft_cmac_h(ctx, p, pr, bf, twa, tab, lane, wave, wacc, loaded); };
+        // tables after the transform in one go (64 VGPRs) or in two parts of eight bins.  Measured per layout (tools/ols2_ab.py WINDOW=8192,
+        // tools/ubench/tile_bench.hip): 13 / 14 channels 22.5 / 21.9 -> 23.9 / 23.2 G frames/s (19 spilled VGPRs either way, fewer live through the
+        // multiply-accumulate), 9 / 10 +-0, 11 / 12 channels 28.5 / 29.2 -> 24.0 / 23.0 (!), 8 channels +-0 (parts of four: -5 %) — seven pairs only.
+        constexpr int kTabG = (kTabEarly0 || kTabEarly1) ? 16 : NP == 7 ? 8 : 16;
+        auto subfft_cmac_ = [&](int pr, cf *bf, bool loaded) { pair_subfft_cmac_h<kTabG>(ctx, p, pr, bf, twa, tab, lane, wave, wacc, loaded); };
 #else
         cf2 tab[2][8];
         auto load_tab_ = [&](int pr) { load_tab(p, pr, wave, lane, tab); };

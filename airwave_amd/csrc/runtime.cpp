@@ -671,9 +671,10 @@ static int lw_fused_crossover_taps(int channels) {
         case 6: return 5500;
         case 7: return 4700;
         case 8: return 5200;
-        case 14: case 15: return 4000;
-        case 16: return 3200;
-        default: return 4900;       // 9 - 13 channels
+        case 13: return 4000;
+        case 14: return 4300;
+        case 15: case 16: return 3200;     // the two-pass layouts (15 channels at 3900 taps: 18.6 against 21.7)
+        default: return 4900;       // 9 - 12 channels
     }
 }
 

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for r in 1 2 3; do for v in tb_h tb_hg tb_te1 tb_te2 tb_te3; do echo -n "$v: "; timeout 60 tools/ubench/$v; done; done
+for r in 1 2 3; do for v in tb_g16 tb_g8 tb_g4 tb14_g16 tb14_g8 tb14_g4; do echo -n "$v: "; timeout 60 tools/ubench/$v; done; done
