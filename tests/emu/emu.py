@@ -40,6 +40,7 @@ def lib():
         _lib.emu_longwin.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
                                      ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
         _lib.emu_fft_small.argtypes = [fp, ctypes.c_int, ctypes.c_int]
+        _lib.emu_sub_fft512h.argtypes = [fp, fp, fp]
         _lib.emu_lw_dft.argtypes = [fp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _lib.emu_eq_process.argtypes = [fp, fp, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_longlong, ctypes.c_double,
                                         ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int]
@@ -111,6 +112,14 @@ def lw_dft(v, inverse=False, odd=False):
     a = np.ascontiguousarray(np.asarray(v, dtype=np.complex64)).view(np.float32).copy()
     assert lib().emu_lw_dft(a.ctypes.data_as(fp), a.size // 2, int(inverse), int(odd)) == 0
     return a.view(np.complex64)
+
+
+def sub_fft512h(rows):
+    """(spectra in natural order, unnormalised inverse of those spectra) of two 512-point rows through the half-wave row transform."""
+    a = np.ascontiguousarray(np.asarray(rows, dtype=np.complex64).reshape(2, 512)).view(np.float32)
+    f = np.zeros_like(a); b = np.zeros_like(a)
+    assert lib().emu_sub_fft512h(a.ctypes.data_as(fp), f.ctypes.data_as(fp), b.ctypes.data_as(fp)) == 0
+    return f.view(np.complex64).reshape(2, 512), b.view(np.complex64).reshape(2, 512)
 
 
 def fft_small(v, inverse=False):

@@ -351,4 +351,40 @@ int emu_eq_process(const float *in, float *out, double *z, int n_streams, long l
     return prep.n_filters;
 }
 
+// One wave's pair of 512-point row transforms in the half-wave form (tile_ols.hpp, sub_fft512h_fwd / _inv): rows = [2][512] complex
+// (interleaved floats); fwd = the spectra in NATURAL bin order [2][512]; back = inverse of those spectra (unnormalised: 512 x rows).
+int emu_sub_fft512h(const float *rows, float *fwd, float *back) {
+    using namespace awk;
+    awh::Twiddles tw;
+    awh::build_twiddles(tw);
+    EmuShared sh;
+    cf *buf = sh.lds.data();
+    cf *twh = buf + 2 * kBufElems;
+    for (int t = 0; t < kThreads; ++t) twh[t] = hl_twiddle(tw.twa.data(), t);
+    const int wave = 3;                                    // rows 3 and 13 of the exchange buffer
+    for (int s = 0; s < 2; ++s)
+        for (int k = 0; k < kSub; ++k) buf[wave_row(wave, s) * kRowStride + k] = mk(rows[(s * kSub + k) * 2], rows[(s * kSub + k) * 2 + 1]);
+    std::vector<std::thread> th;
+    for (int lane = 0; lane < 64; ++lane)
+        th.emplace_back([&, lane] {
+            EmuCtx ctx{wave * 64 + lane, &sh};
+            const HLane L = hl_make(ctx, buf, twh, lane, wave);
+            cf z[16];
+            for (int j = 0; j < 16; ++j) z[j] = ctx.ld(L.row + L.h + 32 * j);
+            sub_fft512h_fwd(ctx, z, L);
+            const int s = lane >> 5;
+            for (int kb = 0; kb < 16; ++kb) {
+                const int k = L.col + 32 * kb;
+                fwd[(s * kSub + k) * 2] = z[kb].x; fwd[(s * kSub + k) * 2 + 1] = z[kb].y;
+            }
+            sub_fft512h_inv(ctx, z, L);
+            for (int j = 0; j < 16; ++j) {
+                const int n = L.h + 32 * j;
+                back[(s * kSub + n) * 2] = z[j].x; back[(s * kSub + n) * 2 + 1] = z[j].y;
+            }
+        });
+    for (auto &t : th) t.join();
+    return 0;
+}
+
 }  // extern "C"
