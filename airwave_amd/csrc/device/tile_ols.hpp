@@ -208,7 +208,7 @@ AW_HD void sub_fft512x2(Ctx &ctx, cf (&a)[2][8], cf *scr0, cf *scr1, const cf *t
 //   twiddle w_32^{h0} on the odd half (h0 = lane & 15), ONE wave-private 16 x 16 LDS transpose (17-element pitch, 272 per group of
 //   16 lanes: conflict-free both ways), radix 16 over h0 -> kb.
 // One LDS exchange per row instead of two (63 LDS instructions per lane and row pair against 94):
-// tools/ubench/fft_core.hip 2.99 -> 2.50 us per pair transform per CU.
+// tools/ubench/fft_core.hip 3.03 -> 2.56 us per pair transform per CU.
 // Bin order: on return a[kb] = X[hl_col(lane) + 32 kb].
 #ifndef AW_OLS_H
 #define AW_OLS_H 1        // 0: the fused 8192-frame tile on the 8 x 8 x 8 row transforms of rounds 1-3

@@ -1,7 +1,9 @@
 // fft_core.hip — cost of ONE 8192-point pair transform of the tile code with no global memory traffic: pass 1 (radix-16 +
 // twiddles + scatter to LDS rows), barrier, per-wave 512-point sub-FFTs of two rows.  One 512-thread workgroup per CU,
 // REPS transforms each (two pairs per barrier interval, like the kernels).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -Iairwave_amd/csrc -Iinclude tools/ubench/fft_core.hip -o tools/ubench/fft_core
+// Both row-transform forms: the 8 x 8 x 8 one of rounds 1-3 (k_core) and the half-wave one of round 4 (k_core16).  Build with the kernels'
+// -fno-slp-vectorize (without it hipcc packs the butterflies into v_pk_* and everything runs 25 % slower):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -fno-slp-vectorize -Iairwave_amd/csrc -Iinclude tools/ubench/fft_core.hip -o tools/ubench/fft_core
 #include "device/tile_ols.hpp"
 #include "device/gpu_ctx.hpp"
 #include "device/tile_lw16.hpp"
@@ -99,14 +101,13 @@ __global__ void __launch_bounds__(kThreads, 4) k_core1(const cf *tw1, const cf *
 namespace awk {
 // The same 512-point row transforms on the 16-point core (tile_ols.hpp, sub_fft512h_fwd): a HALF-wave per row, 16 values per lane.
 template <int VARIANT>
-__global__ void __launch_bounds__(kThreads) k_core16(const cf *tw1, const cf *tw512, const cf *tw32, cf *sink, int reps) {
+__global__ void __launch_bounds__(kThreads) k_core16(const cf *tw1, const cf *twa_g, const cf *, cf *sink, int reps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GpuCtx ctx{reinterpret_cast<cf *>(smem), nullptr};
     const int t = ctx.tid(), lane = ctx.lane(), wave = ctx.wave();
     cf *buf0 = ctx.lds(), *buf1 = buf0 + kBufElems, *twh = buf1 + kBufElems;
     const cf w1 = tw1[t];
-    twh[t] = hl_twiddle(tw512, t);
-    (void)tw32;
+    twh[t] = hl_twiddle(twa_g, t);
     cf x[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) x[j] = mk(0.001f * (t + j), 0.002f * (t - j));
