@@ -27,6 +27,10 @@ SIGNATURES = {
     "aw_context_stream": (_V, [_V]),
     "aw_context_timer_start": (_I32, [_V]),
     "aw_context_timer_stop": (_I32, [_V, c_float_p]),
+    "aw_context_bandwidth_probe": (_I32, [_V, _SZ, _I32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "aw_context_pcie_probe": (_I32, [_V, _SZ, _I32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "aw_host_alloc_pinned": (_I32, [_V, _SZ, c_void_pp]),
+    "aw_host_free_pinned": (_I32, [_V, _V]),
     "aw_device_alloc": (_I32, [_V, _SZ, c_void_pp]),
     "aw_device_free": (_I32, [_V, _V]),
     "aw_memcpy_h2d": (_I32, [_V, _V, _V, _SZ]),
@@ -42,6 +46,7 @@ SIGNATURES = {
     "aw_spatializer_process_host": (_I32, [_V, c_float_p, c_float_p, _I64]),
     "aw_spatializer_process_planar": (_I32, [_V, c_float_p, c_float_p, c_float_p, c_float_p, _I32]),
     "aw_spatializer_reserve": (_I32, [_V, _I64]),
+    "aw_spatializer_reserve_host": (_I32, [_V, _I64]),
     "aw_spatializer_reset": (_I32, [_V]),
     "aw_spatializer_stream_count": (_I32, [_V]),
     "aw_spatializer_channel_count": (_I32, [_V]),
@@ -61,6 +66,7 @@ SIGNATURES = {
     "aw_realtime_destroy": (None, [_V]),
     "aw_realtime_process": (_I32, [_V, c_float_p, c_float_p, c_float_p, c_float_p, _I32]),
     "aw_realtime_reset": (_I32, [_V]),
+    "aw_realtime_info": (_I64, [_V, _I32]),
     "aw_wav_load": (_I32, [_S, c_void_pp]),
     "aw_wav_destroy": (None, [_V]),
     "aw_wav_sample_rate": (_D, [_V]),

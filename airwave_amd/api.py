@@ -104,6 +104,27 @@ class Context:
         _check(self._lib.aw_context_timer_stop(self._h, ctypes.byref(ms)))
         return float(ms.value)
 
+    def bandwidth_probe(self, nbytes: int = 4 << 30, repetitions: int = 3) -> Dict[str, float]:
+        """Measured read-only / write-only / copy rates of this device in GB/s (copy = bytes read + bytes written per second):
+        the ceiling SURVEY.md 8d asks to quote next to the vendor peak."""
+        r, w, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _check(self._lib.aw_context_bandwidth_probe(self._h, nbytes, repetitions, ctypes.byref(r), ctypes.byref(w), ctypes.byref(c)))
+        return {"read": r.value, "write": w.value, "copy": c.value}
+
+    def pcie_probe(self, nbytes: int = 1 << 30, repetitions: int = 2) -> Dict[str, float]:
+        """Page-locked hipMemcpyAsync rates in GB/s: host to device, device to host, and both at once (bytes both ways per second)."""
+        a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _check(self._lib.aw_context_pcie_probe(self._h, nbytes, repetitions, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"h2d": a.value, "d2h": b.value, "duplex": c.value}
+
+    def pinned_empty(self, shape, dtype=np.float32) -> np.ndarray:
+        """A numpy array over page-locked host memory (aw_host_alloc_pinned); freed when the array's base object dies."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = ctypes.c_void_p()
+        _check(self._lib.aw_host_alloc_pinned(self._h, n, ctypes.byref(p)))
+        owner = _PinnedOwner(self, p.value, max(n, 1))
+        return np.asarray(owner)[:n].view(dtype).reshape(shape)
+
     # raw device memory for hosts without torch
     def alloc(self, nbytes: int) -> int:
         p = ctypes.c_void_p()
@@ -123,6 +144,21 @@ class Context:
 
     def synth_fill(self, dptr: int, n_streams: int, frames: int, n_channels: int, seed: int = 0xA17AE, first_stream: int = 0):
         _check(self._lib.aw_synth_fill(self._h, ctypes.c_void_p(dptr), n_streams, frames, n_channels, seed, first_stream))
+
+
+class _PinnedOwner:
+    """Base object of the numpy views over one page-locked allocation (array interface): alive as long as any view is, then frees it."""
+
+    def __init__(self, ctx: "Context", ptr: int, nbytes: int):
+        self._ctx, self._ptr = ctx, ptr
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            if self._ptr and getattr(self._ctx, "_h", None):
+                self._ctx._lib.aw_host_free_pinned(self._ctx._h, ctypes.c_void_p(self._ptr))
+        finally:
+            self._ptr = 0
 
 
 _default_ctx: Optional[Context] = None
@@ -328,7 +364,12 @@ class Spatializer:
         return {"fft": g(0), "hop": g(1), "partitions": g(2), "path": g(3), "history": g(4), "dominant_frames": g(5), "scratch_bytes": g(6),
                 "long_window_rows": g(7),       # long-window kernels ran in the last call on windows of rows x 4096 frames (0: they did not)
                 "long_window_rows_rest": g(8),  # ... and a last, shorter window of this many rows for the remainder (0: one window length)
-                "long_window_table_sets": g(9)} # table sets built so far (one per window length)
+                "long_window_table_sets": g(9), # table sets built so far (one per window length)
+                # the last reserve(): float64 table build on host threads / table upload / scratch pool growth, milliseconds
+                "reserve_tables_ms": g(10) / 1e3, "reserve_upload_ms": g(11) / 1e3, "reserve_scratch_ms": g(12) / 1e3,
+                "device_allocs": g(13),         # device / page-locked allocations made so far on behalf of the context's handles
+                "sync_copies": g(14),           # blocking table uploads likewise
+                "host_chunk_streams": g(15)}    # streams per staged chunk of the last host-entry call (0: one piece)
 
     def process_device(self, in_ptr: int, out_ptr: int, frames: int) -> None:
         _check(self._lib.aw_spatializer_process(self._h, ctypes.c_void_p(in_ptr), ctypes.c_void_p(out_ptr), frames))
@@ -356,6 +397,17 @@ class Spatializer:
     def reserve(self, max_frames: int) -> None:
         """Size every internal device buffer for calls of up to max_frames frames: process never allocates afterwards."""
         _check(self._lib.aw_spatializer_reserve(self._h, int(max_frames)))
+
+    def reserve_host(self, max_frames: int) -> None:
+        """reserve() plus the device-side staging of the host entry (process / process_host_into)."""
+        _check(self._lib.aw_spatializer_reserve_host(self._h, int(max_frames)))
+
+    def process_host_into(self, x: np.ndarray, out: np.ndarray) -> None:
+        """Host entry on caller-owned arrays (e.g. Context.pinned_empty): x [streams][frames][channels], out [streams][frames][2]."""
+        assert x.dtype == np.float32 and out.dtype == np.float32 and x.flags["C_CONTIGUOUS"] and out.flags["C_CONTIGUOUS"]
+        S, F, C = x.shape
+        assert S == self.n_streams and C == self.n_channels and out.shape == (S, F, 2)
+        _check(self._lib.aw_spatializer_process_host(self._h, _fp(x), _fp(out), F))
 
     def reset(self) -> None:
         _check(self._lib.aw_spatializer_reset(self._h))
@@ -452,6 +504,11 @@ class RealtimeAudioProcessor:
 
     def reset(self) -> None:
         _check(self._lib.aw_realtime_reset(self._h))
+
+    def info(self) -> Dict[str, int]:
+        """What the processor holds (all of it allocated in __init__, like RealtimeAudioProcessor.init, :30-62)."""
+        g = lambda i: int(self._lib.aw_realtime_info(self._h, i))
+        return {"host_bytes": g(0), "device_bytes": g(1), "device_allocs": g(2)}
 
 
 class HRIRManager:

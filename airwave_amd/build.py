@@ -28,6 +28,7 @@ SOURCES = [
     "device/lw_split_e.hip",
     "device/ols2_even_kernels.hip",
     "device/eq_kernels.hip",
+    "device/probe_kernels.hip",
     "runtime.cpp",
     "eq_runtime.cpp",
     "host/eq.cpp",
@@ -67,6 +68,20 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _record_head() -> None:
+    """airwave_amd/.build_head = git HEAD (+dirty) when the build runs inside a checkout (provenance.py; the GPU boxes have no .git)."""
+    root = os.path.dirname(HERE)
+    if not os.path.isdir(os.path.join(root, ".git")):
+        return
+    try:
+        head = subprocess.run(["git", "-C", root, "rev-parse", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+        dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "airwave_amd/csrc"], capture_output=True, text=True, check=True).stdout.strip()
+        with open(os.path.join(HERE, ".build_head"), "w") as f:
+            f.write(head + ("+dirty" if dirty else "") + "\n")
+    except Exception:
+        pass
+
+
 def build(force: bool = False, verbose: bool = False, stamps: bool = False, defines=(), suffix: str = "", only=()) -> str:
     """stamps=True builds the DIAGNOSTIC variant (phase time stamps, -DAW_STAMPS=1) as
     libairwave_hip_stamps.so; `defines` + `suffix` build tuning variants (libairwave_hip_<suffix>.so)
@@ -88,7 +103,7 @@ def build(force: bool = False, verbose: bool = False, stamps: bool = False, defi
             if src not in only and os.path.exists(os.path.join(main_obj, o)):
                 shutil.copy2(os.path.join(main_obj, o), os.path.join(OBJ, o))
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    common = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"--offload-arch={ARCH}",
+    common = ["-O3", "-std=c++17", "-fPIC", "-pthread", "-fvisibility=hidden", f"--offload-arch={ARCH}",
               "-Wall", "-Wno-unused-result", "-ffp-contract=fast"] + [f"-D{d}" for d in defines] + os.environ.get("AW_EXTRA_HIPCC_FLAGS", "").split()
     objs, jobs = [], []
     for src in SOURCES:
@@ -105,8 +120,9 @@ def build(force: bool = False, verbose: bool = False, stamps: bool = False, defi
             subprocess.run(cmd, check=True)
         with ThreadPoolExecutor(max_workers=int(os.environ.get("AW_BUILD_JOBS", "8"))) as ex:
             list(ex.map(run, jobs))
+    _record_head()
     if force or _stale(OUT, objs):
-        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs
+        cmd = [hipcc(), "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", "-o", OUT] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -2,6 +2,7 @@
 
 #include <cmath>
 #include <complex>
+#include <atomic>
 #include <thread>
 
 namespace awh {
@@ -158,8 +159,24 @@ static void fft_any(std::vector<cd> &a, const std::vector<cd> &unit_n) {
     }
 }
 
-void build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
+// false: host memory ran out (a worker's or this thread's std::bad_alloc, or no thread could be started) — nothing throws across the
+// C ABI, every worker is joined on every path, and the caller maps the failure to AW_ERR_OUT_OF_MEMORY.
+static void build_lw_tables_impl(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
+                                 const int32_t *right_track, int R, LwTables &out, int rows_form, std::atomic<bool> &failed);
+
+bool build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
                      const int32_t *right_track, int R, LwTables &out, int rows_form) {
+    std::atomic<bool> failed{false};
+    try {
+        build_lw_tables_impl(tracks, n_tracks, taps, n_channels, left_track, right_track, R, out, rows_form, failed);
+    } catch (...) {
+        failed = true;
+    }
+    return !failed.load();
+}
+
+static void build_lw_tables_impl(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
+                                 const int32_t *right_track, int R, LwTables &out, int rows_form, std::atomic<bool> &failed) {
     const int M = awk::kLwM;
     const size_t N = (size_t)R * M;
     const int n_pairs = (n_channels + 1) / 2;
@@ -241,10 +258,21 @@ void build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels
             }
         }
     };
-    std::vector<std::thread> workers;
-    for (int p = 1; p < n_pairs; ++p) workers.emplace_back(build_pair, p);
-    build_pair(0);
-    for (auto &w : workers) w.join();
+    // A worker never lets an exception escape (std::terminate under a C ABI): it records the failure instead.  The guard joins
+    // whatever was started on every path — also when build_pair(0) on this thread, or starting a thread, throws.
+    auto guarded = [&](int p) {
+        try { build_pair(p); } catch (...) { failed = true; }
+    };
+    struct Joiner {
+        std::vector<std::thread> t;
+        ~Joiner() { for (auto &w : t) if (w.joinable()) w.join(); }
+    } workers;
+    workers.t.reserve((size_t)std::max(0, n_pairs - 1));
+    for (int p = 1; p < n_pairs; ++p) {
+        try { workers.t.emplace_back(guarded, p); }
+        catch (...) { guarded(p); }                  // no thread to be had (std::system_error): build that pair here
+    }
+    guarded(0);
 }
 
 }  // namespace awh

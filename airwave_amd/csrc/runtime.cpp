@@ -3,6 +3,7 @@
 #include "runtime.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -16,6 +17,9 @@
 #ifndef AW_DEFAULT_WINDOW
 #define AW_DEFAULT_WINDOW 8192
 #endif
+
+// table sets a spatializer can hold: one per long-window length (kLwRowChoices below); lw_plans reserves this many at create
+static constexpr size_t kLwPlanSlots = 16;
 
 namespace awr {
 
@@ -123,6 +127,14 @@ void aw_context_destroy(aw_context *c) {
     if (c->d_twa) (void)hipFree(c->d_twa);
     if (c->d_twb) (void)hipFree(c->d_twb);
     if (c->d_zeros) (void)hipFree(c->d_zeros);
+    if (c->d_pool) (void)hipFree(c->d_pool);
+    if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
+    if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_h2d[i]) (void)hipEventDestroy(c->ev_h2d[i]);
+        if (c->ev_run[i]) (void)hipEventDestroy(c->ev_run[i]);
+        if (c->ev_d2h[i]) (void)hipEventDestroy(c->ev_d2h[i]);
+    }
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -154,6 +166,78 @@ aw_status aw_context_timer_stop(aw_context *c, float *ms) {
     AW_HIP_TRY(hipEventRecord(c->t1, c->stream));
     AW_HIP_TRY(hipEventSynchronize(c->t1));
     AW_HIP_TRY(hipEventElapsedTime(ms, c->t0, c->t1));
+    return AW_OK;
+}
+
+/* Measured ceilings of the device the context runs on ("confirm on the box and also quote a measured copy-kernel
+ * ceiling"; bench.py's roofline.measured).  Own buffers, freed before returning; blocks; never on a process path. */
+aw_status aw_context_bandwidth_probe(aw_context *c, size_t bytes, int32_t repetitions, double *read_gbs, double *write_gbs, double *copy_gbs) {
+    if (!c || !read_gbs || !write_gbs || !copy_gbs) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (bytes < ((size_t)64 << 20) || repetitions < 1) return fail(AW_ERR_INVALID_ARGUMENT, "probe needs >= 64 MiB and >= 1 repetition");
+    AW_HIP_TRY(hipSetDevice(c->device));
+    void *a = nullptr, *b = nullptr; float *sink = nullptr;
+    hipError_t e = hipMalloc(&a, bytes);
+    if (e == hipSuccess) e = hipMalloc(&b, bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&sink), 64);
+    // the source holds pseudo-random samples, not zeros (all-zero data draws less power and can read faster than real data does)
+    if (e == hipSuccess) e = awk::launch_synth_fill(reinterpret_cast<float *>(a), 1, (long long)(bytes / sizeof(float)), 0xA17AEull, 0, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b, 0, bytes, c->stream);
+    double best[3] = {0.0, 0.0, 0.0};
+    for (int what = 0; what < 3 && e == hipSuccess; ++what)
+        for (int nt = 0; nt < 2 && e == hipSuccess; ++nt) {
+            size_t moved = 0;
+            e = awk::launch_bw_probe(what, nt != 0, a, b, bytes, c->cfg.cus, sink, c->stream, &moved);       // warm-up (clocks, TLB)
+            for (int r = 0; r < repetitions && e == hipSuccess; ++r) {
+                e = hipEventRecord(c->t0, c->stream);
+                if (e == hipSuccess) e = awk::launch_bw_probe(what, nt != 0, a, b, bytes, c->cfg.cus, sink, c->stream, &moved);
+                if (e == hipSuccess) e = hipEventRecord(c->t1, c->stream);
+                if (e == hipSuccess) e = hipEventSynchronize(c->t1);
+                float ms = 0.f;
+                if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->t0, c->t1);
+                if (e == hipSuccess && ms > 0.f) best[what] = std::max(best[what], (double)moved / (ms * 1e-3) / 1e9);
+            }
+        }
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (sink) (void)hipFree(sink);
+    if (e != hipSuccess) return awr::hip_fail(e, "bandwidth probe");
+    *read_gbs = best[0]; *write_gbs = best[1]; *copy_gbs = best[2];
+    return AW_OK;
+}
+
+/* Host link: page-locked host memory to the device and back with hipMemcpyAsync, each way alone and both ways at once (two streams).
+ * The yardstick of the host entry's PCIe-inclusive rate (bench.py's secondary_end_to_end). */
+aw_status aw_context_pcie_probe(aw_context *c, size_t bytes, int32_t repetitions, double *h2d_gbs, double *d2h_gbs, double *duplex_gbs) {
+    if (!c || !h2d_gbs || !d2h_gbs || !duplex_gbs) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (bytes < ((size_t)16 << 20) || repetitions < 1) return fail(AW_ERR_INVALID_ARGUMENT, "probe needs >= 16 MiB and >= 1 repetition");
+    AW_HIP_TRY(hipSetDevice(c->device));
+    void *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
+    hipStream_t s2 = nullptr;
+    hipError_t e = hipHostMalloc(&h_in, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(&h_out, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&d_in, bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_out, bytes);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+    if (e == hipSuccess) { std::memset(h_in, 0, bytes); std::memset(h_out, 0, bytes); e = hipMemsetAsync(d_out, 0, bytes, c->stream); }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    double best[3] = {0.0, 0.0, 0.0};
+    for (int what = 0; what < 3 && e == hipSuccess; ++what)
+        for (int r = 0; r <= repetitions && e == hipSuccess; ++r) {          // (r = 0: warm-up)
+            const auto t0 = std::chrono::steady_clock::now();
+            if (what != 1) e = hipMemcpyAsync(d_in, h_in, bytes, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess && what != 0) e = hipMemcpyAsync(h_out, d_out, bytes, hipMemcpyDeviceToHost, what == 2 ? s2 : c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess && what == 2) e = hipStreamSynchronize(s2);
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (r > 0 && sec > 0.0) best[what] = std::max(best[what], (double)bytes * (what == 2 ? 2.0 : 1.0) / sec / 1e9);
+        }
+    if (s2) (void)hipStreamDestroy(s2);
+    if (h_in) (void)hipHostFree(h_in);
+    if (h_out) (void)hipHostFree(h_out);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return awr::hip_fail(e, "pcie probe");
+    *h2d_gbs = best[0]; *d2h_gbs = best[1]; *duplex_gbs = best[2];
     return AW_OK;
 }
 
@@ -322,7 +406,7 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
     }
     // Long calls may run on the long-window kernels (device/tile_lw.hpp) whatever the path above — chosen per call, see lw_choose();
     // they use the same history buffer.  AW_LW: 0 never, 32/64/128 force that window, unset = the measured policy.
-    sp->lw_plans.reserve(16);                                                            // one entry per window length: pointers into it stay valid
+    sp->lw_plans.reserve(kLwPlanSlots);                                                  // one entry per window length: pointers into it stay valid (static_assert at kLwRowChoices)
     if (const char *e = getenv("AW_LW")) sp->lw_mode = atoi(e);
     if (n_in > 16) sp->lw_mode = 0;                                                      // up to eight channel pairs
     // scratch budget per stream chunk: of the partitioned kernels and of the long-window ones, which also serve path-0 layouts
@@ -375,7 +459,6 @@ void aw_spatializer_destroy(aw_spatializer *sp) {
     if (sp->d_tab) (void)hipFree(sp->d_tab);
     for (int i = 0; i < 2; ++i)
         if (sp->d_hist[i]) (void)hipFree(sp->d_hist[i]);
-    if (sp->d_spec) (void)hipFree(sp->d_spec);
     if (sp->d_tail) (void)hipFree(sp->d_tail);
     for (auto &pl : sp->lw_plans) {
         if (pl.d_tab) (void)hipFree(pl.d_tab);
@@ -412,7 +495,13 @@ int64_t aw_spatializer_info(const aw_spatializer *sp, int32_t what) {
         case 7: return sp->last_lw_R;         // long-window path: rows R of the last call's windows (N = R x 4096); 0 = the partitioned kernels ran
         case 8: return sp->last_lw_R2;        // rows of the last call's remainder window when it ran as two groups of windows (0: one group)
         case 9: return (int64_t)sp->lw_plans.size();   // long-window table sets built so far (one per window length; reserve builds those of its plan)
-        case 6: return (int64_t)(sp->spec_capacity * sizeof(awk::cf) + (sp->stage_in_cap + sp->stage_out_cap) * sizeof(float));   // grow-only device buffers, bytes
+        case 6: return (int64_t)(sp->ctx->pool_capacity * sizeof(awk::cf) + (sp->stage_in_cap + sp->stage_out_cap) * sizeof(float));   // grow-only device buffers, bytes (the context's scratch pool + this handle's staging)
+        case 10: return sp->reserve_tables_us;    // last aw_spatializer_reserve: float64 table build on host threads, microseconds
+        case 11: return sp->reserve_upload_us;    //   table upload (hipMalloc + hipMemcpy)
+        case 12: return sp->reserve_scratch_us;   //   scratch pool growth (hipMalloc)
+        case 13: return sp->ctx->device_allocs;   // device / pinned allocations made so far on behalf of this context's handles
+        case 14: return sp->ctx->sync_copies;     // blocking host-to-device table uploads likewise
+        case 15: return sp->host_chunk_streams;   // streams per staged chunk of the host entry (0: the whole batch in one piece)
         default: return -1;
     }
 }
@@ -523,9 +612,11 @@ static void sp_fill_cfg(const aw_spatializer *sp, awk::TileParams &p) {
     p.debug_occupancy = c.debug_occupancy;
 }
 
-static aw_status sp_process_fused(aw_spatializer *sp, const float *in, float *out, int64_t frames) {
+// Every sp_process_* below runs ONE call's kernels for the streams [s_base, s_base + ns_total) of the spatializer; `in` / `out` point at
+// stream s_base's frames (the caller's whole batch with s_base = 0, or one staged chunk of the host-entry pipeline).
+static aw_status sp_process_fused(aw_spatializer *sp, int s_base, int ns_total, const float *in, float *out, int64_t frames) {
     awk::TileParams p{};
-    p.in = in; p.out = out; p.hist = sp->d_hist[sp->hist_cur];
+    p.in = in; p.out = out; p.hist = sp->d_hist[sp->hist_cur] + (size_t)s_base * sp->hist_len * sp->n_channels;
     p.tab = sp->d_tab; p.tw1 = sp->ctx->d_tw1; p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb; p.zeros = sp->ctx->d_zeros;
     p.frames = frames; p.n_channels = sp->n_channels; p.n_pairs = sp->n_pairs;
     p.hop = sp->hop; p.hist_len = sp->hist_len;
@@ -535,12 +626,13 @@ static aw_status sp_process_fused(aw_spatializer *sp, const float *in, float *ou
     sp_fill_cfg(sp, p);
 #if defined(AW_STAMPS) && AW_STAMPS
     {
-        const long long nwg = (long long)sp->n_streams * p.tiles_per_stream;
+        const long long nwg = (long long)ns_total * p.tiles_per_stream;
         const size_t need = (size_t)nwg * awk::kStamps;
         if (sp->dbg_cap < need) {
             if (sp->d_dbg) AW_HIP_TRY(hipFree(sp->d_dbg));
             sp->d_dbg = nullptr; sp->dbg_cap = 0;
             AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sp->d_dbg), need * sizeof(unsigned long long)));
+            sp->ctx->device_allocs += 1;
             sp->dbg_cap = need;
         }
         AW_HIP_TRY(hipMemsetAsync(sp->d_dbg, 0, need * sizeof(unsigned long long), sp->ctx->stream));
@@ -551,10 +643,10 @@ static aw_status sp_process_fused(aw_spatializer *sp, const float *in, float *ou
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (sp->profiling) { e0 = sp_get_event(sp); e1 = sp_get_event(sp); }
     long long dom_tiles = 0;
-    if (sp->fused2) AW_HIP_TRY(awk::launch_fused_ols2(p, sp->n_streams, sp->ctx->stream, e0, e1, &dom_tiles));
-    else AW_HIP_TRY(awk::launch_fused_ols(p, sp->n_streams, sp->ctx->stream, e0, e1, &dom_tiles));
+    if (sp->fused2) AW_HIP_TRY(awk::launch_fused_ols2(p, ns_total, sp->ctx->stream, e0, e1, &dom_tiles));
+    else AW_HIP_TRY(awk::launch_fused_ols(p, ns_total, sp->ctx->stream, e0, e1, &dom_tiles));
     // output frames the timed launch produced (tiles x hop, the last tile of a stream may be short)
-    sp->dominant_frames = std::min<long long>(dom_tiles * (long long)sp->hop, (long long)sp->n_streams * frames);
+    sp->dominant_frames = std::min<long long>(dom_tiles * (long long)sp->hop, (long long)ns_total * frames);
     if (sp->profiling) sp->pending.emplace_back(e0, e1);
     return AW_OK;
 }
@@ -594,33 +686,40 @@ static size_t part_budget(aw_spatializer *sp) {
     return sp->scratch_budget;
 }
 
+// The scratch is the CONTEXT's pool (runtime.hpp): grow-only, the largest need of any spatializer created on the context.
 static aw_status part_ensure_scratch(aw_spatializer *sp, size_t need) {
-    if (sp->spec_capacity >= need) return AW_OK;
-    if (sp->d_spec) AW_HIP_TRY(hipFree(sp->d_spec));
-    sp->d_spec = nullptr; sp->spec_capacity = 0;
-    AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sp->d_spec), need * sizeof(awk::cf)));
-    sp->spec_capacity = need;
+    aw_context *c = sp->ctx;
+    if (c->pool_capacity >= need) return AW_OK;
+    // (hipFree waits for the device: launches of other handles that still read the old buffer have finished)
+    if (c->d_pool) AW_HIP_TRY(hipFree(c->d_pool));
+    c->d_pool = nullptr; c->pool_capacity = 0;
+    AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_pool), need * sizeof(awk::cf)));
+    c->device_allocs += 1;
+    c->pool_capacity = need;
     return AW_OK;
 }
+// the buffer a call inside what aw_spatializer_reserve() sized may count on (its stream chunk is clamped to it: never a reallocation)
+static size_t sp_held_scratch(const aw_spatializer *sp, int64_t frames) { return frames <= sp->reserved_frames ? sp->ctx->pool_capacity : 0; }
 
-static aw_status sp_process_partitioned(aw_spatializer *sp, const float *in, float *out, int64_t frames) {
+static aw_status sp_process_partitioned(aw_spatializer *sp, int s_base, int ns_total, const float *in, float *out, int64_t frames) {
     const int N = awk::kN, B = sp->hop, P = sp->partitions;
-    const PartPlan pl = part_plan(sp, frames, part_budget(sp), frames <= sp->reserved_frames ? sp->spec_capacity : 0);
+    const PartPlan pl = part_plan(sp, frames, part_budget(sp), sp_held_scratch(sp, frames));
     const int n_blocks = pl.n_blocks;
     const long long chunk = pl.chunk;
     aw_status st = part_ensure_scratch(sp, pl.need);
     if (st != AW_OK) return st;
+    awk::cf *const d_spec = sp->ctx->d_pool;
     sp->dominant_frames = 0;
-    for (long long s0 = 0; s0 < sp->n_streams; s0 += chunk) {
-        const int ns = (int)std::min<long long>(chunk, sp->n_streams - s0);
+    for (long long s0 = 0; s0 < ns_total; s0 += chunk) {
+        const int ns = (int)std::min<long long>(chunk, ns_total - s0);
         awk::TileParams p{};
         p.in = in + (size_t)s0 * frames * sp->n_channels;
         p.out = out + (size_t)s0 * frames * 2;
-        p.hist = sp->d_hist[sp->hist_cur] + (size_t)s0 * sp->hist_len * sp->n_channels;
+        p.hist = sp->d_hist[sp->hist_cur] + (size_t)(s_base + s0) * sp->hist_len * sp->n_channels;
         p.tab = sp->d_tab; p.tw1 = sp->ctx->d_tw1; p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb; p.zeros = sp->ctx->d_zeros;
         p.frames = frames; p.n_channels = sp->n_channels; p.n_pairs = sp->n_pairs;
         p.hop = B; p.hist_len = sp->hist_len; p.tiles_per_stream = n_blocks;
-        p.spec = sp->d_spec; p.wspec = sp->d_spec + pl.per_stream * (size_t)chunk;
+        p.spec = d_spec; p.wspec = d_spec + pl.per_stream * (size_t)chunk;
         p.partitions = P; p.n_blocks = n_blocks; p.first_valid = N - B;
         p.stagger = 0; p.dbg = nullptr;
         sp_fill_cfg(sp, p);
@@ -686,6 +785,7 @@ struct LwGroup { int R; int n_windows; long long frame0, frame_end; };
 struct LwCallPlan { int n_groups; LwGroup g[2]; double cost; };
 
 static const int kLwRowChoices[] = {32, 40, 48, 56, 64, 72, 80, 96, 112, 120, 128};
+static_assert(sizeof(kLwRowChoices) / sizeof(kLwRowChoices[0]) <= kLwPlanSlots, "aw_spatializer::lw_plans holds one table set per window length and never reallocates (sp_process_longwin keeps pointers into it)");
 
 static LwCallPlan lw_choose(const aw_spatializer *sp, int64_t frames, bool for_reserve = false) {
     LwCallPlan none{};
@@ -756,12 +856,17 @@ static aw_status lw_get_plan(aw_spatializer *sp, int R, const aw_spatializer::Lw
         if (pl.R == R) { *out = &pl; return AW_OK; }
     awh::LwTables t;
     const int form = sp->ctx->cfg.lw_rows_form;          // which rows kernel the tables are laid out for (read once per context)
-    awh::build_lw_tables(sp->lw_tracks.data(), sp->lw_n_tracks, sp->taps, sp->n_channels, sp->lw_left.data(), sp->lw_right.data(), R, t, form);
+    const auto t_build = std::chrono::steady_clock::now();
+    if (!awh::build_lw_tables(sp->lw_tracks.data(), sp->lw_n_tracks, sp->taps, sp->n_channels, sp->lw_left.data(), sp->lw_right.data(), R, t, form))
+        return fail(AW_ERR_OUT_OF_MEMORY, "long-window tables: host memory");      // (the caller falls back to the kernels that have always served the spatializer)
+    const auto t_up = std::chrono::steady_clock::now();
+    sp->reserve_tables_us += std::chrono::duration_cast<std::chrono::microseconds>(t_up - t_build).count();
     aw_spatializer::LwPlan pl;
     pl.R = R;
     auto up = [&](const void *src, size_t bytes, void **d) -> hipError_t {
         hipError_t r = hipMalloc(d, bytes);
         if (r != hipSuccess) return r;
+        sp->ctx->device_allocs += 1; sp->ctx->sync_copies += 1;
         return hipMemcpy(*d, src, bytes, hipMemcpyHostToDevice);
     };
     hipError_t e = hipSuccess;
@@ -781,6 +886,7 @@ static aw_status lw_get_plan(aw_spatializer *sp, int R, const aw_spatializer::Lw
             if (d) (void)hipFree(d);
         return awr::hip_fail(e, "long-window tables");
     }
+    sp->reserve_upload_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_up).count();
     sp->lw_plans.push_back(pl);
     *out = &sp->lw_plans.back();
     return AW_OK;
@@ -816,19 +922,20 @@ static LwScratch lw_plan_scratch(const aw_spatializer *sp, const LwCallPlan &pla
     return all;
 }
 
-static aw_status sp_process_longwin(aw_spatializer *sp, const LwCallPlan &call, const float *in, float *out, int64_t frames) {
+static aw_status sp_process_longwin(aw_spatializer *sp, const LwCallPlan &call, int s_base, int ns_total, const float *in, float *out, int64_t frames) {
     const aw_spatializer::LwPlan *tables[2] = {nullptr, nullptr};
     for (int i = 0; i < call.n_groups; ++i) {
         aw_status st = lw_get_plan(sp, call.g[i].R, &tables[i]);
         if (st != AW_OK) return st;
     }
     LwScratch per_group[2];
-    const LwScratch sc = lw_plan_scratch(sp, call, part_budget(sp), frames <= sp->reserved_frames ? sp->spec_capacity : 0, per_group);
+    const LwScratch sc = lw_plan_scratch(sp, call, part_budget(sp), sp_held_scratch(sp, frames), per_group);
     aw_status st = part_ensure_scratch(sp, sc.need);
     if (st != AW_OK) return st;
+    awk::cf *const d_spec = sp->ctx->d_pool;
     sp->dominant_frames = 0;
-    for (long long s0 = 0; s0 < sp->n_streams; s0 += sc.chunk) {
-        const int ns = (int)std::min<long long>(sc.chunk, sp->n_streams - s0);
+    for (long long s0 = 0; s0 < ns_total; s0 += sc.chunk) {
+        const int ns = (int)std::min<long long>(sc.chunk, ns_total - s0);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (sp->profiling) {
             e0 = sp_get_event(sp); e1 = sp_get_event(sp);
@@ -846,16 +953,16 @@ static aw_status sp_process_longwin(aw_spatializer *sp, const LwCallPlan &call, 
             awk::LwParams p{};
             p.in = in + (size_t)s0 * frames * sp->n_channels;
             p.out = out + (size_t)s0 * frames * 2;
-            p.hist = sp->d_hist[sp->hist_cur] + (size_t)s0 * sp->hist_len * sp->n_channels;
+            p.hist = sp->d_hist[sp->hist_cur] + (size_t)(s_base + s0) * sp->hist_len * sp->n_channels;
             // the tail carry rides along in the split kernel of the LAST group: its last window spans the last hist_len frames of the call
-            p.hist_out = gi == call.n_groups - 1 ? sp->d_hist[sp->hist_cur ^ 1] + (size_t)s0 * sp->hist_len * sp->n_channels : nullptr;
+            p.hist_out = gi == call.n_groups - 1 ? sp->d_hist[sp->hist_cur ^ 1] + (size_t)(s_base + s0) * sp->hist_len * sp->n_channels : nullptr;
             p.zeros = sp->ctx->d_zeros;
             p.frames = frames; p.frame0 = g.frame0; p.frame_end = g.frame_end;
             p.n_channels = sp->n_channels; p.n_pairs = (sp->n_channels + 1) / 2; p.real_last = sp->n_channels & 1;
             p.hist_len = sp->hist_len; p.hop = (int)(N - sp->hist_len); p.n_windows = g.n_windows;
             p.R = g.R; p.N = (int)N;
-            p.spec = sp->d_spec; p.spec_per_sw = per_group[gi].spec_per_sw;
-            p.wrows = sp->d_spec + (size_t)sc.chunk * g.n_windows * per_group[gi].spec_per_sw;
+            p.spec = d_spec; p.spec_per_sw = per_group[gi].spec_per_sw;
+            p.wrows = d_spec + (size_t)sc.chunk * g.n_windows * per_group[gi].spec_per_sw;
             p.tab = plan->d_tab; p.tw_coarse = plan->d_coarse; p.tw_fine = plan->d_fine; p.tw_step = plan->d_step; p.tw_r = plan->d_tw_r; p.tw1m = plan->d_tw1m;
             p.twa = sp->ctx->d_twa; p.twb = sp->ctx->d_twb;
             p.persistent_wgs = sp->ctx->cfg.persistent_wgs;
@@ -876,7 +983,33 @@ static aw_status sp_process_longwin(aw_spatializer *sp, const LwCallPlan &call, 
     return AW_OK;
 }
 
-static aw_status sp_grow(float **buf, size_t *cap, size_t need);
+static aw_status sp_grow(aw_spatializer *sp, float **buf, size_t *cap, size_t need) {
+    if (*cap >= need) return AW_OK;
+    if (*buf) AW_HIP_TRY(hipFree(*buf));
+    *buf = nullptr; *cap = 0;
+    AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(buf), need * sizeof(float)));
+    sp->ctx->device_allocs += 1;
+    *cap = need;
+    return AW_OK;
+}
+
+// The longest call of at most max_frames frames that the policy (lw_choose with every window length available) leaves to the partitioned
+// kernels (0: none; a path-0 spatializer never runs them).  A reserved spatializer only has the window lengths of its reserve() plan, so a
+// call well short of max_frames may still come to the partitioned kernels beyond this length: it then runs in stream chunks clamped to the
+// pool (part_plan), correct and a little slower — what reserve() buys is no allocation, and the full rate at the length it was asked for.  Scanned in steps of whole blocks; with more than 2048
+// candidate lengths the scan strides and answers one stride longer, i.e. never too short.
+static int64_t part_longest_call(const aw_spatializer *sp, int64_t max_frames) {
+    if (sp->path != 1) return 0;
+    const int64_t B = sp->hop, n_blocks = (max_frames + B - 1) / B;
+    const int64_t stride = std::max<int64_t>(1, n_blocks / 2048);
+    int64_t longest = 0;
+    for (int64_t nb = 1;; nb += stride) {
+        const int64_t f = std::min<int64_t>(std::min(nb, n_blocks) * B, max_frames);
+        if (!lw_choose(sp, f, true).n_groups) longest = std::min<int64_t>(f + (stride - 1) * B, max_frames);
+        if (nb >= n_blocks) break;
+    }
+    return longest;
+}
 
 // Sizes every grow-only device buffer for calls of up to max_frames frames, so that the process entries never
 // allocate afterwards ("process must not allocate"; creation may block).
@@ -884,45 +1017,60 @@ aw_status aw_spatializer_reserve(aw_spatializer *sp, int64_t max_frames) {
     if (!sp) return fail(AW_ERR_INVALID_ARGUMENT, "sp is NULL");
     if (max_frames <= 0) return fail(AW_ERR_INVALID_ARGUMENT, "max_frames must be positive");
     AW_HIP_TRY(hipSetDevice(sp->ctx->device));
+    std::lock_guard<std::mutex> lk(sp->ctx->launch_mu);
+    sp->reserve_tables_us = sp->reserve_upload_us = sp->reserve_scratch_us = 0;
     const LwCallPlan lw_res = lw_choose(sp, max_frames, true);
     if (sp->path == 1 || lw_res.n_groups) {
-        // shorter calls than max_frames may run on the partitioned kernels or on a smaller window: size for both kernel sets
-        size_t need = 0;
-        if (sp->path == 1) need = part_plan(sp, max_frames, part_budget(sp)).need;
         for (int i = 0; i < lw_res.n_groups; ++i) {
             const aw_spatializer::LwPlan *plan = nullptr;
             aw_status st = lw_get_plan(sp, lw_res.g[i].R, &plan);
             if (st != AW_OK) return st;
         }
+        // From here on a call of up to max_frames frames chooses only among the window lengths whose tables exist (lw_choose).
+        const int64_t reserved_before = sp->reserved_frames;
+        sp->reserved_frames = std::max<int64_t>(sp->reserved_frames, max_frames);
+        size_t need = 0;
         if (lw_res.n_groups) {
             LwScratch per_group[2];
-            need = std::max(need, lw_plan_scratch(sp, lw_res, part_budget(sp), 0, per_group).need);
+            need = lw_plan_scratch(sp, lw_res, part_budget(sp), 0, per_group).need;
         }
+        if (sp->path == 1) {
+            // Shorter calls may still run on the partitioned kernels: size for the longest call lw_choose() leaves to them (cfg 3: 45 056
+            // of 480 000 frames, 4 GB — round 4 sized for max_frames on BOTH kernel sets: 41.5 GB where the long-window kernels need 19),
+            // and for ONE stream of max_frames whatever the policy says (a call inside the reserved size clamps its stream chunk to the
+            // buffer that is there, part_plan / lw_scratch: it never reallocates).
+            const int64_t longest = part_longest_call(sp, sp->reserved_frames);
+            if (longest > 0) need = std::max(need, part_plan(sp, longest, part_budget(sp)).need);
+            const PartPlan one = part_plan(sp, sp->reserved_frames, part_budget(sp));
+            need = std::max(need, one.per_stream + one.per_stream_w);
+        }
+        const auto t0 = std::chrono::steady_clock::now();
         aw_status st = part_ensure_scratch(sp, need);
-        if (st != AW_OK) return st;
+        if (st == AW_OK) {
+            const hipError_t es = hipStreamSynchronize(sp->ctx->stream);
+            if (es != hipSuccess) st = awr::hip_fail(es, "hipStreamSynchronize (reserve)");
+        }
+        sp->reserve_scratch_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (st != AW_OK) { sp->reserved_frames = reserved_before; return st; }
+        sp->reserved_pool = std::max(sp->reserved_pool, need);
     }
     if (sp->n_streams == 1) {       // plug-in shaped use (host / planar entries): their staging buffers too
         const size_t n = (size_t)max_frames * std::max(sp->n_channels, 4);
-        aw_status st = sp_grow(&sp->d_stage_in, &sp->stage_in_cap, n);
-        if (st == AW_OK) st = sp_grow(&sp->d_stage_out, &sp->stage_out_cap, (size_t)max_frames * 4);
+        aw_status st = sp_grow(sp, &sp->d_stage_in, &sp->stage_in_cap, n);
+        if (st == AW_OK) st = sp_grow(sp, &sp->d_stage_out, &sp->stage_out_cap, (size_t)max_frames * 4);
         if (st != AW_OK) return st;
     }
     sp->reserved_frames = std::max<int64_t>(sp->reserved_frames, max_frames);
     return AW_OK;
 }
 
-aw_status aw_spatializer_process(aw_spatializer *sp, const float *in, float *out, int64_t frames) {
-    if (!sp || !in || !out) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (frames <= 0) return frames == 0 ? AW_OK : fail(AW_ERR_INVALID_ARGUMENT, "frames must be >= 0");
-    AW_HIP_TRY(hipSetDevice(sp->ctx->device));
+// One call's launches for the streams [s_base, s_base + ns) (`in` / `out` at stream s_base), history carry included; the caller holds
+// the context's launch lock and flips hist_cur once every stream of the call has been through here.
+static aw_status sp_run_streams(aw_spatializer *sp, const LwCallPlan &lw, int s_base, int ns, const float *in, float *out, int64_t frames) {
     aw_status st = AW_OK;
-    const LwCallPlan lw = lw_choose(sp, frames);
-    const int lw_R = lw.n_groups ? lw.g[0].R : 0;
-    sp->last_lw_R = lw_R;
-    sp->last_lw_R2 = lw.n_groups > 1 ? lw.g[1].R : 0;
     bool lw_ran = false;
-    if (lw_R) {
-        st = sp_process_longwin(sp, lw, in, out, frames);
+    if (lw.n_groups && sp->last_lw_R) {
+        st = sp_process_longwin(sp, lw, s_base, ns, in, out, frames);
         lw_ran = st == AW_OK;
         if (st == AW_ERR_OUT_OF_MEMORY) {
             // the long-window kernels are an optimisation: without memory for their tables or scratch the call takes the kernels
@@ -932,43 +1080,146 @@ aw_status aw_spatializer_process(aw_spatializer *sp, const float *in, float *out
             st = AW_OK;
         }
     }
-    if (st == AW_OK && !lw_ran) st = sp->path == 0 ? sp_process_fused(sp, in, out, frames) : sp_process_partitioned(sp, in, out, frames);
+    if (st == AW_OK && !lw_ran) st = sp->path == 0 ? sp_process_fused(sp, s_base, ns, in, out, frames) : sp_process_partitioned(sp, s_base, ns, in, out, frames);
     if (st != AW_OK) return st;
     // carry the convolution tail: next call's history = last hist_len frames of (history ++ input)
     if (!lw_ran) {    // (the long-window split kernel has written it on the way)
-        float *h_old = sp->d_hist[sp->hist_cur], *h_new = sp->d_hist[sp->hist_cur ^ 1];
+        const size_t off = (size_t)s_base * sp->hist_len * sp->n_channels;
+        float *h_old = sp->d_hist[sp->hist_cur] + off, *h_new = sp->d_hist[sp->hist_cur ^ 1] + off;
         SpStageTimer tm(sp);
         if (sp->profiling) tm.begin();
-        AW_HIP_TRY(awk::launch_hist_update(in, h_old, h_new, frames, sp->n_channels, sp->hist_len, sp->n_streams,
-                                           sp->ctx->stream));
+        AW_HIP_TRY(awk::launch_hist_update(in, h_old, h_new, frames, sp->n_channels, sp->hist_len, ns, sp->ctx->stream));
         if (sp->profiling) tm.end("aw_hist_update_kernel");
     }
+    return AW_OK;
+}
+
+static LwCallPlan sp_begin_call(aw_spatializer *sp, int64_t frames) {
+    const LwCallPlan lw = lw_choose(sp, frames);
+    sp->last_lw_R = lw.n_groups ? lw.g[0].R : 0;
+    sp->last_lw_R2 = lw.n_groups > 1 ? lw.g[1].R : 0;
+    return lw;
+}
+
+aw_status aw_spatializer_process(aw_spatializer *sp, const float *in, float *out, int64_t frames) {
+    if (!sp || !in || !out) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (frames <= 0) return frames == 0 ? AW_OK : fail(AW_ERR_INVALID_ARGUMENT, "frames must be >= 0");
+    AW_HIP_TRY(hipSetDevice(sp->ctx->device));
+    std::lock_guard<std::mutex> lk(sp->ctx->launch_mu);       // this call's launches stay together on the stream (the scratch pool is the context's)
+    const LwCallPlan lw = sp_begin_call(sp, frames);
+    aw_status st = sp_run_streams(sp, lw, 0, sp->n_streams, in, out, frames);
+    if (st != AW_OK) return st;
     sp->hist_cur ^= 1;
     return AW_OK;
 }
 
-static aw_status sp_grow(float **buf, size_t *cap, size_t need) {
-    if (*cap >= need) return AW_OK;
-    if (*buf) AW_HIP_TRY(hipFree(*buf));
-    *buf = nullptr; *cap = 0;
-    AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(buf), need * sizeof(float)));
-    *cap = need;
+/* ---- host entry ------------------------------------------------------------------------------------
+ * The reference's callers hand over host buffers (AudioPipeline.swift:3-11: the four planar pointers of a render callback); an offline
+ * batch host does too.  A multi-stream batch crosses PCIe in CHUNKS OF STREAMS (streams are independent: state is per stream), double
+ * buffered on three HIP streams: H2D of chunk k+1 || kernels of chunk k || D2H of chunk k-1.  Page-locked caller buffers
+ * (aw_host_alloc_pinned, hipHostMalloc, hipHostRegister) are read and written by the DMA engines directly; pageable ones go through
+ * the HIP runtime's own staging (hipMemcpyAsync), still chunked.  aw_spatializer_reserve_host() sizes the device-side chunk buffers
+ * ahead of time; without it they grow on the first call. */
+static int64_t host_chunk_streams(const aw_spatializer *sp, int64_t frames) {
+    const size_t chunk_bytes = (size_t)sp->ctx->cfg.host_chunk_mb << 20;        // input bytes per staged chunk (LaunchCfg: read once per context)
+    const size_t per_stream = (size_t)frames * sp->n_channels * sizeof(float);
+    if (sp->n_streams < 4 || per_stream * sp->n_streams < 2 * chunk_bytes) return 0;           // small batches: one piece, serial (plug-in shaped calls)
+    int64_t cs = (int64_t)std::max<size_t>(1, chunk_bytes / per_stream);
+    cs = std::max<int64_t>(cs, 2);
+    return std::min<int64_t>(cs, (sp->n_streams + 1) / 2);
+}
+
+static aw_status host_pipeline_objects(aw_context *c) {
+    if (c->s_h2d) return AW_OK;
+    AW_HIP_TRY(hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
+    AW_HIP_TRY(hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        AW_HIP_TRY(hipEventCreateWithFlags(&c->ev_h2d[i], hipEventDisableTiming));
+        AW_HIP_TRY(hipEventCreateWithFlags(&c->ev_run[i], hipEventDisableTiming));
+        AW_HIP_TRY(hipEventCreateWithFlags(&c->ev_d2h[i], hipEventDisableTiming));
+    }
     return AW_OK;
+}
+
+static aw_status host_stage_buffers(aw_spatializer *sp, int64_t frames, int64_t cs) {
+    const size_t streams = cs > 0 ? 2 * (size_t)cs : (size_t)sp->n_streams;           // two chunks in flight each way, or the whole batch
+    aw_status st = sp_grow(sp, &sp->d_stage_in, &sp->stage_in_cap, streams * frames * sp->n_channels);
+    if (st == AW_OK) st = sp_grow(sp, &sp->d_stage_out, &sp->stage_out_cap, streams * frames * 2);
+    return st;
+}
+
+aw_status aw_spatializer_reserve_host(aw_spatializer *sp, int64_t max_frames) {
+    aw_status st = aw_spatializer_reserve(sp, max_frames);
+    if (st != AW_OK) return st;
+    std::lock_guard<std::mutex> lk(sp->ctx->launch_mu);
+    const int64_t cs = host_chunk_streams(sp, max_frames);
+    if (cs > 0) { st = host_pipeline_objects(sp->ctx); if (st != AW_OK) return st; }
+    st = host_stage_buffers(sp, max_frames, cs);
+    if (st == AW_OK) { sp->host_chunk_streams = cs; sp->host_chunk_reserved = cs; sp->host_reserved_frames = std::max(sp->host_reserved_frames, max_frames); }
+    return st;
 }
 
 aw_status aw_spatializer_process_host(aw_spatializer *sp, const float *in, float *out, int64_t frames) {
     if (!sp || !in || !out) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     if (frames <= 0) return frames == 0 ? AW_OK : fail(AW_ERR_INVALID_ARGUMENT, "frames must be >= 0");
     AW_HIP_TRY(hipSetDevice(sp->ctx->device));
-    const size_t n_in = (size_t)sp->n_streams * frames * sp->n_channels, n_out = (size_t)sp->n_streams * frames * 2;
-    aw_status st = sp_grow(&sp->d_stage_in, &sp->stage_in_cap, n_in);
-    if (st == AW_OK) st = sp_grow(&sp->d_stage_out, &sp->stage_out_cap, n_out);
+    aw_context *c = sp->ctx;
+    std::lock_guard<std::mutex> lk(c->launch_mu);
+    const size_t in_ps = (size_t)frames * sp->n_channels, out_ps = (size_t)frames * 2;          // floats per stream
+    int64_t cs = host_chunk_streams(sp, frames);
+    // a reserved spatializer keeps the chunking its buffers were sized for (never a reallocation on this path)
+    if (frames <= sp->host_reserved_frames) cs = sp->host_chunk_reserved > 0 ? (cs > 0 ? std::min(cs, sp->host_chunk_reserved) : sp->host_chunk_reserved) : 0;
+    aw_status st = host_stage_buffers(sp, frames, cs);
+    if (st == AW_OK && cs > 0) st = host_pipeline_objects(c);
     if (st != AW_OK) return st;
-    AW_HIP_TRY(hipMemcpyAsync(sp->d_stage_in, in, n_in * sizeof(float), hipMemcpyHostToDevice, sp->ctx->stream));
-    st = aw_spatializer_process(sp, sp->d_stage_in, sp->d_stage_out, frames);
-    if (st != AW_OK) return st;
-    AW_HIP_TRY(hipMemcpyAsync(out, sp->d_stage_out, n_out * sizeof(float), hipMemcpyDeviceToHost, sp->ctx->stream));
-    AW_HIP_TRY(hipStreamSynchronize(sp->ctx->stream));
+    sp->host_chunk_streams = cs;
+    const LwCallPlan lw = sp_begin_call(sp, frames);
+    if (cs == 0) {                       // one piece: H2D -> kernels -> D2H on the context's stream
+        AW_HIP_TRY(hipMemcpyAsync(sp->d_stage_in, in, in_ps * sp->n_streams * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        st = sp_run_streams(sp, lw, 0, sp->n_streams, sp->d_stage_in, sp->d_stage_out, frames);
+        if (st != AW_OK) return st;
+        sp->hist_cur ^= 1;
+        AW_HIP_TRY(hipMemcpyAsync(out, sp->d_stage_out, out_ps * sp->n_streams * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        AW_HIP_TRY(hipStreamSynchronize(c->stream));
+        return AW_OK;
+    }
+    // whatever the context's stream still holds (an earlier device-buffer call of this spatializer) comes first
+    AW_HIP_TRY(hipEventRecord(c->ev_run[0], c->stream));
+    AW_HIP_TRY(hipStreamWaitEvent(c->s_h2d, c->ev_run[0], 0));
+    int k = 0;
+    for (int64_t s0 = 0; s0 < sp->n_streams; s0 += cs, ++k) {
+        const int ns = (int)std::min<int64_t>(cs, sp->n_streams - s0), slot = k & 1;
+        float *d_in = sp->d_stage_in + (size_t)slot * cs * in_ps, *d_out = sp->d_stage_out + (size_t)slot * cs * out_ps;
+        if (k >= 2) AW_HIP_TRY(hipStreamWaitEvent(c->s_h2d, c->ev_run[slot], 0));              // chunk k-2's kernels have read this slot
+        AW_HIP_TRY(hipMemcpyAsync(d_in, in + (size_t)s0 * in_ps, (size_t)ns * in_ps * sizeof(float), hipMemcpyHostToDevice, c->s_h2d));
+        AW_HIP_TRY(hipEventRecord(c->ev_h2d[slot], c->s_h2d));
+        AW_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_h2d[slot], 0));
+        if (k >= 2) AW_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_d2h[slot], 0));             // chunk k-2's output has left this slot
+        st = sp_run_streams(sp, lw, (int)s0, ns, d_in, d_out, frames);
+        if (st != AW_OK) break;
+        AW_HIP_TRY(hipEventRecord(c->ev_run[slot], c->stream));
+        AW_HIP_TRY(hipStreamWaitEvent(c->s_d2h, c->ev_run[slot], 0));
+        AW_HIP_TRY(hipMemcpyAsync(out + (size_t)s0 * out_ps, d_out, (size_t)ns * out_ps * sizeof(float), hipMemcpyDeviceToHost, c->s_d2h));
+        AW_HIP_TRY(hipEventRecord(c->ev_d2h[slot], c->s_d2h));
+    }
+    const hipError_t e1 = hipStreamSynchronize(c->s_h2d), e2 = hipStreamSynchronize(c->stream), e3 = hipStreamSynchronize(c->s_d2h);
+    if (st != AW_OK) return st;          // (a failed chunk: the streams are drained, the history has not been flipped)
+    AW_HIP_TRY(e1); AW_HIP_TRY(e2); AW_HIP_TRY(e3);
+    sp->hist_cur ^= 1;
+    return AW_OK;
+}
+
+/* Page-locked host memory for the host entries (hipHostMalloc): buffers from here cross PCIe by DMA without the runtime's staging copy. */
+aw_status aw_host_alloc_pinned(aw_context *ctx, size_t bytes, void **ptr) {
+    if (!ctx || !ptr) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    AW_HIP_TRY(hipSetDevice(ctx->device));
+    AW_HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    ctx->device_allocs += 1;
+    return AW_OK;
+}
+aw_status aw_host_free_pinned(aw_context *ctx, void *ptr) {
+    if (!ctx) return fail(AW_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (ptr) AW_HIP_TRY(hipHostFree(ptr));
     return AW_OK;
 }
 
@@ -981,8 +1232,8 @@ aw_status aw_spatializer_process_planar(aw_spatializer *sp, const float *in_l, c
     AW_HIP_TRY(hipSetDevice(sp->ctx->device));
     hipStream_t s = sp->ctx->stream;
     // staging layout: [in interleaved 2F | planar L F | planar R F] and [out interleaved 2F | L F | R F]
-    aw_status st = sp_grow(&sp->d_stage_in, &sp->stage_in_cap, (size_t)frames * 4);
-    if (st == AW_OK) st = sp_grow(&sp->d_stage_out, &sp->stage_out_cap, (size_t)frames * 4);
+    aw_status st = sp_grow(sp, &sp->d_stage_in, &sp->stage_in_cap, (size_t)frames * 4);
+    if (st == AW_OK) st = sp_grow(sp, &sp->d_stage_out, &sp->stage_out_cap, (size_t)frames * 4);
     if (st != AW_OK) return st;
     float *d_il = sp->d_stage_in + 2 * (size_t)frames, *d_ir = d_il + frames;
     float *d_ol = sp->d_stage_out + 2 * (size_t)frames, *d_or = d_ol + frames;
@@ -1080,15 +1331,33 @@ aw_status aw_realtime_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_ren
     p->pending.assign((size_t)block_size * 2, 0.f);
     p->fifo_left.assign((size_t)p->fifo_capacity, 0.f);
     p->fifo_right.assign((size_t)p->fifo_capacity, 0.f);
+    // everything a callback can need is allocated here, like the reference's init (RealtimeAudioProcessor.swift:30-62: pending, block and
+    // FIFO buffers): one callback completes at most (block_size - 1 + max_frames) / block_size blocks = fewer than fifo_capacity frames
+    p->ready_in.reserve((size_t)p->fifo_capacity * 2);
+    p->ready_out.reserve((size_t)p->fifo_capacity * 2);
     const int used = std::min(n_renderers, 2);                          // min(renderers.count, 2)  :145
     if (used > 0) {
         int32_t lt[2] = {-1, -1}, rt[2] = {-1, -1};
         for (int r = 0; r < used; ++r) { lt[r] = left_track[r]; rt[r] = right_track[r]; }
         aw_status st = aw_spatializer_create(ctx, hrir, 2, lt, rt, 1, block_size, &p->sp);
+        // device side: kernel scratch and the host entry's staging for the longest device call a callback can make (process must not allocate)
+        if (st == AW_OK) st = aw_spatializer_reserve_host(p->sp, p->fifo_capacity);
         if (st != AW_OK) { aw_realtime_destroy(p); return st; }
     }
     *out = p;
     return AW_OK;
+}
+
+/* Introspection for the "process must not allocate" contract test: 0 bytes of host buffer capacity held (pending, ready, FIFO),
+ * 1 bytes of grow-only device buffers (aw_spatializer_info 6), 2 device allocations made so far on the context (aw_spatializer_info 13). */
+int64_t aw_realtime_info(const aw_realtime *p, int32_t what) {
+    if (!p) return -1;
+    switch (what) {
+        case 0: return (int64_t)((p->pending.capacity() + p->ready_in.capacity() + p->ready_out.capacity() + p->fifo_left.capacity() + p->fifo_right.capacity()) * sizeof(float));
+        case 1: return p->sp ? aw_spatializer_info(p->sp, 6) : 0;
+        case 2: return p->ctx->device_allocs;
+        default: return -1;
+    }
 }
 
 void aw_realtime_destroy(aw_realtime *p) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -33,6 +34,19 @@ struct aw_context {
     float *d_zeros = nullptr;                                       // page of zeros (frames past the end of a call)
     bool literal_resampler = false;                                 // aw_context_set_resampler: aw_preset_activate resamples HRIRs with the literal vgenp call
     awk::LaunchCfg cfg;                                             // device properties + tuning knobs, read once at creation
+    // Scratch pool (round 5): the grow-only HBM scratch of the partitioned and long-window kernels belongs to the CONTEXT and is
+    // shared by every spatializer created on it — their calls are ordered on the context's stream, so one buffer of the largest
+    // need serves them all, and a second spatializer (a preset change: HRIRManager.activatePreset builds a new renderer network
+    // while the old one still plays, HRIRManager.swift:347-446) pays no second multi-GB hipMalloc.  launch_mu keeps one call's
+    // launch sequence contiguous on the stream when two owners drive two handles of one context from two threads.
+    awk::cf *d_pool = nullptr;
+    size_t pool_capacity = 0;                                       // complex elements
+    std::mutex launch_mu;
+    long long device_allocs = 0;                                    // hipMalloc / hipHostMalloc calls made on behalf of this context's handles (tests: a reserved process path makes none)
+    long long sync_copies = 0;                                      // blocking hipMemcpy calls likewise (table uploads)
+    // host-entry pipeline (aw_spatializer_process_host on a multi-stream batch): H2D of chunk k+1 || kernels of chunk k || D2H of chunk k-1
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_run[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
 };
 
 struct aw_hrir {
@@ -51,9 +65,9 @@ struct aw_spatializer {
     awk::cf2 *d_tab = nullptr;          // [partitions][pairs][N]
     float *d_hist[2] = {nullptr, nullptr};
     int hist_cur = 0;
-    // partitioned path scratch (grow-only): input-window spectra [stream][block][pair][N]
-    awk::cf *d_spec = nullptr;
-    size_t spec_capacity = 0;           // elements
+    // scratch of the partitioned / long-window kernels: the context's pool (aw_context::d_pool), grow-only; reserved_pool = what
+    // aw_spatializer_reserve() asked of it for this spatializer (elements)
+    size_t reserved_pool = 0;
     size_t scratch_budget = 0;          // bytes per stream chunk (AW_SPEC_SCRATCH_MB at create; 0 = from free memory at first use)
     bool cmac_group = false;            // partitioned path: block-group CMAC kernel instead of the marched one (> 8 pairs; AW_PART_CMAC=group)
     bool fwd_one_pair = false;          // partitioned path: forward kernel with one channel pair per workgroup (default for more than 4 pairs; AW_PART_FWD=1|2 forces either form)
@@ -70,9 +84,14 @@ struct aw_spatializer {
     int last_lw_R = 0;                  // R of the last call's (first group of) windows (0: the partitioned kernels ran)
     int last_lw_R2 = 0;                 // R of its remainder window when the call ran as two groups
     int64_t reserved_frames = 0;        // aw_spatializer_reserve(): buffers are sized for calls up to this many frames
-    // host-entry staging (grow-only)
+    // host-entry staging (grow-only; a multi-stream batch is staged in two chunks of streams each way: aw_spatializer_process_host)
     float *d_stage_in = nullptr, *d_stage_out = nullptr;
     size_t stage_in_cap = 0, stage_out_cap = 0;   // floats
+    int64_t host_chunk_streams = 0;               // streams per staged chunk of the last host call (0: the whole batch in one piece, serial)
+    int64_t host_chunk_reserved = 0, host_reserved_frames = 0;   // aw_spatializer_reserve_host: the chunking its buffers were sized for, and up to which call length
+    // what the last aw_spatializer_reserve spent where (microseconds): float64 table build on host threads, table upload (hipMalloc +
+    // hipMemcpy), scratch pool growth (hipMalloc) — bench.py's config.activation
+    int64_t reserve_tables_us = 0, reserve_upload_us = 0, reserve_scratch_us = 0;
     unsigned long long *d_dbg = nullptr;   // AW_STAMPS diagnostic builds only
     size_t dbg_cap = 0;                     // words
     long long dbg_nwg = 0;

@@ -34,7 +34,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; measured copy ceiling of a box: tools/ubench/mall_probe)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s) — what `roofline.frac` is priced on; the ceilings MEASURED on the
+                               # box of this run (read-only / write-only / copy kernels, aw_context_bandwidth_probe) are reported next to it: roofline.measured
 FP32_PEAK_TFLOPS = 157.3
 
 WORKLOADS = {
@@ -110,19 +111,29 @@ def load_hrir(name, taps: int):
 
 def committed_traffic(workload: str, S: int, F: int, C: int):
     """Fabric-side (L2 <-> Infinity Cache / HBM) bytes per step from the newest committed rocprofv3 PMC profile of this
-    same workload (profiles/*/traffic_<workload>.json, made by tools/profile_round2.sh: separate --pmc passes, read bytes
+    same workload (profiles/*/traffic_<workload>.json, made by tools/profile_round5.sh: separate --pmc passes, read bytes
     from TCC_EA0_RDREQ_{32,64,128}B because FETCH_SIZE counts a 128-B request as 64 B on gfx950).  PMC counters cannot be
-    collected from inside this process, so this is the last committed measurement, or None when the shape differs."""
+    collected from inside this process, so this is the last committed measurement — and only one made on THESE kernels: a
+    profile records a digest of csrc/device at the time it was taken (and the git HEAD of that build), and a profile whose
+    digest differs from the tree's is refused (returns (None, why)) instead of silently going stale."""
     import glob
-    best = None
+    from airwave_amd.provenance import device_source_digest
+    digest = device_source_digest()
+    best, why = None, "no committed profile of this workload"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"traffic_{workload}.json"))):
         try:
             d = json.load(open(path))
-            if (d["streams_per_gpu"], d["frames_per_stream"], d["input_channels"]) == (S, F, C):
-                best = (path, d)
         except Exception:
             continue
-    return best
+        if (d["streams_per_gpu"], d["frames_per_stream"], d["input_channels"]) != (S, F, C):
+            continue
+        if d.get("device_src_sha16") != digest:
+            why = (f"newest profile of this shape ({os.path.relpath(path, ROOT)}, device sources {d.get('device_src_sha16', 'unrecorded')}, "
+                   f"HEAD {d.get('git_head', 'unrecorded')}) predates the current device sources ({digest}): re-profile")
+            best = None
+            continue
+        best, why = (path, d), ""
+    return best, why
 
 
 def cpu_baseline(x_host, tracks, lt, rt, frames: int, eq_definition=None, rate: float = 48000.0):
@@ -168,21 +179,24 @@ def oracle_spot_check(x_dev, y_dev, tracks, lt, rt, calls: int, streams=(0, -1),
     L = tracks.shape[1]
     F = x_dev.shape[1]
     worst = 0.0
+
+    def host(a):          # device tensors (the timed run) or host arrays (the end-to-end leg)
+        return a.cpu().numpy() if hasattr(a, "cpu") else np.asarray(a)
     for s in streams:
         if calls >= 2 and F >= L - 1:          # history of the last step = the tail of the same input
-            xin = np.concatenate([x_dev[s, F - (L - 1):].cpu().numpy(), x_dev[s, :head].cpu().numpy()])
+            xin = np.concatenate([host(x_dev[s, F - (L - 1):]), host(x_dev[s, :head])])
             ref = orc.spatialize_f64(xin, tracks, lt, rt)[L - 1:]
         else:
-            ref = orc.spatialize_f64(x_dev[s, :head].cpu().numpy(), tracks, lt, rt)
-        worst = max(worst, orc.peak_rel_error(y_dev[s, :head].cpu().numpy(), ref))
+            ref = orc.spatialize_f64(host(x_dev[s, :head]), tracks, lt, rt)
+        worst = max(worst, orc.peak_rel_error(host(y_dev[s, :head]), ref))
         n0 = max(0, F - tail - (L - 1))
-        xin = x_dev[s, n0:].cpu().numpy()
+        xin = host(x_dev[s, n0:])
         if n0 == 0 and calls >= 2 and F >= L - 1:
-            xin = np.concatenate([x_dev[s, F - (L - 1):].cpu().numpy(), xin])
+            xin = np.concatenate([host(x_dev[s, F - (L - 1):]), xin])
             ref = orc.spatialize_f64(xin, tracks, lt, rt)[-tail:]
         else:
             ref = orc.spatialize_f64(xin, tracks, lt, rt)[-tail:]
-        worst = max(worst, orc.peak_rel_error(y_dev[s, F - tail:].cpu().numpy(), ref))
+        worst = max(worst, orc.peak_rel_error(host(y_dev[s, F - tail:]), ref))
     return worst
 
 
@@ -209,7 +223,18 @@ def flops_per_frame(C: int, path: dict) -> float:
     return ((pairs + 1) * fft + path["partitions"] * pairs * n8 * 16) / path["hop"]
 
 
-def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with_cpu: bool, with_check: bool = None):
+def measured_ceilings(ctx) -> dict:
+    """"confirm on the box and also quote a measured copy-kernel ceiling".  Read-only, write-only and copy kernels
+    over 4 GiB each (aw_context_bandwidth_probe: 16 B per lane, plain and non-temporal forms, best of 3), on the box and in the
+    process of this very run, before the timed region."""
+    t0 = time.perf_counter()
+    m = ctx.bandwidth_probe(4 << 30, 3)
+    return {"read": m["read"], "write": m["write"], "copy": m["copy"], "unit": "GB/s", "bytes_per_kernel": 4 << 30,
+            "copy_counts": "bytes read + bytes written", "probe_seconds": round(time.perf_counter() - t0, 3),
+            "source": "aw_context_bandwidth_probe on this box, this process, before the timed region"}
+
+
+def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with_cpu: bool, with_check: bool = None, measured: dict = None):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -223,47 +248,74 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
     steps = args.steps if args.steps is not None else wl["steps"]
     warmup = args.warmup if args.warmup is not None else wl["warmup"]
     rates = wl.get("rates", [48000])
+    n_lanes = max(1, min(args.lanes if args.lanes else wl.get("lanes", 1), S))
     tracks, hrir_src = load_hrir(wl["hrir"], wl["taps"])
 
     layout = aw.InputLayout.detect(C) if C != 7 else aw.InputLayout(SPEAKERS7, "7 speakers")
     first_stream, _ = weak_shard(S, world, rank)                                  # stream ids are global
 
-    # One leg per sample rate (cfg 5 buckets streams by rate; every other workload has one leg).
+    # One leg per (lane, sample rate).  cfg 5 buckets streams by rate; a workload with `lanes` > 1 (cfg 4) runs its batch as that many
+    # chunks of streams, each on a context — a HIP stream — of its own, so that one chunk's EQ kernel (FP64-vector bound) can execute
+    # beside another chunk's split / merge kernels (fabric bound); every other workload is one lane on the bench's context.
     stream_rates = [rates[i * len(rates) // S] for i in range(S)] if len(rates) > 1 else [rates[0]] * S
     cmap = None
     if wl.get("text_map"):            # the 14-channel reading of cfg 3: custom channels mapped by a HeSuVi-style text map
         cmap = aw.HRIRChannelMap.parseHeSuViFormat(open(os.path.join(ROOT, "tests", "golden", wl["text_map"])).read())
-    batch = aw.MixedRateBatch(tracks, 48000.0, layout, stream_rates, hrirMap=cmap, ctx=ctx)
     eq_def = None
     if wl.get("eq"):
         eq_def = aw.EqualizerAPOParser.parse(open(os.path.join(ROOT, "tests", "golden", "eq", "CCA CRA ParametricEq.txt"), "rb").read(), "CCA CRA ParametricEq.txt")
-    legs = []
-    activation_ms = []                # wall time of aw_spatializer_reserve per rate bucket: table build (host, float64) + upload + scratch
-    for rate, b in batch.buckets.items():
-        n, F = len(b.stream_ids), int(round(seconds * rate))
-        x = torch.empty((n, F, C), dtype=torch.float32, device="cuda")
-        y = torch.empty((n, F, 2), dtype=torch.float32, device="cuda")
-        ctx.synth_fill(x.data_ptr(), n, F, C, seed=0xA17AE, first_stream=first_stream + b.stream_ids[0])
-        t_act = time.perf_counter()
-        b.spatializer.reserve(F)      # every internal buffer is sized here (and the long-window tables built): process never allocates
-        torch.cuda.synchronize()
-        activation_ms.append((time.perf_counter() - t_act) * 1e3)
-        eq = aw.ParametricEqualizerState(eq_def, float(rate), n_streams=n, ctx=ctx) if eq_def is not None else None
-        legs.append(dict(rate=rate, n=n, F=F, x=x, y=y, sp=b.spatializer, eq=eq, taps=b.hrir_taps))
+    main_stream = torch.cuda.current_stream()                                    # torch's current stream IS the bench context's stream
+    lane_ctx = [ctx] + [aw.Context(ctx.device) for _ in range(n_lanes - 1)]
+    lane_stream = [main_stream] + [torch.cuda.ExternalStream(c.stream) for c in lane_ctx[1:]]
+    legs, batches = [], []
+    activation = []                   # per leg: what aw_spatializer_reserve spent where (table build on host threads / upload / scratch pool)
+    for li in range(n_lanes):
+        lo, hi = li * S // n_lanes, (li + 1) * S // n_lanes
+        batch = aw.MixedRateBatch(tracks, 48000.0, layout, stream_rates[lo:hi], hrirMap=cmap, ctx=lane_ctx[li])
+        batches.append(batch)
+        for rate, b in batch.buckets.items():
+            n, F = len(b.stream_ids), int(round(seconds * rate))
+            x = torch.empty((n, F, C), dtype=torch.float32, device="cuda")
+            y = torch.empty((n, F, 2), dtype=torch.float32, device="cuda")
+            lane_ctx[li].synth_fill(x.data_ptr(), n, F, C, seed=0xA17AE, first_stream=first_stream + lo + b.stream_ids[0])
+            t_act = time.perf_counter()
+            b.spatializer.reserve(F)  # every internal buffer is sized here (and the long-window tables built): process never allocates
+            torch.cuda.synchronize()
+            total_ms = (time.perf_counter() - t_act) * 1e3
+            inf = b.spatializer.info()
+            activation.append({"total_ms": round(total_ms, 1), "tables_ms": round(inf["reserve_tables_ms"], 1), "upload_ms": round(inf["reserve_upload_ms"], 1),
+                               "scratch_alloc_ms": round(inf["reserve_scratch_ms"], 1), "scratch_bytes": inf["scratch_bytes"], "warm_context": False})
+            eq = aw.ParametricEqualizerState(eq_def, float(rate), n_streams=n, ctx=lane_ctx[li]) if eq_def is not None else None
+            legs.append(dict(lane=li, rate=rate, n=n, F=F, x=x, y=y, sp=b.spatializer, eq=eq, taps=b.hrir_taps, first=lo + b.stream_ids[0]))
+    batch = batches[0]
     torch.cuda.synchronize()
     eq_events = []
 
     def step(timed=False):
         for g in legs:
+            st = lane_stream[g["lane"]]
             g["sp"].process_device(g["x"].data_ptr(), g["y"].data_ptr(), g["F"])
             if g["eq"] is not None:
                 if timed:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                g["eq"].process_device(g["y"].data_ptr(), g["y"].data_ptr(), g["F"])     # in place, on the same stream
+                    e0.record(st)
+                g["eq"].process_device(g["y"].data_ptr(), g["y"].data_ptr(), g["F"])     # in place, on the lane's stream
                 if timed:
-                    e1.record()
+                    e1.record(st)
                     eq_events.append((e0, e1))
+
+    def fork():        # the other lanes' streams start after everything queued on the main stream ...
+        if n_lanes > 1:
+            e = torch.cuda.Event()
+            e.record(main_stream)
+            for st in lane_stream[1:]:
+                st.wait_event(e)
+
+    def join():        # ... and the main stream continues after everything queued on them
+        for st in lane_stream[1:]:
+            e = torch.cuda.Event()
+            e.record(st)
+            main_stream.wait_event(e)
 
     for _ in range(warmup):
         step()
@@ -273,12 +325,14 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
     if world > 1 or dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)     # torch's current stream IS the context stream
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()
+    ev0.record(main_stream)
+    fork()
     for _ in range(steps):
         step(timed=True)
-    ev1.record()
+    join()
+    ev1.record(main_stream)
     torch.cuda.synchronize()
     if world > 1 or dist.is_initialized():        # the timed region ends, like it starts, with a barrier + synchronize on every rank
         dist.barrier()
@@ -309,14 +363,15 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
             dom_names.append(kname)
             lw = info.get("long_window_rows", 0)
             if lw:        # the long-window kernels ran (tile_lw.hpp): windows of lw x 4096 frames, hop = window - history
-                paths.append({"rate": g["rate"], "streams": g["n"], "frames": g["F"], "taps": g["taps"], "fft": lw * 4096, "hop": lw * 4096 - info["history"],
+                paths.append({"lane": g["lane"], "rate": g["rate"], "streams": g["n"], "frames": g["F"], "taps": g["taps"], "fft": lw * 4096, "hop": lw * 4096 - info["history"],
                               "partitions": 1, "path": "long-window overlap-save (four-step FFT: split / rows / merge)"})
             else:
-                paths.append({"rate": g["rate"], "streams": g["n"], "frames": g["F"], "taps": g["taps"], "fft": info["fft"], "hop": info["hop"],
+                paths.append({"lane": g["lane"], "rate": g["rate"], "streams": g["n"], "frames": g["F"], "taps": g["taps"], "fft": info["fft"], "hop": info["hop"],
                               "partitions": info["partitions"], "path": "fused overlap-save" if info["path"] == 0 else "partitioned"})
         finite = all(bool(torch.isfinite(g["y"][:, -4096:]).all().item()) for g in legs)
         g0 = legs[0]
-        if all(pp["path"] != "fused overlap-save" for pp in paths) and stages:
+        multi_kernel = all(pp["path"] != "fused overlap-save" for pp in paths) and bool(stages)
+        if multi_kernel:
             # multi-kernel pipeline: every stage's launches cover all frames of the step; the dominant kernel is the longest stage
             kname = max(stages, key=lambda k: stages[k]["ms_per_step"])
             dom_ms, dom_frames, dom_names = stages[kname]["ms_per_step"], frames_step, [kname]
@@ -326,8 +381,40 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
         # kernel level: the dominant kernel alone, priced on the frames its launches produced
         kern_alg = bytes_per_frame * dom_frames
         kern_gbs = kern_alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        tr = committed_traffic(name, g0["n"], g0["F"], C) if len(legs) == 1 else None
+        tr, tr_why = committed_traffic(name, S, g0["F"], C) if len(rates) == 1 else (None, "several legs")
         lt, rt = batch.left_track, batch.right_track
+        roof = {
+            "bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": step_gbs / HBM_PEAK_GBS,
+            "frac_scope": "whole step: algorithmic bytes of every output frame / HIP-event time of all launches of the step",
+            "step_ms": step_ms, "algorithmic_bytes_per_step": step_alg, "bytes_per_frame": bytes_per_frame, "frames_per_step": frames_step,
+            "kernel": ", ".join(sorted(set(dom_names))), "kernel_avg_ms": dom_ms,
+            "algorithmic_bytes_per_launch": kern_alg, "frames_per_launch": dom_frames, "launches_timed": steps,
+            "stages_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+            "traffic": tr[1]["total_bytes_per_step"] if tr else None,
+            "traffic_unit": "L2 <-> fabric (Infinity Cache / HBM) bytes per step, all kernels, rocprofv3 PMC (Infinity-Cache hits are counted)",
+            "traffic_by_kernel": tr[1].get("by_kernel") if tr else None,
+            "traffic_source": os.path.relpath(tr[0], ROOT) if tr else None,
+            "traffic_head": tr[1].get("git_head") if tr else None,
+            "traffic_device_src_sha16": tr[1].get("device_src_sha16") if tr else None,
+            "traffic_note": ("committed profile of these very device sources, made on another box by tools/profile_round5.sh; not measured in this run"
+                             if tr else tr_why),
+        }
+        if multi_kernel:
+            # (a share of the step's time, NOT a roofline fraction: every launch of a multi-kernel step covers every frame, so pricing the
+            # step's bytes on one of them would flatter it — round-4 review)
+            roof["dominant_kernel_share"] = dom_ms / step_ms if step_ms > 0 else None
+        else:
+            roof["kernel_frac"] = kern_gbs / HBM_PEAK_GBS
+            roof["kernel_frac_scope"] = "the single fused kernel's interior launch: algorithmic bytes of the frames it covers / its HIP-event time"
+        if measured:
+            # the mix ceiling: this workload's algorithmic bytes are 4C read + 8 written per frame; at the measured read-only and
+            # write-only rates they cannot move faster than bytes / (read_bytes / read + write_bytes / write)
+            mix = bytes_per_frame / (4 * C / measured["read"] + 8 / measured["write"])
+            roof["measured"] = dict(measured, mix=mix, mix_scope=f"{4 * C} B read at `read` + 8 B written at `write` per frame")
+            roof["frac_of_measured"] = step_gbs / measured["copy"]
+            roof["frac_of_measured_scope"] = "achieved / measured copy-kernel ceiling of this box (SURVEY 8d); frac_of_measured_mix = achieved / measured.mix"
+            roof["frac_of_measured_mix"] = step_gbs / mix
         result = {
             "metric": "stereo frames/sec @48kHz, 14ch HeSuVi HRIR",
             "value": frames_total / elapsed_max,
@@ -345,27 +432,19 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
             "config": {
                 "workload": wl["desc"], "name": name, "streams_per_gpu": S, "frames_per_stream": g0["F"], "sample_rate": g0["rate"],
                 "input_channels": C, "hrir_tracks": int(tracks.shape[0]), "hrir_taps": g0["taps"],
-                "convolutions_per_stream": int((lt >= 0).sum() + (rt >= 0).sum()), "parallelism": f"streams sharded x{world}, no data-path collective",
+                "convolutions_per_stream": int((lt >= 0).sum() + (rt >= 0).sum()),
+                "parallelism": f"streams sharded x{world}, no data-path collective" + (f"; {n_lanes} stream chunks per GPU on {n_lanes} HIP streams" if n_lanes > 1 else ""),
+                "lanes": n_lanes,
                 "fft": paths[0]["fft"], "hop": paths[0]["hop"], "path": paths[0]["path"], "legs": paths,
                 "outputs_finite": finite,
                 # creation-time cost (not in the timed region; the reference does its HRIR partition FFTs at engine init too,
-                # ConvolutionEngine.swift:143-182): aw_spatializer_reserve = table build in float64 on host threads + upload + scratch
-                "activation_ms": [round(v, 1) for v in activation_ms],
+                # ConvolutionEngine.swift:143-182): aw_spatializer_reserve = table build in float64 on host threads + upload + scratch pool
+                "activation": activation,
+                "activation_ms": [a["total_ms"] for a in activation],
+                "device_src_sha16": __import__("airwave_amd.provenance", fromlist=["x"]).device_source_digest(),
+                "build_head": __import__("airwave_amd.provenance", fromlist=["x"]).build_head(),
             },
-            "roofline": {
-                "bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": step_gbs / HBM_PEAK_GBS,
-                "frac_scope": "whole step: algorithmic bytes of every output frame / HIP-event time of all launches of the step",
-                "step_ms": step_ms, "algorithmic_bytes_per_step": step_alg, "bytes_per_frame": bytes_per_frame, "frames_per_step": frames_step,
-                "kernel": ", ".join(sorted(set(dom_names))), "kernel_avg_ms": dom_ms, "kernel_frac": kern_gbs / HBM_PEAK_GBS,
-                "kernel_frac_scope": "dominant kernel alone: algorithmic bytes of the frames its launches cover / its HIP-event time",
-                "algorithmic_bytes_per_launch": kern_alg, "frames_per_launch": dom_frames, "launches_timed": steps,
-                "stages_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms_per_step"])},
-                "traffic": tr[1]["total_bytes_per_step"] if tr else None,
-                "traffic_unit": "L2 <-> fabric (Infinity Cache / HBM) bytes per step, all kernels, rocprofv3 PMC (Infinity-Cache hits are counted)",
-                "traffic_by_kernel": tr[1].get("by_kernel") if tr else None,
-                "traffic_source": os.path.relpath(tr[0], ROOT) if tr else None,
-            },
+            "roofline": roof,
         }
         if len(legs) == 1:            # second roof (report which one binds): FP32 vector
             fpf = flops_per_frame(C, paths[0])
@@ -378,7 +457,7 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
                                             else "the FP32 roof binds" if fpf / bytes_per_frame > 1.05 * ridge else "both roofs bind within 5 %")}
         if eq_events:
             eq_ms = sum(a.elapsed_time(b) for a, b in eq_events) / steps
-            result["roofline"]["eq_kernel_ms_per_step"] = eq_ms
+            result["roofline"]["eq_kernel_ms_per_step"] = eq_ms           # (sum over lanes: with several lanes the EQ launches overlap other lanes' kernels)
             result["roofline"]["eq_achieved_GBs"] = 16.0 * frames_step / (eq_ms * 1e-3) / 1e9      # 8 B in + 8 B out per frame
         if with_check is None:
             with_check = with_cpu
@@ -389,6 +468,22 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
             result["parity_spot_err"] = err
             result["parity_spot"] = ("max peak-relative error of streams 0 and n-1, first 4096 and last 2048 output frames of the last timed step, "
                                      "against the float64 oracle (direct-form linear convolution; the reference pins only delta-HRIR KATs); tolerance 1e-5")
+        if world == 1 and len(legs) == 1 and not args.no_warm_activation:
+            # activation on a WARM context (a preset change: HRIRManager.activatePreset builds the next renderer network while the old one
+            # plays): a second spatializer of the same shape on the same context finds the scratch pool already there
+            t_act = time.perf_counter()
+            b2 = aw.MixedRateBatch(tracks, 48000.0, layout, stream_rates, hrirMap=cmap, ctx=ctx)
+            t_create = time.perf_counter()
+            sp2 = next(iter(b2.buckets.values())).spatializer
+            sp2.reserve(g0["F"])
+            torch.cuda.synchronize()
+            t_res = time.perf_counter()
+            inf = sp2.info()
+            result["config"]["activation_warm"] = {
+                "create_ms": round((t_create - t_act) * 1e3, 1), "reserve_ms": round((t_res - t_create) * 1e3, 1),
+                "tables_ms": round(inf["reserve_tables_ms"], 1), "upload_ms": round(inf["reserve_upload_ms"], 1),
+                "scratch_alloc_ms": round(inf["reserve_scratch_ms"], 1), "warm_context": True}
+            del b2, sp2
         if with_cpu and world == 1:      # the CPU baseline is reported at N = 1 only
             ns = max(1, min(g0["n"], args.cpu_sample_streams))
             Fc = g0["F"] if name in ("cfg1", "cfg2") else min(g0["F"], int(4 * g0["rate"]))     # long-tap configs: 4 s per stream
@@ -396,9 +491,75 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
             tr0 = aw.resample_tracks(tracks, 48000.0, float(g0["rate"]))
             result["cpu_baseline"] = cpu_baseline(x_host, tr0, lt, rt, Fc, eq_definition=eq_def, rate=float(g0["rate"]))
     # release the device buffers before the next workload of this run
-    del legs, batch
+    del legs, batch, batches
     torch.cuda.empty_cache()
     return result
+
+
+def end_to_end(name: str, args, ctx, streams: int = 0, pcie: dict = None):
+    """SURVEY.md 8d, secondary: the PCIe-inclusive rate of the same hot path when the host hands over HOST buffers
+    (aw_spatializer_process_host: the batch crosses PCIe in chunks of streams, H2D of chunk k+1 || kernels of chunk k || D2H of chunk
+    k-1).  Page-locked buffers (aw_host_alloc_pinned) and, for comparison, pageable ones.  Never `value`."""
+    import numpy as np
+    import torch
+    import airwave_amd as aw
+    wl = dict(WORKLOADS[name])
+    S = streams or wl["streams"]
+    C, rate = wl["channels"], 48000
+    F = int(round((args.seconds or wl["seconds"]) * rate))
+    tracks, _ = load_hrir(wl["hrir"], wl["taps"])
+    layout = aw.InputLayout.detect(C) if C != 7 else aw.InputLayout(SPEAKERS7, "7 speakers")
+    batch = aw.MixedRateBatch(tracks, 48000.0, layout, [rate] * S, ctx=ctx)
+    sp = batch.buckets[float(rate)].spatializer
+    x_dev = torch.empty((S, F, C), dtype=torch.float32, device="cuda")
+    ctx.synth_fill(x_dev.data_ptr(), S, F, C, seed=0xA17AE, first_stream=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x_pin, y_pin = ctx.pinned_empty((S, F, C)), ctx.pinned_empty((S, F, 2))
+    pin_ms = (time.perf_counter() - t0) * 1e3
+    ctx.d2h(x_pin, x_dev.data_ptr())
+    del x_dev
+    torch.cuda.empty_cache()
+    sp.reserve_host(F)
+    ctx.synchronize()
+    in_b, out_b = x_pin.nbytes, y_pin.nbytes
+
+    def timed(x, y, reps):
+        best = 1e30
+        for _ in range(reps):
+            t = time.perf_counter()
+            sp.process_host_into(x, y)          # synchronous
+            best = min(best, time.perf_counter() - t)
+        return best
+    timed(x_pin, y_pin, 1)                       # warm-up (first touch of the pinned pages by the DMA engines, clocks)
+    calls = 1
+    t_pin = timed(x_pin, y_pin, 3); calls += 3
+    # parity of what just crossed PCIe both ways: two streams' head and tail of the last call against the float64 oracle
+    err = oracle_spot_check(x_pin, y_pin, np.asarray(tracks), batch.left_track, batch.right_track, calls=calls) if not args.no_cpu_baseline else None
+    x_page, y_page = np.array(x_pin), np.empty_like(y_pin)             # pageable copies
+    t_page = timed(x_page, y_page, 2)
+    chunk = sp.info()["host_chunk_streams"]
+    res = {"workload": wl["desc"] + (f" — first {S} of {wl['streams']} streams (the PCIe-bound rate does not depend on the batch size)" if S != wl["streams"] else ""),
+           "name": name, "streams": S, "frames_per_stream": F, "input_channels": C,
+           "value": S * F / t_pin, "unit": "stereo frames/s, host buffers in -> host buffers out (PCIe inclusive)", "pinned": True,
+           "ms_per_batch": t_pin * 1e3, "h2d_GBs": in_b / t_pin / 1e9, "d2h_GBs": out_b / t_pin / 1e9,
+           "bytes_in": in_b, "bytes_out": out_b, "streams_per_chunk": chunk, "chunks": -(-S // chunk) if chunk else 1,
+           "pipeline": "H2D of chunk k+1 || kernels of chunk k || D2H of chunk k-1 on three HIP streams; two staged chunks each way",
+           "pageable": {"value": S * F / t_page, "ms_per_batch": t_page * 1e3, "pinned": False,
+                        "note": "same entry on pageable numpy arrays: hipMemcpyAsync stages them through the runtime's own pinned buffers"},
+           "pinned_alloc_ms": round(pin_ms, 1)}
+    if err is not None:
+        res["parity_spot_err"] = err
+    if pcie:
+        serial = in_b / (pcie["h2d"] * 1e9) + out_b / (pcie["d2h"] * 1e9)
+        res["pcie_measured"] = dict(pcie, unit="GB/s", source="aw_context_pcie_probe: 1 GiB page-locked hipMemcpyAsync each way, and both at once")
+        res["pcie_only_ms"] = serial * 1e3
+        res["frac_of_pcie"] = serial / t_pin
+        res["frac_of_pcie_scope"] = ("time of a page-locked H2D of the input followed by a D2H of the output at the measured rates (no kernels) "
+                                     "/ time of the host entry; above 1.0 = the two directions overlapped")
+    del batch, sp, x_pin, y_pin, x_page, y_page
+    torch.cuda.empty_cache()
+    return res
 
 
 # ---------------------------------------------------------------------------------------------- main
@@ -433,6 +594,10 @@ def main() -> int:
     ap.add_argument("--no-secondary", action="store_true", help="skip the second reading of the workload (cfg3: the 14-channel-input run)")
     ap.add_argument("--cpu-sample-streams", type=int, default=48)
     ap.add_argument("--dry-run", action="store_true", help="no GPU: rehearse launch + rendezvous + aggregate only (tests)")
+    ap.add_argument("--lanes", type=int, default=0, help="run the batch as this many chunks of streams on HIP streams of their own (default per workload; cfg4: see WORKLOADS)")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the measured read / write / copy ceiling probe (roofline.measured)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive secondary legs (secondary_end_to_end)")
+    ap.add_argument("--no-warm-activation", action="store_true", help="skip the second, warm-context activation (config.activation_warm)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -488,17 +653,24 @@ def main() -> int:
     print(f"[bench rank {rank}/{world}] device {local_rank}: {torch.cuda.get_device_name(local_rank)}, backend {backend if world > 1 or force_pg else 'none'}"
           + (" (forced one-rank process group)" if force_pg else ""), file=sys.stderr, flush=True)
     ctx = aw.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-    result = run_workload(args.workload, args, ctx, world, rank, backend, with_cpu=not args.no_cpu_baseline)
+    measured = measured_ceilings(ctx) if rank == 0 and not args.no_ceiling else None       # before any timed region, on this box
+    result = run_workload(args.workload, args, ctx, world, rank, backend, with_cpu=not args.no_cpu_baseline, measured=measured)
     sec = SECONDARY.get(args.workload)
     if sec and not args.no_secondary and not args.streams and not args.seconds:
-        r2 = run_workload(sec, args, ctx, world, rank, backend, with_cpu=False, with_check=not args.no_cpu_baseline)
+        r2 = run_workload(sec, args, ctx, world, rank, backend, with_cpu=False, with_check=not args.no_cpu_baseline, measured=measured)
         if rank == 0:
             result["secondary"] = {k: r2[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "roofline", "fp32_roof", "parity_spot_err") if k in r2}
             result["secondary"]["note"] = "same configuration read as 14-channel INPUT (north_star: 'synthetic 48 kHz 14-ch input'); value is never the headline"
+    e2e_of = {"cfg3": [("cfg3", 128), ("cfg2", 0)], "cfg2": [("cfg2", 0)], "cfg2-14ch": [("cfg2-14ch", 0)], "cfg1": [("cfg1", 0)]}
+    if rank == 0 and world == 1 and not args.no_end_to_end and not args.streams and not args.seconds and args.workload in e2e_of:
+        # SURVEY 8d "end-to-end incl. PCIe as secondary": the same hot path fed from host memory; never `value`
+        pcie = ctx.pcie_probe(1 << 30, 2)
+        result["secondary_end_to_end"] = [end_to_end(n, args, ctx, streams=k, pcie=pcie) for n, k in e2e_of[args.workload]]
     rc = 0
     if rank == 0:
         print(json.dumps(result), flush=True)
-        errs = [e for e in (result.get("parity_spot_err"), result.get("secondary", {}).get("parity_spot_err")) if e is not None]
+        errs = [e for e in [result.get("parity_spot_err"), result.get("secondary", {}).get("parity_spot_err")]
+                + [r.get("parity_spot_err") for r in result.get("secondary_end_to_end", [])] if e is not None]
         if any(not (e < 1e-5) for e in errs):
             print(f"bench.py: parity spot check FAILED: {errs} (tolerance 1e-5)", file=sys.stderr)
             rc = 3

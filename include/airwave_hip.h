@@ -15,7 +15,10 @@
  *    one owner"); independent handles are independent.
  *  - creation may block and allocate (the reference builds engines on a background queue,
  *    HRIRManager.swift:347); aw_spatializer_process on device buffers does not allocate once
- *    the handle has seen a call of that size class (scratch is grow-only).
+ *    aw_spatializer_reserve has sized the handle (or it has seen a call of that size class:
+ *    scratch is grow-only).  The scratch of the multi-kernel paths is a pool of the CONTEXT,
+ *    shared by its spatializers; a handle is still single-owner, handles of one context may be
+ *    driven from different threads (their launch sequences are serialised).
  *  - there is NO CPU fallback: without a HIP device every create returns AW_ERR_NO_DEVICE.
  */
 #ifndef AIRWAVE_HIP_H
@@ -68,11 +71,25 @@ AW_API void *aw_context_stream(aw_context *ctx);          /* the hipStream_t ker
 AW_API aw_status aw_context_timer_start(aw_context *ctx);
 AW_API aw_status aw_context_timer_stop(aw_context *ctx, float *elapsed_ms); /* records, syncs, returns ms */
 
+/* Measured ceilings of the device (bench / diagnostics; blocks, allocates its own buffers, never on a process path).
+ * aw_context_bandwidth_probe: a read-only, a write-only and a copy kernel over `bytes` (>= 64 MiB) of HBM each, best of
+ * `repetitions`; GB/s, the copy's figure counting bytes read + bytes written.  SURVEY.md 8d asks for this next to the
+ * vendor peak the roofline is priced on.  aw_context_pcie_probe: page-locked host memory to the device, back, and both at
+ * once (GB/s; duplex = bytes both ways / time) — the yardstick for aw_spatializer_process_host. */
+AW_API aw_status aw_context_bandwidth_probe(aw_context *ctx, size_t bytes, int32_t repetitions, double *read_gbs,
+                                            double *write_gbs, double *copy_gbs);
+AW_API aw_status aw_context_pcie_probe(aw_context *ctx, size_t bytes, int32_t repetitions, double *h2d_gbs, double *d2h_gbs,
+                                       double *duplex_gbs);
+
 /* Device memory helpers for hosts without their own HIP bindings (Swift, ctypes). */
 AW_API aw_status aw_device_alloc(aw_context *ctx, size_t bytes, void **dptr);
 AW_API aw_status aw_device_free(aw_context *ctx, void *dptr);
 AW_API aw_status aw_memcpy_h2d(aw_context *ctx, void *dst_device, const void *src_host, size_t bytes);
 AW_API aw_status aw_memcpy_d2h(aw_context *ctx, void *dst_host, const void *src_device, size_t bytes);
+/* Page-locked host memory (hipHostMalloc): buffers from here cross PCIe by DMA, without the HIP runtime's staging copy, when
+ * handed to the host entries below.  The analogue of the caller-owned render buffers of AudioPipeline.swift:3-11. */
+AW_API aw_status aw_host_alloc_pinned(aw_context *ctx, size_t bytes, void **ptr);
+AW_API aw_status aw_host_free_pinned(aw_context *ctx, void *ptr);
 
 /* ---- HRIR set --------------------------------------------------------------------------------
  * The planar impulse responses a preset provides (WAVData.audioData, WAVLoader.swift:12-17):
@@ -103,8 +120,14 @@ AW_API void aw_spatializer_destroy(aw_spatializer *sp);
  * next call exactly like consecutive ConvolutionEngine.process calls.  Asynchronous on the
  * context stream. */
 AW_API aw_status aw_spatializer_process(aw_spatializer *sp, const float *in_device, float *out_device, int64_t frames);
-/* Same with HOST buffers (staged through device scratch; synchronous). */
+/* Same with HOST buffers; synchronous.  A multi-stream batch crosses PCIe in chunks of streams, double buffered on three HIP
+ * streams (H2D of chunk k+1 || kernels of chunk k || D2H of chunk k-1; streams are independent, so chunks are); page-locked
+ * buffers (aw_host_alloc_pinned) move by DMA directly, pageable ones through the HIP runtime's staging.  Small batches and
+ * single streams (the plug-in shaped calls of aw_engine_* / aw_realtime_*) go in one piece. */
 AW_API aw_status aw_spatializer_process_host(aw_spatializer *sp, const float *in_host, float *out_host, int64_t frames);
+/* aw_spatializer_reserve plus the device-side staging of the host entry for calls of up to max_frames frames (two chunks
+ * each way): afterwards aw_spatializer_process_host does not allocate either. */
+AW_API aw_status aw_spatializer_reserve_host(aw_spatializer *sp, int64_t max_frames);
 /* StereoAudioProcessing.process shape (AudioPipeline.swift:3-11) for a 1-stream, 2-channel
  * spatializer: planar HOST buffers, input_right may be NULL (mono duplication). Zero latency. */
 AW_API aw_status aw_spatializer_process_planar(aw_spatializer *sp, const float *input_left, const float *input_right,
@@ -122,7 +145,11 @@ AW_API int32_t aw_spatializer_channel_count(const aw_spatializer *sp);
  * (the interior-tile launch of the last call; the few boundary tiles are a second, untimed launch),
  * 6 bytes of grow-only internal device buffers currently allocated (sized by aw_spatializer_reserve or by the largest call so far),
  * 7 rows R of the last call's windows when it ran on the long-window kernels (windows of R x 4096 frames; 0: it ran on the
- *   fused / partitioned kernels that 0-3 describe).  The kernel set is chosen per call; results do not depend on it. */
+ *   fused / partitioned kernels that 0-3 describe).  The kernel set is chosen per call; results do not depend on it.
+ * 8 rows of the remainder window of a call that ran as two groups of windows, 9 long-window table sets built so far,
+ * 10 / 11 / 12 microseconds the last aw_spatializer_reserve spent on the float64 table build (host threads) / the table upload /
+ *   growing the context's scratch pool, 13 device or page-locked allocations and 14 blocking table uploads made so far on behalf
+ *   of the context's handles (a reserved process path makes neither), 15 streams per staged chunk of the last host-entry call. */
 AW_API int64_t aw_spatializer_info(const aw_spatializer *sp, int32_t what);
 /* Average device time of the dominant kernel over the launches since the last call (HIP events
  * on the context stream); used for bench.py's roofline object.  Returns launches counted. */
@@ -166,6 +193,10 @@ AW_API void aw_realtime_destroy(aw_realtime *p);
 AW_API aw_status aw_realtime_process(aw_realtime *p, const float *input_left, const float *input_right,
                                      float *left_output, float *right_output, int32_t frame_count);
 AW_API aw_status aw_realtime_reset(aw_realtime *p);
+/* Everything a callback needs is allocated by aw_realtime_create (RealtimeAudioProcessor.init, :30-62); this lets a host or a
+ * test check it: 0 bytes of host buffer capacity held, 1 bytes of grow-only device buffers, 2 device allocations made so far
+ * on the context.  None of them moves across aw_realtime_process calls. */
+AW_API int64_t aw_realtime_info(const aw_realtime *p, int32_t what);
 
 /* ---- host-side data model (no GPU needed) ----------------------------------------------------- */
 /* WAVLoader.load (WAVLoader.swift:26-99): any RIFF/WAVE -> planar float32. */

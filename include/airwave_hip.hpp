@@ -91,6 +91,8 @@ class Spatializer {
         check(aw_spatializer_process_planar(h_, inputLeft, inputRight, outputLeft, outputRight, frameCount));
     }
     void reserve(int64_t maxFrames) { check(aw_spatializer_reserve(h_, maxFrames)); }
+    void reserveHost(int64_t maxFrames) { check(aw_spatializer_reserve_host(h_, maxFrames)); }     // + the host entry's device-side staging
+    int64_t info(int32_t what) const { return aw_spatializer_info(h_, what); }
     void reset() { check(aw_spatializer_reset(h_)); }
     aw_spatializer *get() const { return h_; }
   private:
@@ -110,6 +112,7 @@ class RealtimeAudioProcessor {
         check(aw_realtime_process(h_, inputLeft, inputRight, leftOutput, rightOutput, frameCount));
     }
     void reset() { check(aw_realtime_reset(h_)); }                                                                            // :121
+    int64_t info(int32_t what) const { return aw_realtime_info(h_, what); }          // 0 host bytes, 1 device bytes, 2 device allocations: constant across process()
   private:
     aw_realtime *h_ = nullptr;
 };

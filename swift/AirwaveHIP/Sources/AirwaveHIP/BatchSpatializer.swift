@@ -41,6 +41,19 @@ public final class BatchSpatializer {
         guard st == AW_OK else { throw BatchSpatializer.error(st) }
     }
 
+    /// Host buffers: the batch crosses PCIe in chunks of streams, H2D of the next chunk and D2H of the previous one under the
+    /// kernels of the current one.  Page-locked buffers (`aw_host_alloc_pinned`) move by DMA directly.  Synchronous.
+    public func process(hostInput: UnsafePointer<Float>, hostOutput: UnsafeMutablePointer<Float>, frames: Int64) throws {
+        let st = aw_spatializer_process_host(handle, hostInput, hostOutput, frames)
+        guard st == AW_OK else { throw BatchSpatializer.error(st) }
+    }
+
+    /// `reserve` plus the host entry's device-side staging: `process(hostInput:…)` never allocates afterwards either.
+    public func reserveHost(maxFrames: Int64) throws {
+        let st = aw_spatializer_reserve_host(handle, maxFrames)
+        guard st == AW_OK else { throw BatchSpatializer.error(st) }
+    }
+
     public func reset() { _ = aw_spatializer_reset(handle) }
 
     static func error(_ st: aw_status) -> NSError {

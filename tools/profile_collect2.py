@@ -3,6 +3,8 @@
 bench_<w>.json (the bench line), kernel_stats_<w>.csv (rocprofv3 --stats), traffic_<w>.json (per-kernel fabric-side bytes
 per step from the TCC_EA0 request counters + SQ counters; bench.py reads it for roofline.traffic)."""
 import collections, csv, glob, json, os, shutil, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from airwave_amd.provenance import build_head, device_source_digest
 name, w = sys.argv[1], sys.argv[2]
 src = f"gpurun_out/profile_{name}/{w}"
 dst = os.path.join("profiles", name)
@@ -34,7 +36,7 @@ for k in kernels:
     by_kernel[k] = {"read_bytes_per_step": rd, "write_bytes_per_step": wr, "launches_per_step": len(pmc.get((k, "TCC_EA0_RDREQ_sum"), [])) / steps, "sq_per_step": sq}
     tot_r += rd; tot_w += wr
 cfg = line["config"]
-out = {"workload": w, "streams_per_gpu": cfg["streams_per_gpu"], "frames_per_stream": cfg["frames_per_stream"], "input_channels": cfg["input_channels"],
+out = {"workload": w, "device_src_sha16": device_source_digest(), "git_head": build_head(), "streams_per_gpu": cfg["streams_per_gpu"], "frames_per_stream": cfg["frames_per_stream"], "input_channels": cfg["input_channels"],
        "total_bytes_per_step": tot_r + tot_w, "read_bytes_per_step": tot_r, "write_bytes_per_step": tot_w,
        "algorithmic_bytes_per_step": line["roofline"]["algorithmic_bytes_per_step"],
        "ratio_to_algorithmic": (tot_r + tot_w) / line["roofline"]["algorithmic_bytes_per_step"],
@@ -47,7 +49,7 @@ print(json.dumps({k: v for k, v in out.items() if k != "by_kernel"}, indent=1))
 for k, v in by_kernel.items():
     print(f"{k:60s} R {v['read_bytes_per_step']/1e9:7.2f} GB  W {v['write_bytes_per_step']/1e9:7.2f} GB")
 r = line["roofline"]
-print("bench:", round(line["value"] / 1e9, 2), "G frames/s, frac", round(r["frac"], 4), "kernel_frac", round(r["kernel_frac"], 4), r["stages_ms_per_step"])
+print("bench:", round(line["value"] / 1e9, 2), "G frames/s, frac", round(r["frac"], 4), "frac_of_measured", r.get("frac_of_measured"), r.get("measured"), r["stages_ms_per_step"])
 if "secondary" in line:
     s2 = line["secondary"]; print("secondary:", round(s2["value"] / 1e9, 2), "G frames/s, frac", round(s2["roofline"]["frac"], 4), s2["roofline"]["stages_ms_per_step"])
 if "cpu_baseline" in line:

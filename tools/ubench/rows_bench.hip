@@ -2,7 +2,10 @@
 // 3.5 channel pairs, random rows and tables): a seconds-long A/B loop for variants of tile_lw16.hpp / tile_lw.hpp (timing only).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -fno-slp-vectorize -DAW_XA_REG=1 -DAW_LDS_ATOMIC_READS=1 -Iairwave_amd/csrc -Iinclude tools/ubench/rows_bench.hip -o tools/ubench/rows_bench
 //   -DRB_FORM=8: the 8-point kernel (rows1);  -DAW_STAMPS=1: per-phase s_memtime stamps of wave 0 (diagnostic; perturbs the timing)
-//   run: rows_bench [workgroups per CU] [streams]
+//   run: rows_bench [workgroups per CU] [streams] [sustain seconds]
+//   sustain > 0: launches back to back for that long first, then reports the IN-KERNEL clock of the last launches — every workgroup stamps
+//   s_memtime (shader cycles) and s_memrealtime (100 MHz) once before and once after its tile loop (outside the timed code; the stamps go to
+//   a buffer nothing else reads): clock = d(memtime) / d(memrealtime) x 100 MHz, median over workgroups (MI355X_MICROARCH.md, DVFS item 6)
 #include "device/tile_ols.hpp"
 #include "device/gpu_ctx.hpp"
 #include "device/tile_lw16.hpp"
@@ -23,8 +26,9 @@
 #endif
 namespace awk {
 #if RB_FORM == 16
-__global__ void __launch_bounds__(kR16Threads, AW_R16_MIN_WAVES) k_rows(LwParams p, long long n_sw, unsigned long long *dbg) {
+__global__ void __launch_bounds__(kR16Threads, AW_R16_MIN_WAVES) k_rows(LwParams p, long long n_sw, unsigned long long *dbg, unsigned long long *clk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     GpuCtx ctx{reinterpret_cast<cf *>(smem), dbg ? dbg + (long long)blockIdx.x * kStamps : nullptr};
     const int g = (int)gridDim.x, b = (int)blockIdx.x;
     const int xcd = b % 8, slot = b / 8;
@@ -32,11 +36,13 @@ __global__ void __launch_bounds__(kR16Threads, AW_R16_MIN_WAVES) k_rows(LwParams
     const int n_rp_x = (p.R / 2 - xcd + 7) / 8;
     lw_rows16_tiles<GpuCtx, RB_NP, RB_REAL>(ctx, p, (long long)slot, (long long)per_xcd_wg, (long long)n_rp_x * n_sw, n_sw, xcd, 8);
     ctx.flush_stamps();
+    if (clk && threadIdx.x == 0) { clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - c0; clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 constexpr int kThr = kR16Threads, kLds = kR16LdsBytes;
 #else
-__global__ void __launch_bounds__(kThreads, 4) k_rows(LwParams p, long long n_sw, unsigned long long *dbg) {
+__global__ void __launch_bounds__(kThreads, 4) k_rows(LwParams p, long long n_sw, unsigned long long *dbg, unsigned long long *clk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     GpuCtx ctx{reinterpret_cast<cf *>(smem), dbg ? dbg + (long long)blockIdx.x * kStamps : nullptr};
     const int g = (int)gridDim.x, b = (int)blockIdx.x;
     const int xcd = b % 8, slot = b / 8;
@@ -44,6 +50,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_rows(LwParams p, long long n_sw
     const int n_rp_x = (p.R / 2 - xcd + 7) / 8;
     lw_rows_tiles<GpuCtx, RB_NP, RB_REAL, 1>(ctx, p, (long long)slot, (long long)per_xcd_wg, (long long)n_rp_x * n_sw, n_sw, xcd, 8);
     ctx.flush_stamps();
+    if (clk && threadIdx.x == 0) { clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - c0; clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 constexpr int kThr = kThreads, kLds = lw_rows_lds_elems<1>() * 8;
 #endif
@@ -59,6 +66,7 @@ int main(int argc, char **argv) {
     using namespace awk;
     const int per_cu = argc > 1 ? atoi(argv[1]) : (RB_FORM == 16 ? 3 : 2);
     const int S = argc > 2 ? atoi(argv[2]) : 1024;
+    const double sustain = argc > 3 ? atof(argv[3]) : 0.0;
     const int R = 128; const long long N = (long long)R * kLwM;
     const int real_last = RB_REAL ? 1 : 0;
     LwParams p{};
@@ -86,10 +94,26 @@ int main(int argc, char **argv) {
 #endif
     CK(hipFuncSetAttribute((const void *)k_rows, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    unsigned long long *clk = nullptr;
+    CK(hipMalloc((void **)&clk, (size_t)grid * 16)); CK(hipMemset(clk, 0, (size_t)grid * 16));
+    if (sustain > 0) {          // the chip's clock governor settles over tens of milliseconds of a load: keep it loaded first
+        hipLaunchKernelGGL(k_rows, dim3(grid), dim3(kThr), kLds, 0, p, n_sw, dbg, clk);
+        CK(hipEventRecord(e0)); CK(hipEventSynchronize(e0));
+        const int per = 50;
+        double spent = 0;
+        while (spent < sustain) {
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < per; ++i) hipLaunchKernelGGL(k_rows, dim3(grid), dim3(kThr), kLds, 0, p, n_sw, dbg, clk);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            spent += ms * 1e-3;
+            printf("  sustained: %d launches, %.3f ms each\n", per, ms / per);
+        }
+    }
     float best = 1e9f, sum = 0; int cnt = 0;
     for (int it = 0; it < 7; ++it) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k_rows, dim3(grid), dim3(kThr), kLds, 0, p, n_sw, dbg);
+        hipLaunchKernelGGL(k_rows, dim3(grid), dim3(kThr), kLds, 0, p, n_sw, dbg, clk);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (it >= 2) { best = std::min(best, ms); sum += ms; ++cnt; }
@@ -98,6 +122,15 @@ int main(int argc, char **argv) {
     const double bytes = (double)n_spec * 8 + (double)n_w * 8;
     printf("rows kernel form %d <%d,%d> grid %u (%d per CU), %d stream-windows: best %.3f ms, mean %.3f ms, %.2f TB/s, %.2f us per tile per CU\n", RB_FORM, RB_NP, (int)RB_REAL,
            grid, per_cu, S, best, sum / cnt, bytes / best / 1e9, best * 1e3 / (n_tiles / 256.0));
+    {
+        std::vector<unsigned long long> hc((size_t)grid * 2);
+        CK(hipMemcpy(hc.data(), clk, hc.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<double> ghz;
+        for (unsigned g = 0; g < grid; ++g) if (hc[2 * g + 1] > 0) ghz.push_back((double)hc[2 * g] / (double)hc[2 * g + 1] * 0.1);
+        std::sort(ghz.begin(), ghz.end());
+        if (!ghz.empty()) printf("in-kernel clock (last launch; d s_memtime / d s_memrealtime x 100 MHz over each workgroup's whole tile loop): median %.3f GHz, p10 %.3f, p90 %.3f (%zu workgroups)\n",
+                                 ghz[ghz.size() / 2], ghz[ghz.size() / 10], ghz[ghz.size() * 9 / 10], ghz.size());
+    }
 #if AW_STAMPS
     std::vector<unsigned long long> h((size_t)grid * kStamps);
     CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));

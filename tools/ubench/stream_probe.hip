@@ -3,13 +3,16 @@
 //   mode 0: block = step * G + g            (workgroups that run together read neighbouring blocks: a streaming read)
 //   mode 1: block = g * steps + step        (every workgroup walks its own contiguous region)
 //   mode 2: the rows kernel's order         (row pair = xcd + 8 q fixed, stream-window varies fastest over the slots; 7 rows of a tile 4 MB apart)
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench/stream_probe.hip -o tools/ubench/stream_probe ; run: stream_probe [wgs per CU]
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench/stream_probe.hip -o tools/ubench/stream_probe ; run: stream_probe [wgs per CU] [random data 0|1] [sustain seconds]
+//   sustain > 0: each mode is launched back to back for that long first; the in-kernel clock of the last launch is reported like rows_bench does
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <vector>
 typedef float v2f __attribute__((ext_vector_type(2)));
-__global__ void __launch_bounds__(256, 3) k_probe(const v2f *buf, v2f *sink, long long n_blocks, int mode, long long n_sw) {
+__global__ void __launch_bounds__(256, 3) k_probe(const v2f *buf, v2f *sink, long long n_blocks, int mode, long long n_sw, unsigned long long *clk) {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     const long long G = gridDim.x, g = blockIdx.x;
     const long long steps = n_blocks / G;
     const int tid = threadIdx.x;
@@ -43,6 +46,7 @@ __global__ void __launch_bounds__(256, 3) k_probe(const v2f *buf, v2f *sink, lon
         for (int j = 0; j < 16; ++j) acc += v[j];
     }
     if (acc.x == 1.2345e-30f) sink[g * 256 + tid] = acc;
+    if (clk && tid == 0) { clk[2 * g] = __builtin_amdgcn_s_memtime() - c0; clk[2 * g + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 __global__ void k_fill(float *d, size_t n, unsigned seed) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -63,19 +67,36 @@ int main(int argc, char **argv) {
         CK(hipDeviceSynchronize());
     }
     const unsigned G = 256u * per_cu;
+    const double sustain = argc > 3 ? atof(argv[3]) : 0.0;
+    unsigned long long *clk; CK(hipMalloc((void **)&clk, (size_t)G * 16)); CK(hipMemset(clk, 0, (size_t)G * 16));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int mode = 0; mode < 3; ++mode) {
         const long long n_blocks = mode == 2 ? (n_sw * 64 * 7 / G) * G : n_blocks_total / G * G;
         float best = 1e9f;
+        for (double spent = 0; spent < sustain;) {
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(k_probe, dim3(G), dim3(256), 0, 0, buf, sink, n_blocks, mode, n_sw, clk);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            spent += ms * 1e-3;
+        }
         for (int it = 0; it < 5; ++it) {
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(k_probe, dim3(G), dim3(256), 0, 0, buf, sink, n_blocks, mode, n_sw);
+            hipLaunchKernelGGL(k_probe, dim3(G), dim3(256), 0, 0, buf, sink, n_blocks, mode, n_sw, clk);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (it >= 1) best = std::min(best, ms);
         }
         CK(hipGetLastError());
         printf("mode %d, %u workgroups (%d per CU): %.3f ms for %.2f GB -> %.2f TB/s\n", mode, G, per_cu, best, n_blocks * 32768.0 / 1e9, n_blocks * 32768.0 / best / 1e9);
+        {
+            std::vector<unsigned long long> hc((size_t)G * 2);
+            CK(hipMemcpy(hc.data(), clk, hc.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<double> ghz;
+            for (unsigned g = 0; g < G; ++g) if (hc[2 * g + 1] > 0) ghz.push_back((double)hc[2 * g] / (double)hc[2 * g + 1] * 0.1);
+            std::sort(ghz.begin(), ghz.end());
+            if (!ghz.empty()) printf("  in-kernel clock: median %.3f GHz, p10 %.3f, p90 %.3f\n", ghz[ghz.size() / 2], ghz[ghz.size() / 10], ghz[ghz.size() * 9 / 10]);
+        }
     }
     return 0;
 }
