@@ -29,6 +29,7 @@ SOURCES = [
     "device/ols2_even_kernels.hip",
     "device/eq_kernels.hip",
     "device/probe_kernels.hip",
+    "device/prep_kernels.hip",
     "runtime.cpp",
     "eq_runtime.cpp",
     "host/eq.cpp",

@@ -55,6 +55,13 @@ hipError_t launch_synth_fill(float *dst, int n_streams, long long per_stream, un
 hipError_t launch_interleave2(const float *left, const float *right, float *dst, int frames, hipStream_t stream);
 hipError_t launch_deinterleave2(const float *src, float *left, float *right, int frames, hipStream_t stream);
 
+// HRIR prep on the device (prep_kernels.hip): the long-window filter tables of one window length R x 4096 in the 16-point rows kernel's
+// layout, float64 on the GPU.  d_scratch: lw_prep_scratch_bytes() of temporary device memory; everything is queued on `stream`.
+size_t lw_prep_scratch_bytes(int n_channels, int R);
+hipError_t prepare_prep_kernels();
+hipError_t launch_lw_prep(const float *d_tracks, int n_tracks, int taps, int n_channels, const int *d_left, const int *d_right, int R,
+                          void *d_scratch, LwTab2 *d_tab16, hipStream_t stream);
+
 // Measured-ceiling probe (probe_kernels.hip; aw_context_bandwidth_probe): what 0 read / 1 write / 2 copy over `bytes` of src / dst
 hipError_t launch_bw_probe(int what, bool nt, const void *src, void *dst, size_t bytes, int cus, float *sink, hipStream_t stream, size_t *bytes_moved);
 
@@ -71,6 +78,7 @@ struct LaunchCfg {
     int lw_rows_form = 16;        // long-window rows kernel: 16 = 256-thread workgroups, 16 points of one row per thread (tile_lw16.hpp); 8 = the 8-point forms (AW_LW_ROWS_FORM)
     int lw_rows16_wgs = 3;        // workgroups per CU of the 16-point rows kernel's persistent grid (AW_LW_ROWS16_WGS)
     int hop_align = 64;           // fused windows start on multiples of this many frames (AW_HOP_ALIGN; 1 = off)
+    int lw_tables_on_gpu = 1;     // long-window filter tables built by the prep kernels (prep_kernels.hip); 0 = the float64 host builder (AW_LW_TABLES=host)
     int host_chunk_mb = 96;       // host entry of a multi-stream batch: input megabytes per staged chunk of streams (AW_HOST_CHUNK_MB; a few ms of PCIe Gen5 = the pipeline's fill / drain)
 };
 hipError_t prepare_kernels(LaunchCfg *cfg);   // fills cfg from the current device + environment; sets the dynamic-LDS attribute on every tile kernel

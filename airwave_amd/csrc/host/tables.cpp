@@ -162,13 +162,13 @@ static void fft_any(std::vector<cd> &a, const std::vector<cd> &unit_n) {
 // false: host memory ran out (a worker's or this thread's std::bad_alloc, or no thread could be started) — nothing throws across the
 // C ABI, every worker is joined on every path, and the caller maps the failure to AW_ERR_OUT_OF_MEMORY.
 static void build_lw_tables_impl(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
-                                 const int32_t *right_track, int R, LwTables &out, int rows_form, std::atomic<bool> &failed);
+                                 const int32_t *right_track, int R, LwTables &out, int rows_form, bool filters, std::atomic<bool> &failed);
 
 bool build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
-                     const int32_t *right_track, int R, LwTables &out, int rows_form) {
+                     const int32_t *right_track, int R, LwTables &out, int rows_form, bool filters) {
     std::atomic<bool> failed{false};
     try {
-        build_lw_tables_impl(tracks, n_tracks, taps, n_channels, left_track, right_track, R, out, rows_form, failed);
+        build_lw_tables_impl(tracks, n_tracks, taps, n_channels, left_track, right_track, R, out, rows_form, filters, failed);
     } catch (...) {
         failed = true;
     }
@@ -176,7 +176,7 @@ bool build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels
 }
 
 static void build_lw_tables_impl(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
-                                 const int32_t *right_track, int R, LwTables &out, int rows_form, std::atomic<bool> &failed) {
+                                 const int32_t *right_track, int R, LwTables &out, int rows_form, bool filters, std::atomic<bool> &failed) {
     const int M = awk::kLwM;
     const size_t N = (size_t)R * M;
     const int n_pairs = (n_channels + 1) / 2;
@@ -198,18 +198,20 @@ static void build_lw_tables_impl(const float *tracks, int n_tracks, int taps, in
         for (int j1 = 0; j1 < 8; ++j1) out.tw_r[(size_t)ka * 8 + j1] = unit((double)j1 * (2 * ka + 1), 2.0 * R);
     out.tw1m.resize(512);
     for (int t = 0; t < 512; ++t) out.tw1m[t] = unit((double)t, (double)M);
+    out.tab.clear(); out.tab16.clear(); out.tw2.clear();
+    if (rows_form == 16) {
+        out.tw2.resize(256);
+        for (int m0 = 0; m0 < 16; ++m0)
+            for (int a = 0; a < 16; ++a) out.tw2[(size_t)m0 * 16 + a] = unit((double)a * m0, 256.0);
+    }
+    if (!filters) return;
     // filter tables
     std::vector<cd> unit_n(N), mod(N);
     for (size_t k = 0; k < N; ++k) { const double a = -2.0 * M_PI * (double)k / (double)N; unit_n[k] = cd(std::cos(a), std::sin(a)); }
     for (size_t n = 0; n < N; ++n) { const double a = -M_PI * (double)n / (double)N; mod[n] = cd(std::cos(a), std::sin(a)); }     // w_N^{n/2}
     const bool form16 = rows_form == 16;
-    out.tab.clear(); out.tab16.clear(); out.tw2.clear();
     if (form16) {
         out.tab16.assign((size_t)(R / 2) * n_pairs * 2 * M, awk::LwTab2{awk::mk(0, 0), awk::mk(0, 0)});
-        out.tw2.resize(256);
-        for (int m0 = 0; m0 < 16; ++m0)
-            for (int a = 0; a < 16; ++a) out.tw2[(size_t)m0 * 16 + a] = unit((double)a * m0, 256.0);
-        // position of row bin k2 in thread order
     } else {
         out.tab.assign((size_t)(R / 2) * n_pairs * M, awk::LwTab{awk::mk(0, 0), awk::mk(0, 0), awk::mk(0, 0), awk::mk(0, 0)});
     }

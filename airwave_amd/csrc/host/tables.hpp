@@ -51,7 +51,8 @@ struct LwTables {
     std::vector<awk::LwTab2> tab16;
     std::vector<awk::cf> coarse, fine, step, tw_r, tw1m, tw2;
 };
+// filters = false: only the small twiddle tables (the filter tables then come from the device: device/prep_kernels.hip)
 bool build_lw_tables(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
-                     const int32_t *right_track, int R, LwTables &out, int rows_form = 8);
+                     const int32_t *right_track, int R, LwTables &out, int rows_form = 8, bool filters = true);
 
 }  // namespace awh

@@ -95,6 +95,7 @@ static aw_status context_create_impl(int32_t device, void *ext_stream, bool use_
     if (e == hipSuccess) e = awk::prepare_kernels(&c->cfg);
     if (e == hipSuccess) e = awk::prepare_lw_kernels();
     if (e == hipSuccess) e = awk::prepare_eq_kernels();
+    if (e == hipSuccess) e = awk::prepare_prep_kernels();
     awh::Twiddles tw;
     awh::build_twiddles(tw);
     auto upload = [&](const std::vector<awk::cf> &v, awk::cf **d) -> hipError_t {
@@ -460,6 +461,9 @@ void aw_spatializer_destroy(aw_spatializer *sp) {
     for (int i = 0; i < 2; ++i)
         if (sp->d_hist[i]) (void)hipFree(sp->d_hist[i]);
     if (sp->d_tail) (void)hipFree(sp->d_tail);
+    if (sp->d_lw_tracks) (void)hipFree(sp->d_lw_tracks);
+    if (sp->d_lw_left) (void)hipFree(sp->d_lw_left);
+    if (sp->d_lw_right) (void)hipFree(sp->d_lw_right);
     for (auto &pl : sp->lw_plans) {
         if (pl.d_tab) (void)hipFree(pl.d_tab);
         if (pl.d_tab16) (void)hipFree(pl.d_tab16);
@@ -856,10 +860,14 @@ static aw_status lw_get_plan(aw_spatializer *sp, int R, const aw_spatializer::Lw
         if (pl.R == R) { *out = &pl; return AW_OK; }
     awh::LwTables t;
     const int form = sp->ctx->cfg.lw_rows_form;          // which rows kernel the tables are laid out for (read once per context)
+    // The filter tables of the 16-point rows kernel are computed ON THE DEVICE (device/prep_kernels.hip: float64, the analogue of the
+    // partition FFTs of ConvolutionEngine.init, ConvolutionEngine.swift:141-175); the host builds only the small twiddle tables then.
+    // AW_LW_TABLES=host (read at context creation) or the 8-point kernel forms: the float64 host builder computes everything.
+    const bool on_gpu = form == 16 && sp->ctx->cfg.lw_tables_on_gpu != 0;
     const auto t_build = std::chrono::steady_clock::now();
-    if (!awh::build_lw_tables(sp->lw_tracks.data(), sp->lw_n_tracks, sp->taps, sp->n_channels, sp->lw_left.data(), sp->lw_right.data(), R, t, form))
+    if (!awh::build_lw_tables(sp->lw_tracks.data(), sp->lw_n_tracks, sp->taps, sp->n_channels, sp->lw_left.data(), sp->lw_right.data(), R, t, form, /*filters=*/!on_gpu))
         return fail(AW_ERR_OUT_OF_MEMORY, "long-window tables: host memory");      // (the caller falls back to the kernels that have always served the spatializer)
-    const auto t_up = std::chrono::steady_clock::now();
+    auto t_up = std::chrono::steady_clock::now();
     sp->reserve_tables_us += std::chrono::duration_cast<std::chrono::microseconds>(t_up - t_build).count();
     aw_spatializer::LwPlan pl;
     pl.R = R;
@@ -870,7 +878,27 @@ static aw_status lw_get_plan(aw_spatializer *sp, int R, const aw_spatializer::Lw
         return hipMemcpy(*d, src, bytes, hipMemcpyHostToDevice);
     };
     hipError_t e = hipSuccess;
-    if (form == 16) {
+    if (on_gpu) {
+        const int n_pairs = (sp->n_channels + 1) / 2;
+        if (!sp->d_lw_tracks) {              // the impulse responses and the channel map, once per spatializer
+            e = up(sp->lw_tracks.data(), sp->lw_tracks.size() * sizeof(float), reinterpret_cast<void **>(&sp->d_lw_tracks));
+            if (e == hipSuccess) e = up(sp->lw_left.data(), sp->lw_left.size() * sizeof(int32_t), reinterpret_cast<void **>(&sp->d_lw_left));
+            if (e == hipSuccess) e = up(sp->lw_right.data(), sp->lw_right.size() * sizeof(int32_t), reinterpret_cast<void **>(&sp->d_lw_right));
+        }
+        void *d_tmp = nullptr;
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl.d_tab16), (size_t)(R / 2) * n_pairs * 2 * awk::kLwM * sizeof(awk::LwTab2));
+        if (e == hipSuccess) e = hipMalloc(&d_tmp, awk::lw_prep_scratch_bytes(sp->n_channels, R));
+        if (e == hipSuccess) {
+            sp->ctx->device_allocs += 2;
+            e = awk::launch_lw_prep(sp->d_lw_tracks, sp->lw_n_tracks, sp->taps, sp->n_channels, sp->d_lw_left, sp->d_lw_right, R, d_tmp, pl.d_tab16, sp->ctx->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(sp->ctx->stream);
+        if (d_tmp) (void)hipFree(d_tmp);
+        const auto t_gpu = std::chrono::steady_clock::now();
+        sp->reserve_tables_us += std::chrono::duration_cast<std::chrono::microseconds>(t_gpu - t_up).count();
+        t_up = t_gpu;
+        if (e == hipSuccess) e = up(t.tw2.data(), t.tw2.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_tw2));
+    } else if (form == 16) {
         e = up(t.tab16.data(), t.tab16.size() * sizeof(awk::LwTab2), reinterpret_cast<void **>(&pl.d_tab16));
         if (e == hipSuccess) e = up(t.tw2.data(), t.tw2.size() * sizeof(awk::cf), reinterpret_cast<void **>(&pl.d_tw2));
     } else {

@@ -80,6 +80,8 @@ struct aw_spatializer {
     std::vector<float> lw_tracks;       // the HRIR and channel map, kept for the lazily built tables
     std::vector<int32_t> lw_left, lw_right;
     int lw_n_tracks = 0;
+    float *d_lw_tracks = nullptr;       // device copies of the same for the prep kernels (device/prep_kernels.hip), made with the first table set
+    int32_t *d_lw_left = nullptr, *d_lw_right = nullptr;
     float *d_tail = nullptr;            // 32 floats: the last frame of the last stream of a call + zeros (wide split kernel, tile_lw.hpp)
     int last_lw_R = 0;                  // R of the last call's (first group of) windows (0: the partitioned kernels ran)
     int last_lw_R2 = 0;                 // R of its remainder window when the call ran as two groups

@@ -352,3 +352,33 @@ def test_imported_long_tap_wav_through_preset_activation(aw, oracle, tmp_path, f
     assert tracks.shape == (14, taps)
     for s in range(2):
         assert oracle.peak_rel_error(y[s], oracle.spatialize_f64(x[s], tracks, lt, rt)) < TOL
+
+
+@pytest.mark.parametrize("rows,channels,taps,unmap", [(64, 7, 32768, None), (40, 14, 20000, None), (128, 2, 32768, None), (56, 5, 20000, 2), (96, 16, 20000, 9), (32, 1, 9000, None)])
+def test_device_built_tables_match_the_host_builder(aw, oracle, monkeypatch, rows, channels, taps, unmap):
+    """The HRIR-prep kernels (device/prep_kernels.hip: float64 on the GPU, the analogue of the partition FFTs of ConvolutionEngine.init,
+    ConvolutionEngine.swift:141-175) against the float64 host builder (AW_LW_TABLES=host, the builder the CPU emulation tests run on):
+    same samples to float32 rounding of the tables, and both within tolerance of the float64 oracle.  Odd channel counts (the folded real
+    last channel), 14 and 16 channels, an unmapped speaker, window lengths that are not powers of two."""
+    monkeypatch.setenv("AW_LW", str(rows))
+    S = 2
+    h = oracle.synth_hrir(14, taps, seed=31)
+    lt, rt = _maps(channels)
+    if unmap is not None:
+        lt, rt = lt.copy(), rt.copy()
+        lt[unmap] = -1                                        # a speaker without a mapping is skipped (HRIRManager.swift:370-372)
+    ys, x = {}, None
+    for mode in ("host", "gpu"):
+        monkeypatch.setenv("AW_LW_TABLES", mode)             # read once, at context creation
+        ctx = aw.Context(0)
+        sp = aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=S, ctx=ctx)
+        if x is None:
+            F = rows * 4096 - sp.info()["history"] + 20000   # two windows
+            x = oracle.synth_input(S, F, channels, seed=8)
+        ys[mode] = sp.process(x)
+        assert sp.info()["long_window_rows"] == rows, sp.info()
+    ref = oracle.spatialize_f64(x[1], h, lt, rt)
+    peak = np.max(np.abs(ref))
+    assert np.max(np.abs(ys["gpu"][1] - ys["host"][1])) <= 2e-6 * peak
+    for mode in ys:
+        assert oracle.peak_rel_error(ys[mode][1], ref) < TOL, mode
