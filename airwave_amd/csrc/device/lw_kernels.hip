@@ -17,9 +17,7 @@ __global__ void __launch_bounds__(kThreads) aw_lw_rows_kernel(LwParams p, long l
     const int g = (int)gridDim.x, b = (int)blockIdx.x;
     const int xcd = b % 8, slot = b / 8;
     const int per_xcd_wg = (g - xcd + 7) / 8;
-    const int n_rp = p.R / 2;
-    const int n_rp_x = (n_rp - xcd + 7) / 8;
-    lw_rows_tiles<GpuCtx, NP, REAL_LAST>(ctx, p, (long long)slot, (long long)per_xcd_wg, (long long)n_rp_x * n_sw, n_sw, xcd, 8);
+    lw_rows_tiles<GpuCtx, NP, REAL_LAST>(ctx, p, (long long)slot, (long long)per_xcd_wg, n_sw, xcd, 8);
 }
 
 // PB = 1: one exchange buffer, two workgroups per CU
@@ -30,9 +28,7 @@ __global__ void __launch_bounds__(kThreads, 4) aw_lw_rows1_kernel(LwParams p, lo
     const int g = (int)gridDim.x, b = (int)blockIdx.x;
     const int xcd = b % 8, slot = b / 8;
     const int per_xcd_wg = (g - xcd + 7) / 8;
-    const int n_rp = p.R / 2;
-    const int n_rp_x = (n_rp - xcd + 7) / 8;
-    lw_rows_tiles<GpuCtx, NP, REAL_LAST, 1>(ctx, p, (long long)slot, (long long)per_xcd_wg, (long long)n_rp_x * n_sw, n_sw, xcd, 8);
+    lw_rows_tiles<GpuCtx, NP, REAL_LAST, 1>(ctx, p, (long long)slot, (long long)per_xcd_wg, n_sw, xcd, 8);
 }
 
 // 16 points of one row per thread, 256-thread workgroups (tile_lw16.hpp); the same XCD pinning of row pairs
@@ -46,9 +42,7 @@ __global__ void __launch_bounds__(kR16Threads, AW_R16_MIN_WAVES) aw_lw_rows16_ke
     const int g = (int)gridDim.x, b = (int)blockIdx.x;
     const int xcd = b % 8, slot = b / 8;
     const int per_xcd_wg = (g - xcd + 7) / 8;
-    const int n_rp = p.R / 2;
-    const int n_rp_x = (n_rp - xcd + 7) / 8;
-    lw_rows16_tiles<GpuCtx, NP, REAL_LAST>(ctx, p, (long long)slot, (long long)per_xcd_wg, (long long)n_rp_x * n_sw, n_sw, xcd, 8);
+    lw_rows16_tiles<GpuCtx, NP, REAL_LAST>(ctx, p, (long long)slot, (long long)per_xcd_wg, n_sw, xcd, 8);
 }
 
 template <int RA>

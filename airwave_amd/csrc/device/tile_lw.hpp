@@ -534,12 +534,38 @@ AW_HD void lw_powers8(cf w, cf (&pw)[8]) {
 // Virtual tile id vid -> (row pair, stream-window): rp = rp0 + rp_step * (vid / n_sw), sw = vid % n_sw.  The GPU kernel
 // gives every XCD the row pairs rp = xcd (mod 8), walked one after the other: the 32 workgroups of an XCD work on the
 // same row pair at a time and its 512 KB table slice stays in their L2.
+// Window lengths whose row-pair count is not a multiple of the group count (R = 40, 56, 72, 120: R/2 = 4 mod 8) leave `left` row
+// pairs over after the whole rounds; those are dealt to ALL groups in equal shares of their (row pair, stream-window) tiles — group g
+// takes the tiles [g L / groups, (g + 1) L / groups) of the L left-over tiles in row-pair-major order, so it still works on one table slice at a
+// time (two at most) — instead of handing whole pairs to the first `left` groups (which then ran 8 row pairs against 7 at R = 120,
+// and the launch as long as the fullest group: round-4 advisor finding).
 struct LwRowTile { int rp; long long sw; };
-AW_HD LwRowTile lw_row_tile(long long vid, long long n_sw, int rp0, int rp_step) {
+struct LwRowMap { long long n_sw, full, left_lo, left_hi; int rp0, rp_step, rp_left; };
+AW_HD LwRowMap lw_row_map(long long n_sw, int n_rp, int rp0, int rp_step) {
+    LwRowMap m;
+    const int rounds = n_rp / rp_step, left = n_rp % rp_step;
+    m.n_sw = n_sw; m.rp0 = rp0; m.rp_step = rp_step;
+    m.full = (long long)rounds * n_sw;
+    m.rp_left = rounds * rp_step;
+    const long long left_tiles = (long long)left * n_sw;
+    m.left_lo = left_tiles * rp0 / rp_step;               // group g: tiles [g L / groups, (g + 1) L / groups) of the left-over pairs
+    m.left_hi = left_tiles * (rp0 + 1) / rp_step;
+    return m;
+}
+// virtual tiles of this group: its whole rounds, then its share of the left-over row pairs
+AW_HD long long lw_row_count(const LwRowMap &m) { return m.full + (m.left_hi - m.left_lo); }
+AW_HD LwRowTile lw_row_tile(const LwRowMap &m, long long vid) {
     LwRowTile r;
-    const long long q = vid / n_sw;
-    r.rp = rp0 + rp_step * (int)q;
-    r.sw = vid - q * n_sw;
+    if (vid < m.full) {
+        const long long q = vid / m.n_sw;
+        r.rp = m.rp0 + m.rp_step * (int)q;
+        r.sw = vid - q * m.n_sw;
+    } else {
+        const long long l = m.left_lo + (vid - m.full);
+        const long long q = l / m.n_sw;
+        r.rp = m.rp_left + (int)q;
+        r.sw = l - q * m.n_sw;
+    }
     return r;
 }
 
@@ -548,10 +574,12 @@ AW_HD LwRowTile lw_row_tile(long long vid, long long n_sw, int rp0, int rp_step)
 template <int PB> constexpr int lw_rows_lds_elems() { return PB * kBufElems + kTwaElems + kTwbElems; }
 
 template <class Ctx, int NP, bool REAL_LAST, int PB = 2>
-AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long step, long long end, long long n_sw, int rp0, int rp_step) {
+AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long step, long long n_sw, int rp0, int rp_step) {
     static_assert(NP >= 1 && NP <= 8, "channel pairs");
     static_assert(PB == 1 || PB == 2, "pairs per batch");
     constexpr int NB = (NP + PB - 1) / PB;
+    const LwRowMap rmap = lw_row_map(n_sw, p.R / 2, rp0, rp_step);
+    const long long end = lw_row_count(rmap);
     if (first >= end) return;
     const int t0 = ctx.tid();
     int t = t0, lane = ctx.lane();
@@ -567,7 +595,7 @@ AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long
 
     cf raw[PB][2][8];         // [pair of the batch][row ra / rb][j2]: row samples t + 512 j2
     auto load_batch = [&](long long vid, int b) {
-        const LwRowTile tl = lw_row_tile(vid, n_sw, rp0, rp_step);
+        const LwRowTile tl = lw_row_tile(rmap, vid);
         const cf *spec_sw = p.spec + tl.sw * p.spec_per_sw;
 #pragma unroll
         for (int h = 0; h < PB; ++h) {
@@ -590,7 +618,7 @@ AW_HD void lw_rows_tiles(Ctx &ctx, const LwParams &p, long long first, long long
     for (long long vid = first; vid < end; vid += step) {
         t = ctx.opaque_i(t0);                          // keeps lane-dependent addresses from living across the tile loop
         lane = t & 63;
-        const LwRowTile tl = lw_row_tile(vid, n_sw, rp0, rp_step);
+        const LwRowTile tl = lw_row_tile(rmap, vid);
         cf wacc[2][8];                                 // W1, W2 of this wave's inner row: bins q2 = lane + 64 kc
 #pragma unroll
         for (int s = 0; s < 2; ++s)

@@ -197,9 +197,11 @@ template <bool AFTER_INVERSE, class Ctx> AW_HD void r16_inverse(Ctx &ctx, cf (&v
 
 // Tiles as in lw_rows_tiles: virtual id -> (row pair, stream-window), row pairs pinned to XCDs by the launcher.
 template <class Ctx, int NP, bool REAL_LAST>
-AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long long step, long long end, long long n_sw, int rp0, int rp_step) {
+AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long long step, long long n_sw, int rp0, int rp_step) {
     static_assert(NP >= 1 && NP <= 8, "channel pairs");
     constexpr int NROWS = 2 * NP - (REAL_LAST ? 1 : 0);           // forward row transforms per tile
+    const LwRowMap rmap = lw_row_map(n_sw, p.R / 2, rp0, rp_step);
+    const long long end = lw_row_count(rmap);
     if (first >= end) return;
     const int tid = ctx.tid(), lane = ctx.lane(), wave = ctx.wave();
     const int a = lane & 15, b = (lane >> 4) + 4 * wave, nth = tid;        // nth = a + 16 b
@@ -244,9 +246,9 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
 #endif
         }
     };
-    if (AW_R16_ORDER != 2) load_row(row_src(lw_row_tile(first, n_sw, rp0, rp_step), 0), raw);
+    if (AW_R16_ORDER != 2) load_row(row_src(lw_row_tile(rmap, first), 0), raw);
     for (long long vid = first; vid < end; vid += step) {
-        const LwRowTile tl = lw_row_tile(vid, n_sw, rp0, rp_step);
+        const LwRowTile tl = lw_row_tile(rmap, vid);
 #if defined(AW_STAMPS) && AW_STAMPS
         ctx.stamp_on_ = (vid - first) / step == AW_R16_STAMP_TILE;       // diagnostic builds: one mid-kernel tile
 #endif
@@ -269,7 +271,7 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
             constexpr bool kTabEarly = AW_R16_ORDER == 3;             // all sixteen entries requested before the transform (64 registers)
             LwTab2 T[kTabEarly ? 16 : 1];
             // the next row (of this tile, or the first one of the next tile; the last tile re-reads its own)
-            const cf *next_src = idx + 1 < NROWS ? row_src(tl, idx + 1) : row_src(lw_row_tile(vid + step < end ? vid + step : vid, n_sw, rp0, rp_step), 0);
+            const cf *next_src = idx + 1 < NROWS ? row_src(tl, idx + 1) : row_src(lw_row_tile(rmap, vid + step < end ? vid + step : vid), 0);
             auto prefetch_next = [&](int j0 = 0, int j1 = 16) { load_row(next_src, raw, j0, j1); };
             // AW_R16_SPREAD = n > 1: the sixteen requests of the next row leave in n groups between the phases of this row's transform
             constexpr int NSPREAD = AW_R16_SPREAD > 1 ? AW_R16_SPREAD : 1;

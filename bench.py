@@ -38,12 +38,16 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.
                                # box of this run (read-only / write-only / copy kernels, aw_context_bandwidth_probe) are reported next to it: roofline.measured
 FP32_PEAK_TFLOPS = 157.3
 
+# Warm-up: the chip's clock governor takes ~25 ms of a load to settle (profiles/round5_v1/warmup_study.txt: cfg 2 on one box, same binary,
+# 3 + 20 steps of 1.3 ms: 47.0 G frames/s; 20 + 50: 50.9; 100 + 200 ... 1000 + 1000: 50.9 - 51.1).  Workloads whose step is a millisecond
+# or less therefore warm up for >= 60 ms and time >= 0.2 s (rounds 1-4 timed cfg 2 over 3 + 20 steps, i.e. on a ramping clock: the same
+# kernel read 0.2307 there and reads 0.2546 in steady state); steps of 10 ms and more settle within their first step.
 WORKLOADS = {
-    "cfg1": dict(streams=1, channels=2, hrir="NeutralSH1.0.wav", taps=4320, seconds=10.0, steps=20, warmup=3,
+    "cfg1": dict(streams=1, channels=2, hrir="NeutralSH1.0.wav", taps=4320, seconds=10.0, steps=5000, warmup=3000,
                  desc="cfg1: stereo 48 kHz -> NeutralSH1.0, 1 stream (plumbing)"),
-    "cfg2": dict(streams=128, channels=8, hrir="RoomSH1.0.wav", taps=4320, seconds=10.0, steps=20, warmup=3,
+    "cfg2": dict(streams=128, channels=8, hrir="RoomSH1.0.wav", taps=4320, seconds=10.0, steps=200, warmup=60,
                  desc="cfg2: 7.1 (8ch) 48 kHz -> RoomSH1.0 14-track HeSuVi HRIR, 128-stream batch x 10 s"),
-    "cfg2-14ch": dict(streams=128, channels=14, hrir="RoomSH1.0.wav", taps=4320, seconds=10.0, steps=20, warmup=3, text_map="hesuvi14_custom_map.txt",
+    "cfg2-14ch": dict(streams=128, channels=14, hrir="RoomSH1.0.wav", taps=4320, seconds=10.0, steps=150, warmup=40, text_map="hesuvi14_custom_map.txt",
                       desc="cfg2, 14-ch-input reading (north_star's literal case): InputLayout.detect(14) custom channels through the committed "
                            "parseHeSuViFormat text map -> RoomSH1.0 14-track HeSuVi HRIR (4320 taps), 128-stream batch x 10 s"),
     # (cfg 3: 10 warm-up steps — the chip's clock governor needs ~30 ms of this load to settle: 1.6 -> 1.84 GHz over the first launches)
@@ -509,7 +513,10 @@ def end_to_end(name: str, args, ctx, streams: int = 0, pcie: dict = None):
     F = int(round((args.seconds or wl["seconds"]) * rate))
     tracks, _ = load_hrir(wl["hrir"], wl["taps"])
     layout = aw.InputLayout.detect(C) if C != 7 else aw.InputLayout(SPEAKERS7, "7 speakers")
-    batch = aw.MixedRateBatch(tracks, 48000.0, layout, [rate] * S, ctx=ctx)
+    cmap = None
+    if wl.get("text_map"):
+        cmap = aw.HRIRChannelMap.parseHeSuViFormat(open(os.path.join(ROOT, "tests", "golden", wl["text_map"])).read())
+    batch = aw.MixedRateBatch(tracks, 48000.0, layout, [rate] * S, hrirMap=cmap, ctx=ctx)
     sp = batch.buckets[float(rate)].spatializer
     x_dev = torch.empty((S, F, C), dtype=torch.float32, device="cuda")
     ctx.synth_fill(x_dev.data_ptr(), S, F, C, seed=0xA17AE, first_stream=0)

@@ -39,6 +39,8 @@ def lib():
                                          ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
         _lib.emu_longwin.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
                                      ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
+        _lib.emu_lw_row_map.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ip, ctypes.POINTER(ctypes.c_longlong)]
+        _lib.emu_lw_row_map.restype = ctypes.c_longlong
         _lib.emu_fft_small.argtypes = [fp, ctypes.c_int, ctypes.c_int]
         _lib.emu_sub_fft512h.argtypes = [fp, fp, fp]
         _lib.emu_lw_dft.argtypes = [fp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -157,3 +159,12 @@ def eq_tables(sample_rate, preamp_db, filters):
                              ctypes.byref(td), ctypes.byref(ch))
     assert rc == K, rc
     return tab, plane, ch.value
+
+
+def lw_row_map(n_rp: int, n_sw: int, groups: int = 8):
+    """(visits per (row pair, stream-window), tiles per XCD group) of the rows kernels' tile map (tile_lw.hpp: lw_row_map / lw_row_tile)."""
+    hits = np.zeros((n_rp, n_sw), dtype=np.int32)
+    per = np.zeros(groups, dtype=np.int64)
+    total = lib().emu_lw_row_map(n_rp, n_sw, groups, hits.ctypes.data_as(ip), per.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)))
+    assert total == n_rp * n_sw, total
+    return hits, per

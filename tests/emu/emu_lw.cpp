@@ -111,12 +111,11 @@ int emu_longwin(const float *in, float *out, const float *hist, const float *tra
         }
     };
     with_ra([&](auto RA) { emu_lw_split_or_merge<decltype(RA)::value>(p, n_sw, false); });
-    const long long n_rt = n_sw * (R / 2);
     auto rows = [&](auto PBB) {
         constexpr int pb = decltype(PBB)::value;
         run([&](EmuCtx &ctx) {
             auto go = [&](auto NPP, auto REAL) {
-                lw_rows_tiles<EmuCtx, decltype(NPP)::value, (decltype(REAL)::value != 0), (decltype(NPP)::value > 4 ? 1 : pb)>(ctx, p, 0, 1, n_rt, n_sw, 0, 1);
+                lw_rows_tiles<EmuCtx, decltype(NPP)::value, (decltype(REAL)::value != 0), (decltype(NPP)::value > 4 ? 1 : pb)>(ctx, p, 0, 1, n_sw, 0, 1);
             };
             const int np = p.n_pairs;
             auto go_np = [&](auto REAL) {
@@ -136,7 +135,7 @@ int emu_longwin(const float *in, float *out, const float *hist, const float *tra
             th.emplace_back([&, t]() {
                 EmuCtx ctx{t, &sh16};
                 auto go = [&](auto NPP, auto REAL) {
-                    lw_rows16_tiles<EmuCtx, decltype(NPP)::value, (decltype(REAL)::value != 0)>(ctx, p, 0, 1, n_rt, n_sw, 0, 1);
+                    lw_rows16_tiles<EmuCtx, decltype(NPP)::value, (decltype(REAL)::value != 0)>(ctx, p, 0, 1, n_sw, 0, 1);
                 };
                 auto go_np = [&](auto REAL) {
                     switch (p.n_pairs) {
@@ -170,6 +169,29 @@ int emu_lw_dft(float *data, int n, int inverse, int odd) {
         default: return -1;
     }
     return 0;
+}
+
+
+// The rows kernels' tile map over `groups` XCD groups (lw_row_map / lw_row_tile / lw_row_count, tile_lw.hpp): writes how often every
+// (row pair, stream-window) is visited to hits[n_rp][n_sw] and every group's tile count to per_group[groups]; returns the number of tiles.
+long long emu_lw_row_map(int n_rp, long long n_sw, int groups, int32_t *hits, long long *per_group) {
+    using namespace awk;
+    long long total = 0;
+    for (int g = 0; g < groups; ++g) {
+        const LwRowMap m = lw_row_map(n_sw, n_rp, g, groups);
+        const long long n = lw_row_count(m);
+        per_group[g] = n;
+        int last_rp = -1, slices = 0;
+        for (long long v = 0; v < n; ++v) {
+            const LwRowTile t = lw_row_tile(m, v);
+            if (t.rp < 0 || t.rp >= n_rp || t.sw < 0 || t.sw >= n_sw) return -1;
+            if (t.rp != last_rp) { ++slices; last_rp = t.rp; }
+            hits[(long long)t.rp * n_sw + t.sw] += 1;
+        }
+        if (slices > n_rp / groups + 2) return -2;          // a group walks one table slice at a time: its whole rounds + at most two left-over pairs
+        total += n;
+    }
+    return total;
 }
 
 }  // extern "C"

@@ -126,3 +126,14 @@ def test_emulated_wide_layout_carries_history(oracle):
     assert np.array_equal(hist_out, x[:, -hist_len:])
     for ear in range(2):
         assert oracle.peak_rel_error(y[0, :, ear], ref[hist_len:, ear]) < TOL
+
+
+@pytest.mark.parametrize("rows", [32, 40, 48, 56, 64, 72, 80, 96, 112, 120, 128])
+@pytest.mark.parametrize("n_sw", [1, 3, 128, 1021])
+def test_row_tiles_cover_every_row_pair_once_and_balance_the_xcd_groups(rows, n_sw):
+    """The rows kernels pin row pairs to the 8 XCD groups (table slice in that XCD's L2).  Window lengths with R/2 = 4 mod 8 (40, 56, 72,
+    120 rows) leave four row pairs over: their tiles are dealt to all eight groups in equal shares instead of whole pairs to four of them
+    (round-4 advisor finding: 8 row pairs against 7 at R = 120).  Every (row pair, stream-window) exactly once; groups within one tile."""
+    hits, per = emu.lw_row_map(rows // 2, n_sw)
+    assert (hits == 1).all()
+    assert per.max() - per.min() <= 1 or (rows // 2) % 8 == 0 and per.max() == per.min(), per

@@ -17,7 +17,6 @@ __global__ void __launch_bounds__(kR16Threads, AW_R16_MIN_WAVES) k_rows16(LwPara
     const int g = (int)gridDim.x, b = (int)blockIdx.x;
     const int xcd = b % 8, slot = b / 8;
     const int per_xcd_wg = (g - xcd + 7) / 8;
-    const int n_rp_x = (p.R / 2 - xcd + 7) / 8;
-    lw_rows16_tiles<GpuCtx, PROBE_NP, PROBE_REAL>(ctx, p, (long long)slot, (long long)per_xcd_wg, (long long)n_rp_x * n_sw, n_sw, xcd, 8);
+    lw_rows16_tiles<GpuCtx, PROBE_NP, PROBE_REAL>(ctx, p, (long long)slot, (long long)per_xcd_wg, n_sw, xcd, 8);
 }
 }

@@ -33,8 +33,7 @@ __global__ void __launch_bounds__(kR16Threads, AW_R16_MIN_WAVES) k_rows(LwParams
     const int g = (int)gridDim.x, b = (int)blockIdx.x;
     const int xcd = b % 8, slot = b / 8;
     const int per_xcd_wg = (g - xcd + 7) / 8;
-    const int n_rp_x = (p.R / 2 - xcd + 7) / 8;
-    lw_rows16_tiles<GpuCtx, RB_NP, RB_REAL>(ctx, p, (long long)slot, (long long)per_xcd_wg, (long long)n_rp_x * n_sw, n_sw, xcd, 8);
+    lw_rows16_tiles<GpuCtx, RB_NP, RB_REAL>(ctx, p, (long long)slot, (long long)per_xcd_wg, n_sw, xcd, 8);
     ctx.flush_stamps();
     if (clk && threadIdx.x == 0) { clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - c0; clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
@@ -47,8 +46,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_rows(LwParams p, long long n_sw
     const int g = (int)gridDim.x, b = (int)blockIdx.x;
     const int xcd = b % 8, slot = b / 8;
     const int per_xcd_wg = (g - xcd + 7) / 8;
-    const int n_rp_x = (p.R / 2 - xcd + 7) / 8;
-    lw_rows_tiles<GpuCtx, RB_NP, RB_REAL, 1>(ctx, p, (long long)slot, (long long)per_xcd_wg, (long long)n_rp_x * n_sw, n_sw, xcd, 8);
+    lw_rows_tiles<GpuCtx, RB_NP, RB_REAL, 1>(ctx, p, (long long)slot, (long long)per_xcd_wg, n_sw, xcd, 8);
     ctx.flush_stamps();
     if (clk && threadIdx.x == 0) { clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - c0; clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
