@@ -7,6 +7,7 @@ nothing here computes audio.
 from __future__ import annotations
 
 import ctypes
+import sys
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -38,6 +39,14 @@ class HRIRError(AirwaveError):          # HRIRManager.swift:737-759
 
 class WAVError(AirwaveError):           # WAVLoader.swift:127-147
     pass
+
+
+def _finalizing() -> bool:
+    """True while the interpreter shuts down.  Handles that own device memory are not destroyed then: module globals and reference
+    cycles are collected in no particular order (a context can go before the objects created on it), and the HIP runtime's own exit
+    handlers may already have run — the process is about to return everything to the driver anyway.  (Found by tools/fuzz_eq.py, whose
+    last processor died at exit: std::bad_variant_access out of the HIP runtime, exit code 134 after a clean run.)"""
+    return sys.is_finalizing()
 
 
 def _check(status: int) -> None:
@@ -82,7 +91,8 @@ class Context:
             self._h = None
 
     def __del__(self):
-        self.close()
+        if not _finalizing():
+            self.close()
 
     def set_resampler(self, literal_vgenp: bool = False) -> None:
         """Which resampler activatePreset uses for this context: the intended interpolation (default) or the literal
@@ -155,7 +165,7 @@ class _PinnedOwner:
 
     def __del__(self):
         try:
-            if self._ptr and getattr(self._ctx, "_h", None):
+            if self._ptr and getattr(self._ctx, "_h", None) and not _finalizing():
                 self._ctx._lib.aw_host_free_pinned(self._ctx._h, ctypes.c_void_p(self._ptr))
         finally:
             self._ptr = 0
@@ -330,7 +340,7 @@ class HRIR:
         self.n_tracks, self.taps = t.shape
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not _finalizing():
             self._lib.aw_hrir_destroy(self._h)
             self._h = None
 
@@ -355,7 +365,7 @@ class Spatializer:
         self.n_channels = self._lib.aw_spatializer_channel_count(self._h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not _finalizing():
             self._lib.aw_spatializer_destroy(self._h)
             self._h = None
 
@@ -446,7 +456,7 @@ class ConvolutionEngine:
         self.blockSize = blockSize
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not _finalizing():
             self._lib.aw_engine_destroy(self._h)
             self._h = None
 
@@ -488,7 +498,7 @@ class RealtimeAudioProcessor:
         self.blockSize, self.maxFramesPerCallback = blockSize, maxFramesPerCallback
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not _finalizing():
             self._lib.aw_realtime_destroy(self._h)
             self._h = None
 

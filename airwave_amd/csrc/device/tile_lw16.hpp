@@ -26,7 +26,6 @@
 // instead of two 8-wave ones.  The inverse is the mirror image (conjugate twiddles, passes in reverse), so the s1 / s2 rows leave
 // in natural order as 512-byte runs per wave, exactly where lw_merge_tiles reads them.
 #pragma once
-#include <type_traits>
 #include "tile_lw.hpp"
 
 namespace awk {
@@ -43,35 +42,16 @@ constexpr int kR16Threads = 256;
 constexpr int kR16Stride = 272;
 constexpr int kR16BufElems = 16 * kR16Stride;
 constexpr int kR16Tw2Elems = 256;
-#ifndef AW_R16_T1_LDS
-#define AW_R16_T1_LDS 0         // 1: every thread's pass-1 twiddle powers w^1 .. w^8 live in LDS (16 KB per workgroup), w^9 .. w^15 = w^8 w^k: 22 instead of 29 complex
-                                // multiplies per transform (-3.6 % vector instructions).  Measured +-0 (4.19 against 4.15 ms): the core is held by the LDS
-                                // and vector pipes together, not by the instruction count; off
-#endif
-constexpr int kR16Tw1Elems = AW_R16_T1_LDS ? 8 * 256 : 0;
-constexpr int kR16LdsElems = kR16BufElems + kR16Tw2Elems + kR16Tw1Elems;
-constexpr int kR16LdsBytes = kR16LdsElems * 8;          // 36 864 B (53 248 B with the pass-1 powers in LDS): three workgroups per CU fit either way
+constexpr int kR16LdsElems = kR16BufElems + kR16Tw2Elems;
+constexpr int kR16LdsBytes = kR16LdsElems * 8;          // 36 864 B: three workgroups per CU
+// (Variants measured on tools/ubench/rows_bench in round 4 and removed from the source in round 5 — DESIGN.md §4.5b has the numbers: the
+// pass-1 powers w^1 .. w^8 in LDS, uniform-base addressing, the next row's requests spread over the transform, table batches requested
+// before the last pass, no row prefetch with four workgroups per CU, all sixteen table entries requested before the transform.)
 
 struct alignas(16) LwTab2 { cf u, w; };
 
 // FFT_4096 output bin held by (thread, register m1) of the 16-point core
 AW_HD int r16_bin(int thread, int m1) { return (thread >> 4) + 16 * (thread & 15) + 256 * m1; }
-
-// v[k] *= w^k (CONJ: conj(w)^k) with w^1 .. w^8 read from the thread's column of an LDS table (t1[256 (k - 1)]) and w^9 .. w^15 = w^8 w^(k-8)
-template <bool CONJ, class Ctx> AW_HD void r16_pow_apply_lds(Ctx &ctx, cf (&v)[16], const cf *t1) {
-    cf p[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = ctx.ld(t1 + 256 * k);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k + 1] = twmul<CONJ>(v[k + 1], p[k]);
-#pragma unroll
-    for (int k = 0; k < 7; ++k) v[k + 9] = twmul<CONJ>(v[k + 9], cmul(p[7], p[k]));
-}
-
-// uniform pointer + 32-bit per-lane byte offset: the form the global_load / global_store saddr addressing mode takes (no vector address arithmetic)
-template <class T> AW_HD T *r16_at(T *uniform_base, unsigned lane_bytes) {
-    return reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<typename std::remove_const<T>::type *>(uniform_base)) + lane_bytes);
-}
 
 // Per-thread constants of the core
 struct R16Thread {
@@ -81,7 +61,6 @@ struct R16Thread {
     cf *e2w;          // E2 store base: quarter + 272 (lane >> 4) + a           (+ 17 m0)
     cf *e2r;          // E2 load base:  quarter + 272 (lane >> 4) + 17 alpha    (+ rho)
     const cf *tw2;    // w_256^{a m0} at tw2[16 m0]
-    const cf *tw1;    // AW_R16_T1_LDS: w1^(k+1) at tw1[256 k], k < 8
 };
 
 // E2: 16 x 16 transpose between the register index and the lane field a, through the wave's own quarter of the E1 buffer
@@ -114,7 +93,7 @@ template <bool INV, class Ctx> AW_HD void r16_tw2_apply(Ctx &ctx, cf (&v)[16], c
 }
 
 // forward: v[j] = row[a + 16 b + 256 j]  ->  v[m1] = X[kappa + 16 alpha + 256 m1].  SB >= 0: phase stamps SB.. (diagnostic builds)
-template <int SB = -1, class Ctx, class Hook> AW_HD void r16_forward(Ctx &ctx, cf (&v)[16], const R16Thread &th, Hook &&hook) {
+template <int SB = -1, class Ctx> AW_HD void r16_forward(Ctx &ctx, cf (&v)[16], const R16Thread &th) {
     auto stamp = [&](int i) {              // (the values pass through an opaque asm first: arithmetic does not float across the stamp)
         if constexpr (SB >= 0) {
 #pragma unroll
@@ -124,10 +103,8 @@ template <int SB = -1, class Ctx, class Hook> AW_HD void r16_forward(Ctx &ctx, c
     };
     fft16<false>(v);
     stamp(0);
-    if constexpr (AW_R16_T1_LDS) r16_pow_apply_lds<false>(ctx, v, th.tw1);
-    else r16_pow_apply(v, ctx.opaque(th.w1));
+    r16_pow_apply(v, ctx.opaque(th.w1));
     stamp(1);
-    hook(LwIdx<0>{});                                // caller's memory requests between the phases (phase 0: after pass 1)
     if constexpr (AW_R16_PRIO & 4) ctx.template prio<1>();
     ctx.barrier();                                   // every wave has read the previous transform's exchange
     stamp(2);
@@ -139,17 +116,14 @@ template <int SB = -1, class Ctx, class Hook> AW_HD void r16_forward(Ctx &ctx, c
 #pragma unroll
     for (int bb = 0; bb < 16; ++bb) v[bb] = ctx.ld(th.str + 16 * bb);
     if constexpr (AW_R16_PRIO & 4) ctx.template prio<0>();
-    hook(LwIdx<1>{});                                // phase 1: E1 loads issued
     fft16<false>(v);
     stamp(5);
     r16_tw2_apply<false>(ctx, v, th.tw2);
     stamp(6);
-    hook(LwIdx<2>{});                                // phase 2: after pass 2
     if constexpr (AW_R16_PRIO & 8) ctx.template prio<1>();
     r16_lane_transpose(ctx, v, th);
     if constexpr (AW_R16_PRIO & 8) ctx.template prio<0>();
     stamp(7);
-    hook(LwIdx<3>{});                                // phase 3: before the last pass
     fft16<false>(v);
     stamp(8);
 }
@@ -168,8 +142,7 @@ template <bool AFTER_INVERSE, class Ctx> AW_HD void r16_inverse(Ctx &ctx, cf (&v
     ctx.barrier();
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) v[k2] = ctx.ld(th.lin + kR16Stride * k2);
-    if constexpr (AW_R16_T1_LDS) r16_pow_apply_lds<true>(ctx, v, th.tw1);
-    else r16_pow_apply(v, conj(ctx.opaque(th.w1)));
+    r16_pow_apply(v, conj(ctx.opaque(th.w1)));
     fft16<true>(v);
 }
 
@@ -182,18 +155,6 @@ template <bool AFTER_INVERSE, class Ctx> AW_HD void r16_inverse(Ctx &ctx, cf (&v
 #ifndef AW_R16_STAMP_TILE
 #define AW_R16_STAMP_TILE 40    // diagnostic builds (-DAW_STAMPS=1): the tile of every workgroup whose phases are recorded
 #endif
-#ifndef AW_R16_SPREAD
-#define AW_R16_SPREAD 1         // 2 / 4: the next row's sixteen requests leave in that many groups spread over this row's transform
-#endif
-#ifndef AW_R16_SADDR
-#define AW_R16_SADDR 0          // 1: global accesses as a uniform base plus one 32-bit lane offset (scalar address arithmetic)
-#endif
-#ifndef AW_R16_TAB_EARLY
-#define AW_R16_TAB_EARLY 0      // 1: the first table batches are requested before the transform's last pass
-#endif
-#ifndef AW_R16_ORDER
-#define AW_R16_ORDER 0          // issue order of the row and table loads, see lw_rows16_tiles
-#endif
 
 // Tiles as in lw_rows_tiles: virtual id -> (row pair, stream-window), row pairs pinned to XCDs by the launcher.
 template <class Ctx, int NP, bool REAL_LAST>
@@ -205,7 +166,6 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
     if (first >= end) return;
     const int tid = ctx.tid(), lane = ctx.lane(), wave = ctx.wave();
     const int a = lane & 15, b = (lane >> 4) + 4 * wave, nth = tid;        // nth = a + 16 b
-    const unsigned nth_bytes = (unsigned)nth * 8u, tid_bytes16 = (unsigned)tid * 16u;
     cf *buf = ctx.lds();
     cf *tw2 = buf + kR16BufElems;
     tw2[tid] = p.tw2[tid];                                       // visible after the first transform's first barrier
@@ -216,37 +176,25 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
     th.e2w = buf + kR16Stride * (4 * wave + (lane >> 4)) + a;
     th.e2r = buf + kR16Stride * (4 * wave + (lane >> 4)) + 17 * a;
     th.tw2 = tw2 + a;
-    th.tw1 = tw2 + kR16Tw2Elems + tid;
-    if constexpr (AW_R16_T1_LDS) {               // this thread's own column: written and read by this thread only
-        cf *t1 = tw2 + kR16Tw2Elems + tid;
-        cf pw = th.w1;
-        t1[0] = pw;
-#pragma unroll
-        for (int k = 1; k < 8; ++k) { pw = k == 1 ? cmul(th.w1, th.w1) : k == 3 ? cmul(t1[256], t1[256]) : k == 7 ? cmul(t1[3 * 256], t1[3 * 256]) : cmul(pw, th.w1); t1[256 * k] = pw; }
-    }
     const int R = p.R;
 
     auto row_src = [&](const LwRowTile &tl, int idx) -> const cf * {     // idx = 2 pair + (0: row ra, 1: row rb)
         const int pair = idx >> 1;
         const int row = (idx & 1) ? R - 1 - tl.rp : tl.rp;
-#ifdef AW_R16_ABL_LINEAR_ROWS     // timing ablation only (wrong results): rows laid out [row pair][stream-window][row of the tile]
-        return p.spec + (((long long)tl.rp * n_sw + tl.sw) * NROWS + idx) * kLwM + nth + 0 * (row + pair);
-#endif
-        return p.spec + tl.sw * p.spec_per_sw + (long long)pair * p.N + (long long)row * kLwM + (AW_R16_SADDR ? 0 : nth);     // AW_R16_SADDR: uniform
+        return p.spec + tl.sw * p.spec_per_sw + (long long)pair * p.N + (long long)row * kLwM + nth;
     };
     cf raw[16];
-    auto load_row = [&](const cf *src, cf (&d)[16], int j0 = 0, int j1 = 16) {
+    auto load_row = [&](const cf *src, cf (&d)[16]) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            if (j < j0 || j >= j1) continue;
 #ifdef AW_LW_ABL_ROWS_NOLOAD      // timing ablation only (wrong results)
             d[j] = mk(0.001f * tid, (float)(src == nullptr) + 0.002f * j);
 #else
-            d[j] = AW_R16_SADDR ? ctx.ld_stream(r16_at(src + 256 * j, nth_bytes)) : ctx.ld_stream(src + 256 * j);
+            d[j] = ctx.ld_stream(src + 256 * j);
 #endif
         }
     };
-    if (AW_R16_ORDER != 2) load_row(row_src(lw_row_tile(rmap, first), 0), raw);
+    load_row(row_src(lw_row_tile(rmap, first), 0), raw);
     for (long long vid = first; vid < end; vid += step) {
         const LwRowTile tl = lw_row_tile(rmap, vid);
 #if defined(AW_STAMPS) && AW_STAMPS
@@ -260,91 +208,50 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
             cf v[16];
             constexpr int SB = idx == (NROWS > 2 ? 2 : 0) ? 1 : -1;       // diagnostic builds stamp one row of the tile
             if constexpr (SB >= 0) ctx.stamp(0);
-            const LwTab2 *tb = p.tab16 + ((((long long)tl.rp * NP + pair) * 2 + r) * 16) * kR16Threads + (AW_R16_SADDR ? 0 : tid);
+            const LwTab2 *tb = p.tab16 + ((((long long)tl.rp * NP + pair) * 2 + r) * 16) * kR16Threads + tid;
             auto tab_entry = [&](int m1) -> LwTab2 {
 #ifdef AW_LW_ABL_ROWS_NOTAB       // timing ablation only (wrong results)
                 return LwTab2{mk(1.f, 0.5f * lane), mk(0.25f * m1, 1.f * wave + (float)(tb == nullptr))};
 #else
-                return AW_R16_SADDR ? *r16_at(tb + m1 * kR16Threads, tid_bytes16) : tb[m1 * kR16Threads];
+                return tb[m1 * kR16Threads];
 #endif
             };
-            constexpr bool kTabEarly = AW_R16_ORDER == 3;             // all sixteen entries requested before the transform (64 registers)
-            LwTab2 T[kTabEarly ? 16 : 1];
-            // the next row (of this tile, or the first one of the next tile; the last tile re-reads its own)
+            // the next row (of this tile, or the first one of the next tile; the last tile re-reads its own): requested at the start of this
+            // row's transform.  Vector-memory results return in issue order — a wait for the table entries also waits for every load issued
+            // before them — so the tables are requested after the transform.
             const cf *next_src = idx + 1 < NROWS ? row_src(tl, idx + 1) : row_src(lw_row_tile(rmap, vid + step < end ? vid + step : vid), 0);
-            auto prefetch_next = [&](int j0 = 0, int j1 = 16) { load_row(next_src, raw, j0, j1); };
-            // AW_R16_SPREAD = n > 1: the sixteen requests of the next row leave in n groups between the phases of this row's transform
-            constexpr int NSPREAD = AW_R16_SPREAD > 1 ? AW_R16_SPREAD : 1;
-            // Vector-memory results return in issue order: a wait for the table entries also waits for every load issued before
-            // them.  AW_R16_ORDER picks what is issued when:
-            //   0  next row at the start of this row's transform, tables after the transform
-            //   2  no row prefetch: this row at the start of the transform, tables after it (fewest registers: four workgroups per CU)
-            //   3  tables, then the next row, both at the start of the transform (96 registers in flight)
-            if constexpr (AW_R16_ORDER == 2) {
-                load_row(row_src(tl, idx), v);
-            } else {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = raw[j];
-                ctx.sched_fence_hard();           // keeps hipcc from hoisting several rows' loads to the top of the unrolled tile
-                if constexpr (kTabEarly) {
-#pragma unroll
-                    for (int m1 = 0; m1 < 16; ++m1) T[m1] = tab_entry(m1);
-                    ctx.sched_fence_hard();
-                }
-                if constexpr (AW_R16_PRIO & 1) ctx.template prio<3>();
-                prefetch_next(0, 16 / NSPREAD);
-                if constexpr (AW_R16_PRIO & 1) ctx.template prio<0>();
-                ctx.sched_fence_hard();
-            }
+            for (int j = 0; j < 16; ++j) v[j] = raw[j];
+            ctx.sched_fence_hard();               // keeps hipcc from hoisting several rows' loads to the top of the unrolled tile
+            if constexpr (AW_R16_PRIO & 1) ctx.template prio<3>();
+            load_row(next_src, raw);
+            if constexpr (AW_R16_PRIO & 1) ctx.template prio<0>();
+            ctx.sched_fence_hard();
             // Table entries in batches of K, DEPTH batches in flight, fenced: left in one loop hipcc emits load, s_waitcnt vmcnt(0),
             // eight multiply-accumulates, sixteen times over — sixteen exposed L2 round trips per row (8.9 k of its 15.6 k cycles).
-            // AW_R16_TAB_EARLY: the first DEPTH - 1 batches are requested before the transform's last pass.
             constexpr int K = AW_R16_TAB_K, NBATCH = 16 / K, DEPTH = AW_R16_TAB_DEPTH;
-            LwTab2 tq[kTabEarly ? 1 : DEPTH][K];
+            LwTab2 tq[DEPTH][K];
             auto issue = [&](int bi) {
 #pragma unroll
                 for (int i = 0; i < K; ++i) tq[bi % DEPTH][i] = tab_entry(bi * K + i);
             };
-            auto issue_first = [&]() {
-                if constexpr (!kTabEarly) {
-#pragma unroll
-                    for (int bi = 0; bi < DEPTH - 1 && bi < NBATCH; ++bi) issue(bi);
-                }
-            };
-            r16_forward<SB>(ctx, v, th, [&](auto PH) {
-                constexpr int ph = decltype(PH)::value;
-                if constexpr (ph < 3 && ph + 1 < NSPREAD) {          // groups 1 .. NSPREAD-1 after phases 0, 1, 2
-                    ctx.sched_fence_hard();
-                    if constexpr (AW_R16_PRIO & 1) ctx.template prio<3>();
-                    prefetch_next((ph + 1) * (16 / NSPREAD), (ph + 2) * (16 / NSPREAD));
-                    if constexpr (AW_R16_PRIO & 1) ctx.template prio<0>();
-                    ctx.sched_fence_hard();
-                }
-                if constexpr (ph == 3 && AW_R16_TAB_EARLY) { ctx.sched_fence_hard(); issue_first(); ctx.sched_fence_hard(); }
-            });
+            r16_forward<SB>(ctx, v, th);
             ctx.sched_fence_hard();               // (table loads hoisted above the transform end up in scratch)
             if constexpr (SB >= 0) ctx.stamp(10);
-            if constexpr (kTabEarly) {
+            if constexpr (AW_R16_PRIO & 2) ctx.template prio<2>();
 #pragma unroll
-                for (int m1 = 0; m1 < 16; ++m1) {
-                    w1acc[m1] = cfma(v[m1], T[kTabEarly ? m1 : 0].u, w1acc[m1]);
-                    w2acc[m1] = cfma(v[m1], T[kTabEarly ? m1 : 0].w, w2acc[m1]);
+            for (int bi = 0; bi < DEPTH - 1 && bi < NBATCH; ++bi) issue(bi);
+#pragma unroll
+            for (int bi = 0; bi < NBATCH; ++bi) {
+                if (bi + DEPTH - 1 < NBATCH) issue(bi + DEPTH - 1);
+                ctx.sched_fence_hard();
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const int m1 = bi * K + i;
+                    w1acc[m1] = cfma(v[m1], tq[bi % DEPTH][i].u, w1acc[m1]);
+                    w2acc[m1] = cfma(v[m1], tq[bi % DEPTH][i].w, w2acc[m1]);
                 }
-            } else {
-                if constexpr (AW_R16_PRIO & 2) ctx.template prio<2>();
-                if constexpr (!AW_R16_TAB_EARLY) issue_first();
-#pragma unroll
-                for (int bi = 0; bi < NBATCH; ++bi) {
-                    if (bi + DEPTH - 1 < NBATCH) issue(bi + DEPTH - 1);
-                    ctx.sched_fence_hard();
-#pragma unroll
-                    for (int i = 0; i < K; ++i) {
-                        const int m1 = bi * K + i;
-                        w1acc[m1] = cfma(v[m1], tq[bi % DEPTH][i].u, w1acc[m1]);
-                        w2acc[m1] = cfma(v[m1], tq[bi % DEPTH][i].w, w2acc[m1]);
-                    }
-                    ctx.sched_fence_hard();
-                }
+                ctx.sched_fence_hard();
             }
             if constexpr (AW_R16_PRIO & 2) ctx.template prio<0>();
             // pins the multiply-accumulates here: left free, hipcc sinks every row's to the end of the tile and keeps the rows' spectra
@@ -354,18 +261,14 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
             if constexpr (SB >= 0) ctx.stamp(11);
         });
         ctx.stamp(12);
-#ifdef AW_R16_ABL_LINEAR_ROWS
-        cf *dst = p.wrows + ((long long)tl.rp * n_sw + tl.sw) * (long long)(2 * kLwM) + nth;
-#else
-        cf *dst = p.wrows + (tl.sw * (R / 2) + tl.rp) * (long long)(2 * kLwM) + (AW_R16_SADDR ? 0 : nth);
-#endif
+        cf *dst = p.wrows + (tl.sw * (R / 2) + tl.rp) * (long long)(2 * kLwM) + nth;
         r16_inverse<false>(ctx, w1acc, th);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
 #ifdef AW_LW_ABL_ROWS_NOSTORE     // timing ablation only (wrong results)
             if (w1acc[j].x != 1.2345e-30f) continue;
 #endif
-            ctx.st_stream(AW_R16_SADDR ? r16_at(dst + 256 * j, nth_bytes) : dst + 256 * j, w1acc[j]);
+            ctx.st_stream(dst + 256 * j, w1acc[j]);
         }
         r16_inverse<true>(ctx, w2acc, th);
 #pragma unroll
@@ -373,7 +276,7 @@ AW_HD void lw_rows16_tiles(Ctx &ctx, const LwParams &p, long long first, long lo
 #ifdef AW_LW_ABL_ROWS_NOSTORE
             if (w2acc[j].x != 1.2345e-30f) continue;
 #endif
-            ctx.st_stream(AW_R16_SADDR ? r16_at(dst + kLwM + 256 * j, nth_bytes) : dst + kLwM + 256 * j, w2acc[j]);
+            ctx.st_stream(dst + kLwM + 256 * j, w2acc[j]);
         }
         ctx.stamp(13);
     }

@@ -833,7 +833,10 @@ AW_HD void tiles_fused_ols(Ctx &ctx, const TileParams &p, long long first, long 
         // tables after the transform in one go (64 VGPRs) or in two parts of eight bins.  Measured per layout (tools/ols2_ab.py WINDOW=8192,
         // tools/ubench/tile_bench.hip): 13 / 14 channels 22.5 / 21.9 -> 23.9 / 23.2 G frames/s (19 spilled VGPRs either way, fewer live through the
         // multiply-accumulate), 9 / 10 +-0, 11 / 12 channels 28.5 / 29.2 -> 24.0 / 23.0 (!), 8 channels +-0 (parts of four: -5 %) — seven pairs only.
-        constexpr int kTabG = (kTabEarly0 || kTabEarly1) ? 16 : NP == 7 ? 8 : 16;
+#ifndef AW_TAB_G7
+#define AW_TAB_G7 8
+#endif
+        constexpr int kTabG = (kTabEarly0 || kTabEarly1) ? 16 : NP == 7 ? AW_TAB_G7 : 16;
         auto subfft_cmac_ = [&](int pr, cf *bf, bool loaded) { pair_subfft_cmac_h<kTabG>(ctx, p, pr, bf, twa, tab, lane, wave, wacc, loaded); };
 #else
         cf2 tab[2][8];

@@ -12,7 +12,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 from . import _capi
-from .api import AW_OK, AirwaveError, Context, _check, _f32, _fp, default_context
+from .api import AW_OK, AirwaveError, Context, _check, _f32, _finalizing, _fp, default_context
 
 PEAKING, LOW_SHELF, HIGH_SHELF = 0, 1, 2
 _BIQUAD_KINDS = {1: "invalidSampleRate", 2: "invalidFrequency", 3: "invalidQ", 4: "nonFiniteInput", 5: "nonFiniteCoefficients"}
@@ -171,7 +171,7 @@ class ParametricEqualizerState:
         self.preampLinear = self._lib.aw_eq_state_preamp_linear(h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not _finalizing():
             self._lib.aw_eq_state_destroy(self._h)
             self._h = None
 
@@ -209,7 +209,7 @@ class ParametricEqualizerProcessor:
         self.transitionLength = self._lib.aw_eq_transition_length(h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not _finalizing():
             self._lib.aw_eq_destroy(self._h)
             self._h = None
 

@@ -268,6 +268,7 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
     eq_def = None
     if wl.get("eq"):
         eq_def = aw.EqualizerAPOParser.parse(open(os.path.join(ROOT, "tests", "golden", "eq", "CCA CRA ParametricEq.txt"), "rb").read(), "CCA CRA ParametricEq.txt")
+    mem_free0, mem_total = torch.cuda.mem_get_info()
     main_stream = torch.cuda.current_stream()                                    # torch's current stream IS the bench context's stream
     lane_ctx = [ctx] + [aw.Context(ctx.device) for _ in range(n_lanes - 1)]
     lane_stream = [main_stream] + [torch.cuda.ExternalStream(c.stream) for c in lane_ctx[1:]]
@@ -293,6 +294,7 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
             legs.append(dict(lane=li, rate=rate, n=n, F=F, x=x, y=y, sp=b.spatializer, eq=eq, taps=b.hrir_taps, first=lo + b.stream_ids[0]))
     batch = batches[0]
     torch.cuda.synchronize()
+    mem_free1 = torch.cuda.mem_get_info()[0]
     eq_events = []
 
     def step(timed=False):
@@ -443,6 +445,8 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
                 "outputs_finite": finite,
                 # creation-time cost (not in the timed region; the reference does its HRIR partition FFTs at engine init too,
                 # ConvolutionEngine.swift:143-182): aw_spatializer_reserve = table build in float64 on host threads + upload + scratch pool
+                # per-rank HBM footprint of this workload (input + output + history + tables + scratch pool), of the device's total
+                "device_memory": {"used_by_workload_bytes": int(mem_free0 - mem_free1), "free_before_bytes": int(mem_free0), "total_bytes": int(mem_total)},
                 "activation": activation,
                 "activation_ms": [a["total_ms"] for a in activation],
                 "device_src_sha16": __import__("airwave_amd.provenance", fromlist=["x"]).device_source_digest(),

@@ -156,3 +156,55 @@ def test_realtime_adapter_allocates_everything_at_creation(oracle, taps):
     assert np.max(np.abs(got - exp)) <= 1e-5 * np.max(np.abs(exp))
     p.reset()
     assert p.info() == held
+
+
+@pytest.mark.gpu
+def test_two_handles_of_one_context_driven_from_two_threads(oracle):
+    """"A handle is single-threaded, independent handles are independent"  — also when two handles share a context, whose
+    scratch pool they then share: each call's kernels are queued under the context's launch lock, so one call's split / rows / merge (or
+    forward / march / inverse) sequence is never interleaved with the other's on the stream.  Two path-1 spatializers (both kernel families
+    that use the pool), two threads, forty interleaved calls: every output equals the single-threaded one."""
+    import threading
+    import torch
+    import airwave_amd as aw
+    ctx = aw.Context(0)
+    h = oracle.synth_hrir(14, 20000, seed=3)
+    shapes = [(7, 3, 70000), (2, 5, 9000)]               # (channels, streams, frames): a long-window call and a partitioned one
+    sps, xs, refs = [], [], []
+    for C, S, F in shapes:
+        lt = (np.arange(C) % 14).astype(np.int32)
+        rt = ((np.arange(C) + 7) % 14).astype(np.int32)
+        x = torch.empty((S, F, C), dtype=torch.float32, device="cuda")
+        ctx.synth_fill(x.data_ptr(), S, F, C, seed=C)
+        one = aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=S, ctx=ctx)
+        y = torch.empty((S, F, 2), dtype=torch.float32, device="cuda")
+        outs = []
+        for _ in range(20):
+            one.process_device(x.data_ptr(), y.data_ptr(), F)
+            ctx.synchronize()
+            outs.append(y.cpu().numpy().copy())
+        refs.append(outs)
+        sps.append(aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=S, ctx=ctx))
+        xs.append(x)
+    got = [[], []]
+    errors = []
+
+    def drive(i):
+        try:
+            C, S, F = shapes[i]
+            ys = [torch.empty((S, F, 2), dtype=torch.float32, device="cuda") for _ in range(20)]
+            for k in range(20):
+                sps[i].process_device(xs[i].data_ptr(), ys[k].data_ptr(), F)        # asynchronous: the two threads' launches interleave
+            ctx.synchronize()
+            got[i] = [y.cpu().numpy() for y in ys]
+        except Exception as e:          # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=drive, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        for k in range(20):
+            assert np.array_equal(got[i][k], refs[i][k]), (i, k)

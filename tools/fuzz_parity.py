@@ -20,7 +20,7 @@ while time.time() < t_end:
         taps = int(rng.integers(1, 14000))
     if rng.random() < 0.2:                       # long HRIRs: the partitioned path (marched CMAC; several passes above 8 partitions)
         taps = int(rng.choice([12290, 16384, 16385, 20000, 32768, 40000, 70000, int(rng.integers(12290, 80000))]))
-    S = int(rng.choice([1, 2, 3, 5]))
+    S = int(rng.choice([1, 2, 3, 5, 4, 7]))
     total = int(rng.integers(1, 60000)) if rng.random() < 0.8 else int(rng.choice([1, 2, 3839, 3840, 3841, 8191, 8192, 8193, 16384]))
     env = {}
     r = rng.random()
@@ -43,7 +43,10 @@ while time.time() < t_end:
     elif r3 < 0.4: env["AW_LW"] = "0"
     elif r3 < 0.6 and taps >= 8000:              # the policy's own choice on calls long enough for one or two window lengths
         total = int(rng.integers(150000, 700000)); S = int(rng.choice([1, 2, 6]))
-    for k in ("AW_WINDOW", "AW_PART_FWD", "AW_PART_CMAC", "AW_PART_HERM", "AW_SPEC_SCRATCH_MB", "AW_LW", "AW_LW_ROWS_PB", "AW_LW_ROWS_FORM"):
+    # round 5: the host entry in chunks of streams (1-MB chunks: a few streams each, ragged last chunk) and the host table builder
+    if rng.random() < 0.3: env["AW_HOST_CHUNK_MB"] = "1"
+    if rng.random() < 0.15: env["AW_LW_TABLES"] = "host"
+    for k in ("AW_WINDOW", "AW_PART_FWD", "AW_PART_CMAC", "AW_PART_HERM", "AW_SPEC_SCRATCH_MB", "AW_LW", "AW_LW_ROWS_PB", "AW_LW_ROWS_FORM", "AW_HOST_CHUNK_MB", "AW_LW_TABLES"):
         os.environ.pop(k, None)
     os.environ.update(env)
     n_tracks = int(rng.choice([2, 7, 14]))
@@ -59,7 +62,7 @@ while time.time() < t_end:
     if os.environ.get("AW_FUZZ_TRACE"):
         print("CASE", C, taps, S, total, bounds, env, n_tracks, flush=True)
     try:
-        ctx = aw.Context(0) if ("AW_LW_ROWS_PB" in env or "AW_LW_ROWS_FORM" in env) else None        # (those knobs are read when a context is created)
+        ctx = aw.Context(0) if any(k in env for k in ("AW_LW_ROWS_PB", "AW_LW_ROWS_FORM", "AW_HOST_CHUNK_MB", "AW_LW_TABLES")) else None        # (those knobs are read when a context is created)
         sp = aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=S, ctx=ctx) if ctx else aw.Spatializer(aw.HRIR(h), lt, rt, n_streams=S)
         info = sp.info()
         y = np.concatenate([sp.process(x[:, a:b]) for a, b in zip(bounds[:-1], bounds[1:])], axis=1)
