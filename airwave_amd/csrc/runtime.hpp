@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <mutex>
 #include <string>
@@ -42,8 +43,8 @@ struct aw_context {
     awk::cf *d_pool = nullptr;
     size_t pool_capacity = 0;                                       // complex elements
     std::mutex launch_mu;
-    long long device_allocs = 0;                                    // hipMalloc / hipHostMalloc calls made on behalf of this context's handles (tests: a reserved process path makes none)
-    long long sync_copies = 0;                                      // blocking hipMemcpy calls likewise (table uploads)
+    std::atomic<long long> device_allocs{0};                        // hipMalloc / hipHostMalloc calls made on behalf of this context's handles (tests: a reserved process path makes none)
+    std::atomic<long long> sync_copies{0};                          // blocking hipMemcpy calls likewise (table uploads)
     // host-entry pipeline (aw_spatializer_process_host on a multi-stream batch): H2D of chunk k+1 || kernels of chunk k || D2H of chunk k-1
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_run[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
