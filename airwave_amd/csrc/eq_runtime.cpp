@@ -136,6 +136,8 @@ struct aw_eq {
     bool reset_requested = false;
     float *d_old = nullptr, *d_new = nullptr;   // [stream][transition_length][2] crossfade scratch (oldScratch/newScratch :137-140)
     float *d_stage = nullptr;                   // planar host entry staging
+    float *h_pin = nullptr;                     // ... and its page-locked form for callback-sized calls: [2 F] interleaved, processed IN PLACE by the kernels over PCIe
+    size_t pin_cap = 0;                         // floats
     size_t stage_cap = 0;
 };
 
@@ -272,6 +274,8 @@ aw_status aw_eq_create(aw_context *ctx, double sample_rate, int32_t n_streams, i
     if (he == hipSuccess && n_streams == 1 && max_frames > 0) {
         he = hipMalloc(reinterpret_cast<void **>(&eq->d_stage), (size_t)max_frames * 4 * sizeof(float));
         if (he == hipSuccess) eq->stage_cap = (size_t)max_frames * 4;
+        if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void **>(&eq->h_pin), (size_t)max_frames * 2 * sizeof(float), hipHostMallocDefault);
+        if (he == hipSuccess) eq->pin_cap = (size_t)max_frames * 2;
     }
     if (he != hipSuccess) {                      // a failed later allocation must not leak the earlier ones: destroy frees whatever exists
         aw_eq_destroy(eq.release());
@@ -288,6 +292,7 @@ void aw_eq_destroy(aw_eq *eq) {
     if (eq->d_old) (void)hipFree(eq->d_old);
     if (eq->d_new) (void)hipFree(eq->d_new);
     if (eq->d_stage) (void)hipFree(eq->d_stage);
+    if (eq->h_pin) (void)hipHostFree(eq->h_pin);
     delete eq;
 }
 
@@ -428,6 +433,18 @@ aw_status aw_eq_process_planar(aw_eq *eq, const float *in_l, const float *in_r, 
     if (frames <= 0) return frames == 0 ? AW_OK : fail(AW_ERR_INVALID_ARGUMENT, "frameCount must be >= 0");
     AW_HIP_TRY(hipSetDevice(eq->ctx->device));
     hipStream_t s = eq->ctx->stream;
+    if (eq->pin_cap >= (size_t)frames * 2) {
+        // the render-callback shape: interleave into the page-locked staging (left duplicated when there is no right, :68), let the
+        // kernels filter it in place over PCIe, deinterleave on the way out — no copy engine, no (de)interleave kernels
+        const float *r_src = in_r ? in_r : in_l;
+        float *px = eq->h_pin;
+        for (int i = 0; i < frames; ++i) { px[2 * (size_t)i] = in_l[i]; px[2 * (size_t)i + 1] = r_src[i]; }
+        const aw_status st0 = aw_eq_process(eq, px, px, frames);
+        if (st0 != AW_OK) return st0;
+        AW_HIP_TRY(hipStreamSynchronize(s));
+        for (int i = 0; i < frames; ++i) { out_l[i] = px[2 * (size_t)i]; out_r[i] = px[2 * (size_t)i + 1]; }
+        return AW_OK;
+    }
     const size_t need = (size_t)frames * 4;   // [interleaved 2F | planar L F | planar R F]
     if (eq->stage_cap < need) {
         if (eq->d_stage) AW_HIP_TRY(hipFree(eq->d_stage));

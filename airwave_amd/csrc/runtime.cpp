@@ -477,6 +477,8 @@ void aw_spatializer_destroy(aw_spatializer *sp) {
     if (sp->d_dbg) (void)hipFree(sp->d_dbg);
     if (sp->d_stage_in) (void)hipFree(sp->d_stage_in);
     if (sp->d_stage_out) (void)hipFree(sp->d_stage_out);
+    if (sp->h_pin_in) (void)hipHostFree(sp->h_pin_in);
+    if (sp->h_pin_out) (void)hipHostFree(sp->h_pin_out);
     if (sp->k0) (void)hipEventDestroy(sp->k0);
     if (sp->k1) (void)hipEventDestroy(sp->k1);
     for (auto &pr : sp->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -973,7 +975,7 @@ static aw_status sp_process_longwin(aw_spatializer *sp, const LwCallPlan &call, 
         awk::StageTimer *tmp = sp->profiling ? &tm : nullptr;
         if (sp->n_channels > 8)          // the wide split kernel reads the last frame of the last stream from a padded copy (allocated at create)
             AW_HIP_TRY(hipMemcpyAsync(sp->d_tail, in + ((size_t)(s0 + ns) * frames - 1) * sp->n_channels, sp->n_channels * sizeof(float),
-                                      hipMemcpyDeviceToDevice, sp->ctx->stream));
+                                      hipMemcpyDefault, sp->ctx->stream));          // (`in` is device memory, or the page-locked staging of a one-stream call)
         for (int gi = 0; gi < call.n_groups; ++gi) {
             const LwGroup &g = call.g[gi];
             const aw_spatializer::LwPlan *plan = tables[gi];
@@ -1019,6 +1021,23 @@ static aw_status sp_grow(aw_spatializer *sp, float **buf, size_t *cap, size_t ne
     sp->ctx->device_allocs += 1;
     *cap = need;
     return AW_OK;
+}
+
+static aw_status sp_grow_pinned(aw_spatializer *sp, float **buf, size_t *cap, size_t need) {
+    if (*cap >= need) return AW_OK;
+    if (*buf) AW_HIP_TRY(hipHostFree(*buf));
+    *buf = nullptr; *cap = 0;
+    AW_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(buf), need * sizeof(float), hipHostMallocDefault));
+    sp->ctx->device_allocs += 1;
+    *cap = need;
+    return AW_OK;
+}
+
+// Callback-sized calls of a one-stream spatializer take the zero-copy staging (runtime.hpp) when aw_spatializer_reserve has made it;
+// longer calls move by DMA (a fused tile reads every input line about twice: not over PCIe).
+static constexpr int64_t kZeroCopyFrames = 16384;
+static bool sp_zero_copy(const aw_spatializer *sp, int64_t frames) {
+    return sp->n_streams == 1 && frames <= kZeroCopyFrames && sp->pin_in_cap >= (size_t)frames * sp->n_channels && sp->pin_out_cap >= (size_t)frames * 2;
 }
 
 // The longest call of at most max_frames frames that the policy (lw_choose with every window length available) leaves to the partitioned
@@ -1086,6 +1105,10 @@ aw_status aw_spatializer_reserve(aw_spatializer *sp, int64_t max_frames) {
         const size_t n = (size_t)max_frames * std::max(sp->n_channels, 4);
         aw_status st = sp_grow(sp, &sp->d_stage_in, &sp->stage_in_cap, n);
         if (st == AW_OK) st = sp_grow(sp, &sp->d_stage_out, &sp->stage_out_cap, (size_t)max_frames * 4);
+        // callback-sized calls: page-locked staging the kernels address directly
+        const size_t zf = (size_t)std::min<int64_t>(max_frames, kZeroCopyFrames);
+        if (st == AW_OK) st = sp_grow_pinned(sp, &sp->h_pin_in, &sp->pin_in_cap, zf * sp->n_channels);
+        if (st == AW_OK) st = sp_grow_pinned(sp, &sp->h_pin_out, &sp->pin_out_cap, zf * 2);
         if (st != AW_OK) return st;
     }
     sp->reserved_frames = std::max<int64_t>(sp->reserved_frames, max_frames);
@@ -1194,6 +1217,17 @@ aw_status aw_spatializer_process_host(aw_spatializer *sp, const float *in, float
     aw_context *c = sp->ctx;
     std::lock_guard<std::mutex> lk(c->launch_mu);
     const size_t in_ps = (size_t)frames * sp->n_channels, out_ps = (size_t)frames * 2;          // floats per stream
+    if (sp_zero_copy(sp, frames)) {      // one stream, a callback's worth of frames: the kernels read and write page-locked host memory themselves
+        std::memcpy(sp->h_pin_in, in, in_ps * sizeof(float));
+        const LwCallPlan lw0 = sp_begin_call(sp, frames);
+        aw_status st0 = sp_run_streams(sp, lw0, 0, 1, sp->h_pin_in, sp->h_pin_out, frames);
+        if (st0 != AW_OK) return st0;
+        sp->hist_cur ^= 1;
+        AW_HIP_TRY(hipStreamSynchronize(c->stream));
+        std::memcpy(out, sp->h_pin_out, out_ps * sizeof(float));
+        sp->host_chunk_streams = 0;
+        return AW_OK;
+    }
     int64_t cs = host_chunk_streams(sp, frames);
     // a reserved spatializer keeps the chunking its buffers were sized for (never a reallocation on this path)
     if (frames <= sp->host_reserved_frames) cs = sp->host_chunk_reserved > 0 ? (cs > 0 ? std::min(cs, sp->host_chunk_reserved) : sp->host_chunk_reserved) : 0;
@@ -1259,6 +1293,23 @@ aw_status aw_spatializer_process_planar(aw_spatializer *sp, const float *in_l, c
     if (frames <= 0) return frames == 0 ? AW_OK : fail(AW_ERR_INVALID_ARGUMENT, "frameCount must be >= 0");
     AW_HIP_TRY(hipSetDevice(sp->ctx->device));
     hipStream_t s = sp->ctx->stream;
+    if (sp_zero_copy(sp, frames)) {
+        // The render-callback shape (AudioPipeline.swift:3-11).  Interleave on the way into the page-locked staging (mono duplication,
+        // RealtimeAudioProcessor.swift:95-107), let the kernels read and write it in place over PCIe, deinterleave on the way out: two or
+        // three kernel launches and one synchronisation per callback (round 4: four copies through the DMA engines and two more kernels).
+        std::lock_guard<std::mutex> lk(sp->ctx->launch_mu);
+        const float *r_src = in_r ? in_r : in_l;
+        float *pi = sp->h_pin_in;
+        for (int i = 0; i < frames; ++i) { pi[2 * (size_t)i] = in_l[i]; pi[2 * (size_t)i + 1] = r_src[i]; }
+        const LwCallPlan lw0 = sp_begin_call(sp, frames);
+        aw_status st0 = sp_run_streams(sp, lw0, 0, 1, sp->h_pin_in, sp->h_pin_out, frames);
+        if (st0 != AW_OK) return st0;
+        sp->hist_cur ^= 1;
+        AW_HIP_TRY(hipStreamSynchronize(s));
+        const float *po = sp->h_pin_out;
+        for (int i = 0; i < frames; ++i) { out_l[i] = po[2 * (size_t)i]; out_r[i] = po[2 * (size_t)i + 1]; }
+        return AW_OK;
+    }
     // staging layout: [in interleaved 2F | planar L F | planar R F] and [out interleaved 2F | L F | R F]
     aw_status st = sp_grow(sp, &sp->d_stage_in, &sp->stage_in_cap, (size_t)frames * 4);
     if (st == AW_OK) st = sp_grow(sp, &sp->d_stage_out, &sp->stage_out_cap, (size_t)frames * 4);
@@ -1299,6 +1350,9 @@ aw_status aw_engine_create(aw_context *ctx, const float *hrir_samples, int32_t c
     aw_status st = aw_hrir_create(ctx, hrir_samples, 1, count, 0.0, &e->hrir);
     const int32_t zero = 0;
     if (st == AW_OK) st = aw_spatializer_create(ctx, e->hrir, 1, &zero, &zero, 1, block_size, &e->sp);
+    // the engine processes exactly block_size frames per call: everything process needs is allocated here, like
+    // ConvolutionEngine.init (ConvolutionEngine.swift:97-138) — process does not allocate
+    if (st == AW_OK) st = aw_spatializer_reserve_host(e->sp, block_size);
     if (st != AW_OK) { aw_engine_destroy(e); return st; }
     e->tmp_out.assign((size_t)block_size * 2, 0.f);
     *out = e;

@@ -90,6 +90,10 @@ struct aw_spatializer {
     // host-entry staging (grow-only; a multi-stream batch is staged in two chunks of streams each way: aw_spatializer_process_host)
     float *d_stage_in = nullptr, *d_stage_out = nullptr;
     size_t stage_in_cap = 0, stage_out_cap = 0;   // floats
+    // one-stream, callback-sized calls (aw_spatializer_process_planar, aw_engine_*, aw_realtime_*): page-locked staging that the kernels read
+    // and write DIRECTLY over PCIe — no copy engine, no (de)interleave kernels: the caller's samples are (de)interleaved by the CPU on the way
+    float *h_pin_in = nullptr, *h_pin_out = nullptr;
+    size_t pin_in_cap = 0, pin_out_cap = 0;       // floats
     int64_t host_chunk_streams = 0;               // streams per staged chunk of the last host call (0: the whole batch in one piece, serial)
     int64_t host_chunk_reserved = 0, host_reserved_frames = 0;   // aw_spatializer_reserve_host: the chunking its buffers were sized for, and up to which call length
     // what the last aw_spatializer_reserve spent where (microseconds): float64 table build on host threads, table upload (hipMalloc +
