@@ -2,7 +2,9 @@
 
 #include <cmath>
 #include <complex>
+#include <algorithm>
 #include <atomic>
+#include <functional>
 #include <thread>
 
 namespace awh {
@@ -30,6 +32,29 @@ static void fft_inplace(std::vector<cd> &a) {
     }
 }
 
+// fn(0) .. fn(n - 1) on up to n host threads (fn(0) on the calling one).  Nothing throws out of here — the library is a C ABI: a worker
+// records its failure, every started thread is joined on every path, and a thread that cannot be started has its index run inline.
+// false = some fn threw (std::bad_alloc in practice).
+bool parallel_for(int n, const std::function<void(int)> &fn) {
+    std::atomic<bool> failed{false};
+    auto guarded = [&](int i) {
+        try { fn(i); } catch (...) { failed = true; }
+    };
+    {
+        struct Joiner {
+            std::vector<std::thread> t;
+            ~Joiner() { for (auto &w : t) if (w.joinable()) w.join(); }
+        } workers;
+        try { workers.t.reserve((size_t)std::max(0, n - 1)); } catch (...) { failed = true; }
+        for (int i = 1; i < n; ++i) {
+            try { workers.t.emplace_back(guarded, i); }
+            catch (...) { guarded(i); }
+        }
+        if (n > 0) guarded(0);
+    }
+    return !failed.load();
+}
+
 static awk::cf unit(double num, double den) {   // exp(-2 pi i num / den)
     const double a = -2.0 * M_PI * num / den;
     return awk::mk((float)std::cos(a), (float)std::sin(a));
@@ -46,20 +71,22 @@ void build_twiddles(Twiddles &tw) {
         for (int l0 = 0; l0 < 8; ++l0) tw.twb[kb * 8 + l0] = unit((double)l0 * kb, 64.0);
 }
 
-void build_pair_tables(const float *tracks, int n_tracks, int taps, int n_channels,
+bool build_pair_tables(const float *tracks, int n_tracks, int taps, int n_channels,
                        const int32_t *left_track, const int32_t *right_track, int tap_offset,
-                       int tap_count, std::vector<awk::cf2> &out) {
+                       int tap_count, std::vector<awk::cf2> &out, bool pair_threads) {
     const int N = awk::kN;
     const int n_pairs = (n_channels + 1) / 2;
     out.assign((size_t)n_pairs * N, awk::cf2{awk::mk(0, 0), awk::mk(0, 0)});
     const double scale = 1.0 / (2.0 * (double)N);
-    std::vector<cd> zl(N), zr(N);
     auto tap = [&](int track, int i) -> double {
         if (track < 0 || track >= n_tracks) return 0.0;
         const int idx = tap_offset + i;
         return (idx < taps && i < tap_count) ? (double)tracks[(size_t)track * taps + idx] : 0.0;
     };
-    for (int p = 0; p < n_pairs; ++p) {
+    // the pairs write disjoint table entries: one host thread each when the caller allows it (aw_spatializer_create runs the PARTITIONS of a
+    // long HRIR side by side instead, one thread per partition)
+    auto one_pair = [&](int p) {
+        std::vector<cd> zl(N), zr(N);
         const int a = 2 * p, b = 2 * p + 1;
         const int la = left_track[a], ra = right_track[a];
         const int lb = b < n_channels ? left_track[b] : -1, rb = b < n_channels ? right_track[b] : -1;
@@ -82,10 +109,13 @@ void build_pair_tables(const float *tracks, int n_tracks, int taps, int n_channe
             e.a = awk::mk((float)A.real(), (float)A.imag());
             e.b = awk::mk((float)B.real(), (float)B.imag());
         }
-    }
+    };
+    if (pair_threads && n_pairs > 1) return parallel_for(n_pairs, one_pair);
+    for (int p = 0; p < n_pairs; ++p) one_pair(p);
+    return true;
 }
 
-void build_poly_tables(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
+bool build_poly_tables(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
                        const int32_t *right_track, std::vector<awk::cf4> &out) {
     const int N = awk::kN;
     const int Lh = taps / 2 + 1;
@@ -110,10 +140,11 @@ void build_poly_tables(const float *tracks, int n_tracks, int taps, int n_channe
             l2[cp] = left_track[c] < 0 || left_track[c] >= n_tracks ? -1 : left_track[c] * 3 + sel;
             r2[cp] = right_track[c] < 0 || right_track[c] >= n_tracks ? -1 : right_track[c] * 3 + sel;
         }
-        build_pair_tables(bank.data(), n_tracks * 3, Lh, C2, l2.data(), r2.data(), 0, Lh, tab[o]);
+        if (!build_pair_tables(bank.data(), n_tracks * 3, Lh, C2, l2.data(), r2.data(), 0, Lh, tab[o], /*pair_threads=*/true)) return false;
     }
     out.resize((size_t)n_pairs * N);
     for (size_t i = 0; i < out.size(); ++i) { out[i].e = tab[0][i]; out[i].o = tab[1][i]; }
+    return true;
 }
 
 // FFT with a precomputed twiddle table tw[k] = exp(-2 pi i k / n), k < n/2 (every entry one cos/sin in double)

@@ -5,6 +5,7 @@
 // spatializer, shared by every stream.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 #include "../device/tile_ols2.hpp"
@@ -22,16 +23,19 @@ void build_twiddles(Twiddles &tw);
 // [pair][k1][k2] with k = k1 + 16 k2 (see tile_ols.hpp).  Channels whose track index is < 0
 // contribute a zero filter (skipped speakers, HRIRManager.swift:370-372).  `scale` is folded
 // into the tables (1/N for the inverse transform).
-void build_pair_tables(const float *tracks, int n_tracks, int taps, int n_channels,
+// pair_threads: one host thread per channel pair (false: the caller already runs several calls side by side).  false = out of host memory.
+bool build_pair_tables(const float *tracks, int n_tracks, int taps, int n_channels,
                        const int32_t *left_track, const int32_t *right_track, int tap_offset,
-                       int tap_count, std::vector<awk::cf2> &out);
+                       int tap_count, std::vector<awk::cf2> &out, bool pair_threads = false);
+// fn(0) .. fn(n - 1) on up to n host threads; never throws; false = some fn threw (bad_alloc)
+bool parallel_for(int n, const std::function<void(int)> &fn);
 
 // Two-output (polyphase) tables of the 16384-frame window path (device/tile_ols2.hpp): the 2C pseudo-channels
 // (parity * C + channel) against the half-rate polyphase components of every HRIR,
 //   even outputs: even-frame channel -> h[2j],   odd-frame channel -> h[2j-1] (j >= 1)
 //   odd  outputs: even-frame channel -> h[2j+1], odd-frame channel -> h[2j]
 // laid out [pseudo-pair][k1][k2] of {A_e, B_e, A_o, B_o}.  Half-rate filter length = taps / 2 + 1.
-void build_poly_tables(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
+bool build_poly_tables(const float *tracks, int n_tracks, int taps, int n_channels, const int32_t *left_track,
                        const int32_t *right_track, std::vector<awk::cf4> &out);
 inline int poly_history_frames(int taps) { return 2 * (taps / 2); }          // real frames kept between calls (= N2 - hop)
 

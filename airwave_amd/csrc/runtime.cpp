@@ -421,25 +421,37 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
             if (et != hipSuccess) { aw_spatializer_destroy(sp); return awr::hip_fail(et, "spatializer setup"); }
         }
     }
-    std::vector<awk::cf2> tab, all;
-    if (sp->fused2) {
-        std::vector<awk::cf4> t4;
-        awh::build_poly_tables(hrir->tracks.data(), hrir->n_tracks, hrir->taps, n_in, left_track, right_track, t4);
-        all.resize(t4.size() * 2);
-        std::memcpy(all.data(), t4.data(), t4.size() * sizeof(awk::cf4));
-        all.resize(all.size() + 2 * (size_t)awk::kN, awk::cf2{awk::mk(0.f, 0.f), awk::mk(0.f, 0.f)});   // the zero pair
-    } else {
-        for (int q = 0; q < sp->partitions; ++q) {
-            const int off = sp->path == 0 ? 0 : q * sp->hop;
-            const int cnt = sp->path == 0 ? hrir->taps : sp->hop;
-            awh::build_pair_tables(hrir->tracks.data(), hrir->n_tracks, hrir->taps, n_in, left_track, right_track, off,
-                                   cnt, tab);
-            all.insert(all.end(), tab.begin(), tab.end());
+    // The tables of the short-call kernels (fused tiles, partitioned delay line) are built in float64 on the host, the analogue of the
+    // partition FFTs of ConvolutionEngine.init (ConvolutionEngine.swift:141-175) — the partitions of a long HRIR side by side, one host
+    // thread each (round 5; cfg 3: 8 partitions x 4 pairs of 8192-point transforms, 48 ms on one thread).  Nothing throws across the ABI.
+    std::vector<awk::cf2> all;
+    bool tables_ok = true;
+    try {
+        if (sp->fused2) {
+            std::vector<awk::cf4> t4;
+            tables_ok = awh::build_poly_tables(hrir->tracks.data(), hrir->n_tracks, hrir->taps, n_in, left_track, right_track, t4);
+            all.resize(t4.size() * 2);
+            std::memcpy(all.data(), t4.data(), t4.size() * sizeof(awk::cf4));
+            all.resize(all.size() + 2 * (size_t)awk::kN, awk::cf2{awk::mk(0.f, 0.f), awk::mk(0.f, 0.f)});   // the zero pair
+        } else {
+            const int P = sp->partitions;
+            std::vector<std::vector<awk::cf2>> tabs((size_t)P);
+            tables_ok = awh::parallel_for(P, [&](int q) {
+                const int off = sp->path == 0 ? 0 : q * sp->hop;
+                const int cnt = sp->path == 0 ? hrir->taps : sp->hop;
+                if (!awh::build_pair_tables(hrir->tracks.data(), hrir->n_tracks, hrir->taps, n_in, left_track, right_track, off, cnt, tabs[(size_t)q],
+                                            /*pair_threads=*/P == 1))
+                    throw std::bad_alloc();
+            });
+            for (int q = 0; q < P && tables_ok; ++q) all.insert(all.end(), tabs[(size_t)q].begin(), tabs[(size_t)q].end());
+            // fused path: one all-zero pair after the last one — a phantom pair (odd pair count in the runtime-loop
+            // kernels; stray lanes of non-float4 frames) multiplies it and contributes nothing
+            if (sp->path == 0) all.resize(all.size() + awk::kN, awk::cf2{awk::mk(0.f, 0.f), awk::mk(0.f, 0.f)});
         }
-        // fused path: one all-zero pair after the last one — a phantom pair (odd pair count in the runtime-loop
-        // kernels; stray lanes of non-float4 frames) multiplies it and contributes nothing
-        if (sp->path == 0) all.resize(all.size() + awk::kN, awk::cf2{awk::mk(0.f, 0.f), awk::mk(0.f, 0.f)});
+    } catch (...) {
+        tables_ok = false;
     }
+    if (!tables_ok) { aw_spatializer_destroy(sp); return fail(AW_ERR_OUT_OF_MEMORY, "filter tables: host memory"); }
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&sp->d_tab), all.size() * sizeof(awk::cf2));
     if (e == hipSuccess) e = hipMemcpy(sp->d_tab, all.data(), all.size() * sizeof(awk::cf2), hipMemcpyHostToDevice);
     if (e != hipSuccess) { aw_spatializer_destroy(sp); return awr::hip_fail(e, "filter tables"); }
