@@ -241,12 +241,17 @@ def test_reserve_builds_the_tables_and_process_builds_none(aw, oracle):
     sp.reserve(F)
     built, held = sp.info()["long_window_table_sets"], sp.info()["scratch_bytes"]
     assert built >= 1 and held > 0
+    i0 = sp.info()
+    assert i0["reserve_tables_ms"] > 0 and i0["reserve_tables_ms"] + i0["reserve_upload_ms"] + i0["reserve_scratch_ms"] < 5000      # what bench.py prints as config.activation
+    allocs, copies = i0["device_allocs"], i0["sync_copies"]
     y = torch.empty((S, F, 2), dtype=torch.float32, device="cuda")
     for n in (F, 200000, 4096, F):                           # long, shorter (an existing window length or the partitioned kernels), short, long
         sp.reset()
         sp.process_device(x.data_ptr(), y.data_ptr(), n)     # (a call of n frames reads the streams packed with stride n)
         torch.cuda.synchronize()
         assert sp.info()["long_window_table_sets"] == built and sp.info()["scratch_bytes"] == held, (n, sp.info())
+        # the library's own count: a reserved spatializer makes no hipMalloc and no blocking hipMemcpy on its process path
+        assert (sp.info()["device_allocs"], sp.info()["sync_copies"]) == (allocs, copies), (n, sp.info())
     assert sp.info()["long_window_rows"] > 0
     xs = x[1].cpu().numpy()
     assert oracle.peak_rel_error(y[1].cpu().numpy()[:50000], oracle.spatialize_f64(xs[:50000], h, lt, rt)) < TOL
