@@ -27,6 +27,8 @@ SIGNATURES = {
     "aw_context_stream": (_V, [_V]),
     "aw_context_timer_start": (_I32, [_V]),
     "aw_context_timer_stop": (_I32, [_V, c_float_p]),
+    "aw_context_reserve_scratch": (_I32, [_V, _SZ]),
+    "aw_context_scratch_bytes": (_SZ, [_V]),
     "aw_context_bandwidth_probe": (_I32, [_V, _SZ, _I32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "aw_context_pcie_probe": (_I32, [_V, _SZ, _I32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "aw_host_alloc_pinned": (_I32, [_V, _SZ, c_void_pp]),

@@ -114,6 +114,14 @@ class Context:
         _check(self._lib.aw_context_timer_stop(self._h, ctypes.byref(ms)))
         return float(ms.value)
 
+    def reserve_scratch(self, nbytes: int) -> None:
+        """Size the context's scratch pool (shared by its spatializers) ahead of time: the one large hipMalloc at start-up."""
+        _check(self._lib.aw_context_reserve_scratch(self._h, int(nbytes)))
+
+    @property
+    def scratch_bytes(self) -> int:
+        return int(self._lib.aw_context_scratch_bytes(self._h))
+
     def bandwidth_probe(self, nbytes: int = 4 << 30, repetitions: int = 3) -> Dict[str, float]:
         """Measured read-only / write-only / copy rates of this device in GB/s (copy = bytes read + bytes written per second):
         the ceiling SURVEY.md 8d asks to quote next to the vendor peak."""

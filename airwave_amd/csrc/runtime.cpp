@@ -170,6 +170,24 @@ aw_status aw_context_timer_stop(aw_context *c, float *ms) {
     return AW_OK;
 }
 
+/* The context's scratch pool (runtime.hpp), sized ahead of time: a host that knows its largest batch pays the one large hipMalloc at
+ * start-up (its wall time is erratic on these boxes: 0.2 ms ... 3.7 s, profiles/round5_v1/alloc_probe.txt) instead of inside the first
+ * aw_spatializer_reserve / process that needs it.  Grow-only; bytes the pool already holds are kept. */
+aw_status aw_context_reserve_scratch(aw_context *c, size_t bytes) {
+    if (!c) return fail(AW_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    AW_HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->launch_mu);
+    const size_t need = (bytes + sizeof(awk::cf) - 1) / sizeof(awk::cf);
+    if (c->pool_capacity >= need) return AW_OK;
+    if (c->d_pool) AW_HIP_TRY(hipFree(c->d_pool));          // (hipFree waits for the device: nothing still reads the old buffer)
+    c->d_pool = nullptr; c->pool_capacity = 0;
+    AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_pool), need * sizeof(awk::cf)));
+    c->device_allocs += 1;
+    c->pool_capacity = need;
+    return AW_OK;
+}
+size_t aw_context_scratch_bytes(const aw_context *c) { return c ? c->pool_capacity * sizeof(awk::cf) : 0; }
+
 /* Measured ceilings of the device the context runs on ("confirm on the box and also quote a measured copy-kernel
  * ceiling"; bench.py's roofline.measured).  Own buffers, freed before returning; blocks; never on a process path. */
 aw_status aw_context_bandwidth_probe(aw_context *c, size_t bytes, int32_t repetitions, double *read_gbs, double *write_gbs, double *copy_gbs) {

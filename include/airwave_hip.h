@@ -71,6 +71,13 @@ AW_API void *aw_context_stream(aw_context *ctx);          /* the hipStream_t ker
 AW_API aw_status aw_context_timer_start(aw_context *ctx);
 AW_API aw_status aw_context_timer_stop(aw_context *ctx, float *elapsed_ms); /* records, syncs, returns ms */
 
+/* The HBM scratch of the multi-kernel paths (long HRIRs, long calls) is ONE grow-only pool per context, shared by the
+ * spatializers created on it.  aw_spatializer_reserve grows it as needed; a host that knows its largest batch can size it at
+ * start-up instead (one large hipMalloc, whose wall time varies from 0.2 ms to seconds on MI355X boxes).  The analogue of
+ * allocating every engine buffer in ConvolutionEngine.init (ConvolutionEngine.swift:97-138), hoisted to the context. */
+AW_API aw_status aw_context_reserve_scratch(aw_context *ctx, size_t bytes);
+AW_API size_t aw_context_scratch_bytes(const aw_context *ctx);
+
 /* Measured ceilings of the device (bench / diagnostics; blocks, allocates its own buffers, never on a process path).
  * aw_context_bandwidth_probe: a read-only, a write-only and a copy kernel over `bytes` (>= 64 MiB) of HBM each, best of
  * `repetitions`; GB/s, the copy's figure counting bytes read + bytes written.  SURVEY.md 8d asks for this next to the

@@ -30,6 +30,8 @@ class Context {
     Context &operator=(const Context &) = delete;
     aw_context *get() const { return h_; }
     void synchronize() { check(aw_context_synchronize(h_)); }
+    void reserveScratch(size_t bytes) { check(aw_context_reserve_scratch(h_, bytes)); }      // the pool its spatializers share, sized at start-up
+    size_t scratchBytes() const { return aw_context_scratch_bytes(h_); }
   private:
     aw_context *h_ = nullptr;
 };

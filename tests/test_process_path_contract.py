@@ -208,3 +208,30 @@ def test_two_handles_of_one_context_driven_from_two_threads(oracle):
     for i in range(2):
         for k in range(20):
             assert np.array_equal(got[i][k], refs[i][k]), (i, k)
+
+
+@pytest.mark.gpu
+def test_context_scratch_pool_sized_at_start_up(oracle):
+    """aw_context_reserve_scratch: a host pays the one large hipMalloc when it creates the context; the spatializers created on it later
+    find the pool there (their reserve adds no scratch allocation), share it, and still give the right samples."""
+    import torch
+    import airwave_amd as aw
+    ctx = aw.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    assert ctx.scratch_bytes == 0
+    ctx.reserve_scratch(1 << 30)
+    assert ctx.scratch_bytes >= 1 << 30
+    h = oracle.synth_hrir(14, 20000, seed=9)
+    lt, rt = np.array([0, 8, 6], np.int32), np.array([1, 7, 13], np.int32)
+    S, F = 2, 120000
+    x = torch.empty((S, F, 3), dtype=torch.float32, device="cuda")
+    ctx.synth_fill(x.data_ptr(), S, F, 3, seed=4)
+    y = torch.empty((S, F, 2), dtype=torch.float32, device="cuda")
+    sp = aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=S, ctx=ctx)
+    pool = ctx.scratch_bytes
+    sp.reserve(F)
+    assert ctx.scratch_bytes == pool and sp.info()["reserve_scratch_ms"] < 20.0          # nothing to allocate: the pool was there
+    ctx.reserve_scratch(1 << 20)                                                           # never shrinks
+    assert ctx.scratch_bytes == pool
+    sp.process_device(x.data_ptr(), y.data_ptr(), F)
+    torch.cuda.synchronize()
+    assert oracle.peak_rel_error(y[1].cpu().numpy(), oracle.spatialize_f64(x[1].cpu().numpy(), h, lt, rt)) < 1e-5
