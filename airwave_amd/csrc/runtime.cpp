@@ -7,8 +7,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <new>
+#include <thread>
 
 #include "device/eq_kernels.hpp"
 #include "host/tables.hpp"
@@ -20,6 +22,67 @@
 
 // table sets a spatializer can hold: one per long-window length (kLwRowChoices below); lw_plans reserves this many at create
 static constexpr size_t kLwPlanSlots = 16;
+
+// Host threads that copy slices of ONE buffer at a time: the multi-stream host entry bounces pageable caller memory through page-locked
+// chunks with them (one thread copies ~10 GB/s, PCIe Gen5 moves 57 GB/s each way).  copy() blocks; the caller copies a slice too.
+struct aw_context::CopyPool {
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    char *dst = nullptr; const char *src = nullptr;
+    size_t bytes = 0, slice = 0;
+    int n_slices = 0, next = 0, done = 0;
+    unsigned long long gen = 0;
+    bool stop = false;
+    explicit CopyPool(int n) {
+        for (int i = 0; i < n; ++i) {
+            try { workers.emplace_back([this] { run(); }); } catch (...) { break; }          // fewer threads: the caller's own slice loop still finishes the job
+        }
+    }
+    ~CopyPool() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv_work.notify_all();
+        for (auto &w : workers) if (w.joinable()) w.join();
+    }
+    bool take(int &i) { if (next >= n_slices) return false; i = next++; return true; }       // under m
+    void slice_copy(int i) {
+        const size_t off = (size_t)i * slice, n = std::min(slice, bytes - off);
+        std::memcpy(dst + off, src + off, n);
+    }
+    void run() {
+        unsigned long long seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv_work.wait(lk, [&] { return stop || (gen != seen && next < n_slices); });
+            if (stop) return;
+            seen = gen;
+            int i;
+            while (take(i)) {
+                lk.unlock();
+                slice_copy(i);
+                lk.lock();
+                if (++done == n_slices) cv_done.notify_all();
+            }
+        }
+    }
+    void copy(void *d, const void *s_, size_t n) {
+        if (n == 0) return;
+        std::unique_lock<std::mutex> lk(m);
+        dst = static_cast<char *>(d); src = static_cast<const char *>(s_); bytes = n;
+        const int parts = (int)std::min<size_t>(workers.size() + 1, std::max<size_t>(1, n >> 20));      // slices of >= 1 MiB
+        slice = ((n + parts - 1) / parts + 4095) & ~(size_t)4095;
+        n_slices = (int)((n + slice - 1) / slice); next = 0; done = 0; ++gen;
+        cv_work.notify_all();
+        int i;
+        while (take(i)) {
+            lk.unlock();
+            slice_copy(i);
+            lk.lock();
+            ++done;
+        }
+        cv_done.wait(lk, [&] { return done == n_slices; });
+    }
+};
 
 namespace awr {
 
@@ -129,6 +192,7 @@ void aw_context_destroy(aw_context *c) {
     if (c->d_twb) (void)hipFree(c->d_twb);
     if (c->d_zeros) (void)hipFree(c->d_zeros);
     if (c->d_pool) (void)hipFree(c->d_pool);
+    delete c->copy_pool;
     if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
     if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
     for (int i = 0; i < 2; ++i) {
@@ -509,6 +573,8 @@ void aw_spatializer_destroy(aw_spatializer *sp) {
     if (sp->d_stage_out) (void)hipFree(sp->d_stage_out);
     if (sp->h_pin_in) (void)hipHostFree(sp->h_pin_in);
     if (sp->h_pin_out) (void)hipHostFree(sp->h_pin_out);
+    if (sp->h_bounce_in) (void)hipHostFree(sp->h_bounce_in);
+    if (sp->h_bounce_out) (void)hipHostFree(sp->h_bounce_out);
     if (sp->k0) (void)hipEventDestroy(sp->k0);
     if (sp->k1) (void)hipEventDestroy(sp->k1);
     for (auto &pr : sp->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1210,8 +1276,20 @@ static int64_t host_chunk_streams(const aw_spatializer *sp, int64_t frames) {
     return std::min<int64_t>(cs, (sp->n_streams + 1) / 2);
 }
 
+// Page-locked (hipHostMalloc / hipHostRegister) memory moves by DMA as it is; anything else is bounced.
+static bool host_ptr_is_pinned(const void *p) {
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }     // (plain malloc'ed memory: invalid value)
+    return a.type == hipMemoryTypeHost;
+}
+
 static aw_status host_pipeline_objects(aw_context *c) {
     if (c->s_h2d) return AW_OK;
+    if (!c->copy_pool) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        c->copy_pool = new (std::nothrow) aw_context::CopyPool((int)std::min(12u, std::max(1u, hw / 4)));
+        if (!c->copy_pool) return fail(AW_ERR_OUT_OF_MEMORY, "copy threads");
+    }
     AW_HIP_TRY(hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
     AW_HIP_TRY(hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
@@ -1222,10 +1300,16 @@ static aw_status host_pipeline_objects(aw_context *c) {
     return AW_OK;
 }
 
-static aw_status host_stage_buffers(aw_spatializer *sp, int64_t frames, int64_t cs) {
+static aw_status sp_grow_pinned(aw_spatializer *sp, float **buf, size_t *cap, size_t need);
+
+// bounce: also the page-locked chunks that pageable caller buffers go through (aw_spatializer_reserve_host makes them; a call on pageable
+// memory that was not reserved for makes them on its first use)
+static aw_status host_stage_buffers(aw_spatializer *sp, int64_t frames, int64_t cs, bool bounce_in = false, bool bounce_out = false) {
     const size_t streams = cs > 0 ? 2 * (size_t)cs : (size_t)sp->n_streams;           // two chunks in flight each way, or the whole batch
     aw_status st = sp_grow(sp, &sp->d_stage_in, &sp->stage_in_cap, streams * frames * sp->n_channels);
     if (st == AW_OK) st = sp_grow(sp, &sp->d_stage_out, &sp->stage_out_cap, streams * frames * 2);
+    if (st == AW_OK && cs > 0 && bounce_in) st = sp_grow_pinned(sp, &sp->h_bounce_in, &sp->bounce_in_cap, streams * frames * sp->n_channels);
+    if (st == AW_OK && cs > 0 && bounce_out) st = sp_grow_pinned(sp, &sp->h_bounce_out, &sp->bounce_out_cap, streams * frames * 2);
     return st;
 }
 
@@ -1235,7 +1319,7 @@ aw_status aw_spatializer_reserve_host(aw_spatializer *sp, int64_t max_frames) {
     std::lock_guard<std::mutex> lk(sp->ctx->launch_mu);
     const int64_t cs = host_chunk_streams(sp, max_frames);
     if (cs > 0) { st = host_pipeline_objects(sp->ctx); if (st != AW_OK) return st; }
-    st = host_stage_buffers(sp, max_frames, cs);
+    st = host_stage_buffers(sp, max_frames, cs, /*bounce_in=*/true, /*bounce_out=*/true);
     if (st == AW_OK) { sp->host_chunk_streams = cs; sp->host_chunk_reserved = cs; sp->host_reserved_frames = std::max(sp->host_reserved_frames, max_frames); }
     return st;
 }
@@ -1261,7 +1345,8 @@ aw_status aw_spatializer_process_host(aw_spatializer *sp, const float *in, float
     int64_t cs = host_chunk_streams(sp, frames);
     // a reserved spatializer keeps the chunking its buffers were sized for (never a reallocation on this path)
     if (frames <= sp->host_reserved_frames) cs = sp->host_chunk_reserved > 0 ? (cs > 0 ? std::min(cs, sp->host_chunk_reserved) : sp->host_chunk_reserved) : 0;
-    aw_status st = host_stage_buffers(sp, frames, cs);
+    const bool page_in = cs > 0 && !host_ptr_is_pinned(in), page_out = cs > 0 && !host_ptr_is_pinned(out);
+    aw_status st = host_stage_buffers(sp, frames, cs, page_in, page_out);
     if (st == AW_OK && cs > 0) st = host_pipeline_objects(c);
     if (st != AW_OK) return st;
     sp->host_chunk_streams = cs;
@@ -1278,25 +1363,49 @@ aw_status aw_spatializer_process_host(aw_spatializer *sp, const float *in, float
     // whatever the context's stream still holds (an earlier device-buffer call of this spatializer) comes first
     AW_HIP_TRY(hipEventRecord(c->ev_run[0], c->stream));
     AW_HIP_TRY(hipStreamWaitEvent(c->s_h2d, c->ev_run[0], 0));
+    // Pageable caller memory is bounced through page-locked chunks by the context's copy threads: the copy INTO slot k & 1 runs while the
+    // DMA engines move chunk k-1, the copy OUT of chunk k-1 while the kernels of chunk k run (round 5; before: hipMemcpyAsync on the
+    // pageable pointers themselves, which the HIP runtime stages on one thread).
     int k = 0;
-    for (int64_t s0 = 0; s0 < sp->n_streams; s0 += cs, ++k) {
+    int64_t prev_s0 = -1; int prev_ns = 0;
+    hipError_t he = hipSuccess;
+    auto drain_prev = [&](int slot_prev) {          // chunk k-1's output: wait for its D2H, then copy it to the caller's buffer
+        if (!page_out || prev_s0 < 0 || he != hipSuccess) return;
+        he = hipEventSynchronize(c->ev_d2h[slot_prev]);
+        if (he == hipSuccess) c->copy_pool->copy(out + (size_t)prev_s0 * out_ps, sp->h_bounce_out + (size_t)slot_prev * cs * out_ps, (size_t)prev_ns * out_ps * sizeof(float));
+    };
+    for (int64_t s0 = 0; s0 < sp->n_streams && he == hipSuccess; s0 += cs, ++k) {
         const int ns = (int)std::min<int64_t>(cs, sp->n_streams - s0), slot = k & 1;
         float *d_in = sp->d_stage_in + (size_t)slot * cs * in_ps, *d_out = sp->d_stage_out + (size_t)slot * cs * out_ps;
-        if (k >= 2) AW_HIP_TRY(hipStreamWaitEvent(c->s_h2d, c->ev_run[slot], 0));              // chunk k-2's kernels have read this slot
-        AW_HIP_TRY(hipMemcpyAsync(d_in, in + (size_t)s0 * in_ps, (size_t)ns * in_ps * sizeof(float), hipMemcpyHostToDevice, c->s_h2d));
-        AW_HIP_TRY(hipEventRecord(c->ev_h2d[slot], c->s_h2d));
-        AW_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_h2d[slot], 0));
-        if (k >= 2) AW_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_d2h[slot], 0));             // chunk k-2's output has left this slot
+        const float *src = in + (size_t)s0 * in_ps;
+        if (page_in) {
+            float *b = sp->h_bounce_in + (size_t)slot * cs * in_ps;
+            if (k >= 2) he = hipEventSynchronize(c->ev_h2d[slot]);                              // chunk k-2's H2D has read this bounce slot
+            if (he != hipSuccess) break;
+            c->copy_pool->copy(b, src, (size_t)ns * in_ps * sizeof(float));
+            src = b;
+        }
+        if (k >= 2) he = hipStreamWaitEvent(c->s_h2d, c->ev_run[slot], 0);                      // chunk k-2's kernels have read this device slot
+        if (he == hipSuccess) he = hipMemcpyAsync(d_in, src, (size_t)ns * in_ps * sizeof(float), hipMemcpyHostToDevice, c->s_h2d);
+        if (he == hipSuccess) he = hipEventRecord(c->ev_h2d[slot], c->s_h2d);
+        if (he == hipSuccess) he = hipStreamWaitEvent(c->stream, c->ev_h2d[slot], 0);
+        if (he == hipSuccess && k >= 2) he = hipStreamWaitEvent(c->stream, c->ev_d2h[slot], 0); // chunk k-2's output has left this device slot
+        if (he != hipSuccess) break;
         st = sp_run_streams(sp, lw, (int)s0, ns, d_in, d_out, frames);
         if (st != AW_OK) break;
-        AW_HIP_TRY(hipEventRecord(c->ev_run[slot], c->stream));
-        AW_HIP_TRY(hipStreamWaitEvent(c->s_d2h, c->ev_run[slot], 0));
-        AW_HIP_TRY(hipMemcpyAsync(out + (size_t)s0 * out_ps, d_out, (size_t)ns * out_ps * sizeof(float), hipMemcpyDeviceToHost, c->s_d2h));
-        AW_HIP_TRY(hipEventRecord(c->ev_d2h[slot], c->s_d2h));
+        he = hipEventRecord(c->ev_run[slot], c->stream);
+        if (he == hipSuccess) he = hipStreamWaitEvent(c->s_d2h, c->ev_run[slot], 0);
+        float *dst = page_out ? sp->h_bounce_out + (size_t)slot * cs * out_ps : out + (size_t)s0 * out_ps;   // (bounce slot: chunk k-2's copy-out finished on this thread)
+        if (he == hipSuccess) he = hipMemcpyAsync(dst, d_out, (size_t)ns * out_ps * sizeof(float), hipMemcpyDeviceToHost, c->s_d2h);
+        if (he == hipSuccess) he = hipEventRecord(c->ev_d2h[slot], c->s_d2h);
+        drain_prev(slot ^ 1);
+        prev_s0 = s0; prev_ns = ns;
     }
     const hipError_t e1 = hipStreamSynchronize(c->s_h2d), e2 = hipStreamSynchronize(c->stream), e3 = hipStreamSynchronize(c->s_d2h);
     if (st != AW_OK) return st;          // (a failed chunk: the streams are drained, the history has not been flipped)
-    AW_HIP_TRY(e1); AW_HIP_TRY(e2); AW_HIP_TRY(e3);
+    AW_HIP_TRY(he); AW_HIP_TRY(e1); AW_HIP_TRY(e2); AW_HIP_TRY(e3);
+    drain_prev((k - 1) & 1);             // the last chunk's output
+    AW_HIP_TRY(he);
     sp->hist_cur ^= 1;
     return AW_OK;
 }

@@ -46,6 +46,8 @@ struct aw_context {
     std::atomic<long long> device_allocs{0};                        // hipMalloc / hipHostMalloc calls made on behalf of this context's handles (tests: a reserved process path makes none)
     std::atomic<long long> sync_copies{0};                          // blocking hipMemcpy calls likewise (table uploads)
     // host-entry pipeline (aw_spatializer_process_host on a multi-stream batch): H2D of chunk k+1 || kernels of chunk k || D2H of chunk k-1
+    struct CopyPool;                                                // a few host threads that copy slices of one buffer at a time (runtime.cpp)
+    CopyPool *copy_pool = nullptr;                                  // made with the pipeline objects; pageable caller buffers are bounced through page-locked chunks by it
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_run[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
 };
@@ -94,6 +96,9 @@ struct aw_spatializer {
     // and write DIRECTLY over PCIe — no copy engine, no (de)interleave kernels: the caller's samples are (de)interleaved by the CPU on the way
     float *h_pin_in = nullptr, *h_pin_out = nullptr;
     size_t pin_in_cap = 0, pin_out_cap = 0;       // floats
+    // multi-stream host entry on PAGEABLE caller buffers: page-locked bounce chunks (two each way), filled / drained by the context's copy threads
+    float *h_bounce_in = nullptr, *h_bounce_out = nullptr;
+    size_t bounce_in_cap = 0, bounce_out_cap = 0; // floats (both slots)
     int64_t host_chunk_streams = 0;               // streams per staged chunk of the last host call (0: the whole batch in one piece, serial)
     int64_t host_chunk_reserved = 0, host_reserved_frames = 0;   // aw_spatializer_reserve_host: the chunking its buffers were sized for, and up to which call length
     // what the last aw_spatializer_reserve spent where (microseconds): float64 table build on host threads, table upload (hipMalloc +

@@ -557,7 +557,7 @@ def end_to_end(name: str, args, ctx, streams: int = 0, pcie: dict = None):
            "bytes_in": in_b, "bytes_out": out_b, "streams_per_chunk": chunk, "chunks": -(-S // chunk) if chunk else 1,
            "pipeline": "H2D of chunk k+1 || kernels of chunk k || D2H of chunk k-1 on three HIP streams; two staged chunks each way",
            "pageable": {"value": S * F / t_page, "ms_per_batch": t_page * 1e3, "pinned": False,
-                        "note": "same entry on pageable numpy arrays: hipMemcpyAsync stages them through the runtime's own pinned buffers"},
+                        "note": "same entry on pageable numpy arrays: bounced through page-locked chunks by the context's host copy threads"},
            "pinned_alloc_ms": round(pin_ms, 1)}
     if err is not None:
         res["parity_spot_err"] = err

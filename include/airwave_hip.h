@@ -129,7 +129,7 @@ AW_API void aw_spatializer_destroy(aw_spatializer *sp);
 AW_API aw_status aw_spatializer_process(aw_spatializer *sp, const float *in_device, float *out_device, int64_t frames);
 /* Same with HOST buffers; synchronous.  A multi-stream batch crosses PCIe in chunks of streams, double buffered on three HIP
  * streams (H2D of chunk k+1 || kernels of chunk k || D2H of chunk k-1; streams are independent, so chunks are); page-locked
- * buffers (aw_host_alloc_pinned) move by DMA directly, pageable ones through the HIP runtime's staging.  Small batches and
+ * buffers (aw_host_alloc_pinned) move by DMA directly, pageable ones are bounced through page-locked chunks by host copy threads.  Small batches and
  * single streams (the plug-in shaped calls of aw_engine_* / aw_realtime_*) go in one piece. */
 AW_API aw_status aw_spatializer_process_host(aw_spatializer *sp, const float *in_host, float *out_host, int64_t frames);
 /* aw_spatializer_reserve plus the device-side staging of the host entry for calls of up to max_frames frames (two chunks
