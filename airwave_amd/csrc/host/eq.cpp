@@ -89,13 +89,16 @@ struct Cursor {
         while (!end() && is_space(s[i])) { ++i; ++n; }
         return n;
     }
-    // ASCII case-insensitive keyword at the cursor
+    // case-insensitive keyword at the cursor, as ICU's .caseInsensitive compares: simple case foldings, i.e. the ASCII pairs plus
+    // U+212A KELVIN SIGN -> k and U+017F LATIN SMALL LETTER LONG S -> s
     bool keyword(const char *kw) {
         const size_t n = std::strlen(kw);
         if (i + n > s.size()) return false;
         for (size_t k = 0; k < n; ++k) {
             unsigned c = s[i + k];
             if (c >= 'A' && c <= 'Z') c += 32;
+            else if (c == 0x212A) c = 'k';
+            else if (c == 0x17F) c = 's';
             unsigned e = (unsigned char)kw[k];
             if (e >= 'A' && e <= 'Z') e += 32;
             if (c != e) return false;
@@ -175,8 +178,9 @@ bool match_filter(const std::vector<unsigned> &line, std::string &number, bool &
     else if (c.keyword("off")) on = false;
     else return false;
     if (c.skip_ws() == 0) return false;
-    if (c.keyword("pk")) type = 0;
-    else if (c.keyword("lsc")) type = 1;
+    const size_t type_at = c.i;
+    if (c.keyword("pk")) type = c.s[type_at + 1] == 0x212A ? -1 : 0;      // :91-99: "P\u212A".uppercased() is not "PK" -> unsupported filter type
+    else if (c.keyword("lsc")) type = 1;                                    //         (a long s uppercases to S and is accepted)
     else if (c.keyword("hsc")) type = 2;
     else return false;
     if (c.skip_ws() == 0 || !c.keyword("fc") || c.skip_ws() == 0 || !c.token(fc)) return false;
@@ -243,6 +247,10 @@ bool eq_parse(const void *data, size_t len, EqDefinition &def, std::vector<EqIss
             int type = 0;
             if (!match_filter(line, number, on, type, fc, gain, q)) {
                 issues.push_back({line_number, "malformed Filter directive"});
+                continue;
+            }
+            if (type < 0) {
+                issues.push_back({line_number, "unsupported filter type"});
                 continue;
             }
             double f = 0, g = 0, qq = 0;

@@ -49,11 +49,53 @@ bool in_set(const std::string &s, const char *const *set, int n) {
     return false;
 }
 
-std::string trim_ws(const std::string &s) {   // .whitespaces: space and tab
+// CharacterSet.whitespaces = general category Zs + TAB, as UTF-8 byte sequences; returns the length of the one at s[i] (0: none)
+size_t ws_at(const std::string &s, size_t i) {
+    const unsigned char c = (unsigned char)s[i];
+    if (c == ' ' || c == '\t') return 1;
+    if (c == 0xC2 && i + 1 < s.size() && (unsigned char)s[i + 1] == 0xA0) return 2;                      // U+00A0
+    if (i + 2 >= s.size()) return 0;
+    const unsigned char d = (unsigned char)s[i + 1], e = (unsigned char)s[i + 2];
+    if (c == 0xE1 && d == 0x9A && e == 0x80) return 3;                                                     // U+1680
+    if (c == 0xE2 && d == 0x80 && ((e >= 0x80 && e <= 0x8A) || e == 0xAF)) return 3;                      // U+2000-200A, U+202F
+    if (c == 0xE2 && d == 0x81 && e == 0x9F) return 3;                                                     // U+205F
+    if (c == 0xE3 && d == 0x80 && e == 0x80) return 3;                                                     // U+3000
+    return 0;
+}
+std::string trim_ws(const std::string &s) {   // trimmingCharacters(in: .whitespaces)
     size_t a = 0, b = s.size();
-    while (a < b && (s[a] == ' ' || s[a] == '\t')) ++a;
-    while (b > a && (s[b - 1] == ' ' || s[b - 1] == '\t')) --b;
+    for (size_t n; a < b && (n = ws_at(s, a)) > 0 && a + n <= b;) a += n;
+    for (bool again = true; again && b > a;) {
+        again = false;
+        for (size_t n = 1; n <= 3 && n <= b - a; ++n)
+            if (ws_at(s, b - n) == n) { b -= n; again = true; break; }
+    }
     return s.substr(a, b - a);
+}
+// CharacterSet.newlines = U+000A-000D, U+0085, U+2028, U+2029: components(separatedBy:) splits at EVERY such scalar
+std::vector<std::string> split_newlines(const std::string &t) {
+    std::vector<std::string> out(1);
+    for (size_t i = 0; i < t.size(); ++i) {
+        const unsigned char c = (unsigned char)t[i];
+        size_t n = 0;
+        if (c >= 0x0A && c <= 0x0D) n = 1;
+        else if (c == 0xC2 && i + 1 < t.size() && (unsigned char)t[i + 1] == 0x85) n = 2;
+        else if (c == 0xE2 && i + 2 < t.size() && (unsigned char)t[i + 1] == 0x80 && ((unsigned char)t[i + 2] == 0xA8 || (unsigned char)t[i + 2] == 0xA9)) n = 3;
+        if (n) { out.emplace_back(); i += n - 1; }
+        else out.back().push_back(t[i]);
+    }
+    return out;
+}
+// String.uppercased() as far as it can reach the ASCII alias table: ASCII letters, U+017F LONG S -> S, U+FB02 "fl" ligature -> FL
+std::string alias_upper(const std::string &s) {
+    std::string u;
+    for (size_t i = 0; i < s.size(); ++i) {
+        const unsigned char c = (unsigned char)s[i];
+        if (c == 0xC5 && i + 1 < s.size() && (unsigned char)s[i + 1] == 0xBF) { u.push_back('S'); ++i; }
+        else if (c == 0xEF && i + 2 < s.size() && (unsigned char)s[i + 1] == 0xAC && (unsigned char)s[i + 2] == 0x82) { u += "FL"; i += 2; }
+        else u.push_back(c < 0x80 ? (char)std::toupper(c) : (char)c);
+    }
+    return u;
 }
 
 // Swift Int(String): optional sign + ASCII digits only, nil on Int64 overflow.  The ABI carries indices as
@@ -267,16 +309,11 @@ aw_status aw_map_parse_text(const char *text, aw_channel_map **out) {          /
     aw_status st = map_new(out, &m);
     if (st != AW_OK) return st;
     if (!text) { delete m; return fail(AW_ERR_INVALID_ARGUMENT, "text is NULL"); }
-    std::string t(text), norm;
-    for (size_t i = 0; i < t.size(); ++i) {       // .newlines: \n, \r\n, \r
-        if (t[i] == '\r') { norm.push_back('\n'); if (i + 1 < t.size() && t[i + 1] == '\n') ++i; }
-        else norm.push_back(t[i]);
-    }
     static const struct { const char *alias; const char *spk; } A[] = {
         {"FL", "FL"}, {"L", "FL"}, {"FR", "FR"}, {"R", "FR"}, {"FC", "FC"}, {"C", "FC"}, {"LFE", "LFE"}, {"SUB", "LFE"},
         {"BL", "BL"}, {"RL", "BL"}, {"BR", "BR"}, {"RR", "BR"}, {"SL", "SL"}, {"SR", "SR"}, {"TFL", "TFL"},
         {"TFR", "TFR"}, {"TBL", "TBL"}, {"TBR", "TBR"}};
-    for (const std::string &raw : split(norm, '\n')) {
+    for (const std::string &raw : split_newlines(text)) {
         const std::string line = trim_ws(raw);
         if (line.empty() || line[0] == '#' || line[0] == ';') continue;        // :308-311
         const auto parts = split(line, '=');
@@ -288,8 +325,7 @@ aw_status aw_map_parse_text(const char *text, aw_channel_map **out) {          /
             if (swift_int(trim_ws(tok), &v)) idx.push_back(v);                    // compactMap { Int(...) }  :320
         }
         if (idx.size() != 2) continue;                                           // :322
-        std::string upper = name;
-        for (auto &ch : upper) ch = (char)std::toupper((unsigned char)ch);
+        const std::string upper = alias_upper(name);                             // :325
         std::string speaker = name;                                              // default: .custom(speakerName)  :339
         for (const auto &a : A)
             if (upper == a.alias) { speaker = a.spk; break; }

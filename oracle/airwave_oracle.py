@@ -346,15 +346,19 @@ def parse_hesuvi_format(text: str) -> ChannelMap:
     """parseHeSuViFormat  VirtualSpeaker.swift:301-346.  Unknown names become custom speakers keyed by
     the name as written; a later line for the same speaker overwrites an earlier one."""
     m: ChannelMap = {}
-    for line in text.replace("\r\n", "\n").replace("\r", "\n").split("\n"):
-        t = line.strip(" \t")
+    # components(separatedBy: .newlines) splits at every newline scalar (U+000A-000D, U+0085, U+2028, U+2029; CR LF gives an empty
+    # component, which is skipped); .whitespaces is general category Zs plus TAB; String.uppercased() is the full Unicode mapping
+    # (a long s or an "fl" ligature therefore reaches the alias table: Python's str.upper() is the same mapping)
+    ws = " \t\u00a0\u1680\u2000\u2001\u2002\u2003\u2004\u2005\u2006\u2007\u2008\u2009\u200a\u202f\u205f\u3000"
+    for line in _re.split("[\n\x0b\x0c\r\x85\u2028\u2029]", text):
+        t = line.strip(ws)
         if not t or t.startswith("#") or t.startswith(";"):
             continue
         parts = t.split("=")
         if len(parts) != 2:
             continue
-        name = parts[0].strip(" \t")
-        idx = [v for v in (_swift_int(p.strip(" \t")) for p in parts[1].strip(" \t").split(",")) if v is not None]
+        name = parts[0].strip(ws)
+        idx = [v for v in (_swift_int(p.strip(ws)) for p in parts[1].strip(ws).split(",")) if v is not None]
         if len(idx) != 2:
             continue
         speaker = _ALIASES.get(name.upper(), name)
@@ -583,8 +587,31 @@ class EqualizerParseError(ValueError):
         super().__init__(f"Could not read {filename}: {det}")
 
 
-_PREAMP_RE = _re.compile(r"^Preamp\s*:\s*(\S+)\s+dB$", _re.IGNORECASE)
-_FILTER_RE = _re.compile(r"^Filter(?:\s+([0-9]+))?\s*:\s+(ON|OFF)\s+(PK|LSC|HSC)\s+Fc\s+(\S+)\s+Hz\s+Gain\s+(\S+)\s+dB\s+Q\s+(\S+)$", _re.IGNORECASE)
+# NSRegularExpression is ICU: \s is [\t\n\f\r\p{Z}] (NOT Python's str.isspace(), which adds U+001C-001F, VT and NEL), and
+# .caseInsensitive compares simple case foldings: besides the ASCII pairs, U+212A KELVIN SIGN folds to k and U+017F LONG S to s
+# (Python's re.IGNORECASE would also pair i with U+0130 / U+0131, which ICU does not) — so both are spelled out here.
+_S = "[\\t\\n\\f\\r \u00a0\u1680\u2000-\u200a\u2028\u2029\u202f\u205f\u3000]"
+_NS = "[^" + _S[1:]
+_FOLD = {"k": "Kk\u212a", "s": "Ss\u017f"}
+
+
+def _icu(pattern: str) -> "_re.Pattern":
+    out, i = [], 0
+    while i < len(pattern):
+        c = pattern[i]
+        if c == "\\":
+            out.append({"s": _S, "S": _NS}.get(pattern[i + 1], pattern[i:i + 2])); i += 2; continue
+        if c == "[":                           # [0-9]: as written
+            j = pattern.index("]", i); out.append(pattern[i:j + 1]); i = j + 1; continue
+        out.append("[" + _FOLD.get(c.lower(), c.upper() + c.lower()) + "]" if c.isalpha() else c)
+        i += 1
+    return _re.compile("".join(out))
+
+
+_PREAMP_RE = _icu(r"^Preamp\s*:\s*(\S+)\s+dB$")
+_FILTER_RE = _icu(r"^Filter(?:\s+([0-9]+))?\s*:\s+(ON|OFF)\s+(PK|LSC|HSC)\s+Fc\s+(\S+)\s+Hz\s+Gain\s+(\S+)\s+dB\s+Q\s+(\S+)$")
+# CharacterSet.whitespacesAndNewlines: general category Z*, TAB, U+000A-000D, U+0085
+_TRIM = "\t\n\x0b\x0c\r\x85 \u00a0\u1680\u2000\u2001\u2002\u2003\u2004\u2005\u2006\u2007\u2008\u2009\u200a\u2028\u2029\u202f\u205f\u3000"
 
 
 def _finite_double(text: str) -> Optional[float]:
@@ -616,7 +643,7 @@ def eq_parse(data: bytes, filename: str = "preset.txt") -> EqualizerDefinition:
     # component and advances the line number twice) — unpinned by the reference tests, kept literal.
     for index, raw in enumerate(_re.split("[\n\r\x0b\x0c\x85\u2028\u2029]", source)):
         n = index + 1
-        line = raw.strip()
+        line = raw.strip(_TRIM)                      # :60
         if not line or line.startswith("#"):
             continue
         m = _PREAMP_RE.fullmatch(line)
@@ -637,7 +664,9 @@ def eq_parse(data: bytes, filename: str = "preset.txt") -> EqualizerDefinition:
                 issues.append((n, "malformed Filter directive")); continue
             number = int(m.group(1)) if m.group(1) else None
             enabled = m.group(2).upper() == "ON"
-            ftype = {"PK": PEAKING, "LSC": LOW_SHELF, "HSC": HIGH_SHELF}[m.group(3).upper()]
+            ftype = {"PK": PEAKING, "LSC": LOW_SHELF, "HSC": HIGH_SHELF}.get(m.group(3).upper())     # :91-99 ("P" + KELVIN SIGN matches, and is no type)
+            if ftype is None:
+                issues.append((n, "unsupported filter type")); continue
             f, g, q = _finite_double(m.group(4)), _finite_double(m.group(5)), _finite_double(m.group(6))
             num = []
             if f is not None:

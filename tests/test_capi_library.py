@@ -163,6 +163,25 @@ def test_hesuvi_text_parser_matches_oracle_on_mutated_maps(oracle):
             assert m.getIndices(k) == (clamp(v[0]), clamp(v[1])), (text, k, v)
 
 
+def test_hesuvi_text_parser_uses_foundation_character_sets(oracle):
+    """parseHeSuViFormat (VirtualSpeaker.swift:301-346) splits at CharacterSet.newlines (U+000A-000D, U+0085, U+2028, U+2029), trims
+    CharacterSet.whitespaces (Zs + TAB — not U+001C-001F, not ZERO WIDTH SPACE) and matches aliases on String.uppercased(), the full
+    Unicode mapping (a long s reaches "SL" / "SUB", the "fl" ligature "FL" / "TFL")."""
+    m = aw.HRIRChannelMap.parseHeSuViFormat("FL=0,1\x0bFR=1,0\x0cFC=2,3\x85BL=4,5\u2028BR=5,4\u2029SL=6,7\r\nSR=7,6")
+    assert len(m) == 7 and m.getIndices("FC") == (2, 3) and m.getIndices("BR") == (5, 4) and m.getIndices("SR") == (7, 6)
+    m = aw.HRIRChannelMap.parseHeSuViFormat("\u00a0FL\u2003=\u30000\u202f,\u205f1\u1680")
+    assert m.getIndices("FL") == (0, 1)
+    m = aw.HRIRChannelMap.parseHeSuViFormat("FL\x1d=0,1\nFR=\u200b2,3\nFC=4,\x1f5")
+    assert len(m) == 1 and m.getIndices("FL\x1d") == (0, 1) and m.getIndices("FL") is None     # a custom speaker; the other lines have one index
+    m = aw.HRIRChannelMap.parseHeSuViFormat("\u017fl=0,1\n\u017fub=2,3\n\ufb02=4,5\nt\ufb02=6,7\nP\u212a=8,9")
+    assert m.getIndices("SL") == (0, 1) and m.getIndices("LFE") == (2, 3) and m.getIndices("FL") == (4, 5) and m.getIndices("TFL") == (6, 7)
+    assert m.getIndices("P\u212a") == (8, 9) and len(m) == 5
+    for text in ["FL=0,1\x0bFR=1,0\x85C = 2 , 3", "\u00a0FL\u2003=\u30000\u202f,\u205f1\u1680", "FL\x1d=0,1\nFR=\u200b2,3", "\u017fl=0,1\n\ufb02=4,5\nt\ufb02=6,7",
+                 "# c\u2028; d\u2029 rl = 3,2 \r\n\rsub=+6,-0"]:
+        om, m = oracle.parse_hesuvi_format(text), aw.HRIRChannelMap.parseHeSuViFormat(text)
+        assert len(m) == len(om) and all(m.getIndices(k) == v for k, v in om.items()), (text, om)
+
+
 def test_wav_reader_matches_oracle_on_generated_files(oracle, tmp_path):
     """Structure-level fuzz of the RIFF/WAVE reader: every sample format the loader knows, plain and EXTENSIBLE headers,
     1..16 channels, extra chunks (odd sizes with their pad byte) before, between and after fmt/data, truncated data.

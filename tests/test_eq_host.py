@@ -135,6 +135,40 @@ def test_parser_matches_oracle_on_mutated_presets(oracle):
         _same_parse(oracle, text.encode("utf-8"))
 
 
+def test_parser_follows_icu_whitespace_and_case_folding(oracle):
+    """NSRegularExpression is ICU: \\s is [\\t\\n\\f\\r\\p{Z}] — U+001C-001F are NOT white space (Python's str.isspace() says they are) —, and
+    .caseInsensitive compares simple case foldings: KELVIN SIGN matches k, LONG S matches s, dotted / dotless i match nothing
+    (EqualizerAPOParser.swift:27-34).  captures[2].uppercased() then turns a long s into S (a valid shelf) and leaves the Kelvin
+    sign alone ("unsupported filter type", :91-99).  trimmingCharacters(in: .whitespacesAndNewlines) (:60) trims Z* and TAB only."""
+    ok = "Filter 1: ON PK Fc 100 Hz Gain 3 dB Q 1"
+    for sp in ["\u00a0", "\u1680", "\u2003", "\u202f", "\u205f", "\u3000", "\t"]:
+        d = aw.EqualizerAPOParser.parse(ok.replace(" ", sp).encode(), "f.txt")
+        assert len(d.filters) == 1 and d.filters[0].frequencyHz == 100.0, repr(sp)
+    for cc in ["\x1c", "\x1d", "\x1e", "\x1f", "\u200b", "\ufeff"]:
+        with pytest.raises(aw.EqualizerParseError) as e:
+            aw.EqualizerAPOParser.parse(ok.replace("Fc 100", "Fc" + cc + "100").encode(), "f.txt")
+        assert e.value.issues == [(1, "malformed Filter directive")], repr(cc)
+        if cc == "\ufeff":                                              # one leading BOM is dropped (:49-51)
+            assert aw.EqualizerAPOParser.parse((cc + "Preamp: 3 dB").encode(), "f.txt").preampDB == 3.0
+            continue
+        with pytest.raises(aw.EqualizerParseError) as e:                 # not trimmed either: the line does not start with "Preamp"
+            aw.EqualizerAPOParser.parse((cc + "Preamp: 3 dB").encode(), "f.txt")
+        assert e.value.issues == [(1, "unsupported directive")], repr(cc)
+    d = aw.EqualizerAPOParser.parse("Filter 1: ON L\u017fC Fc 100 Hz Gain 3 dB Q 1".encode(), "f.txt")
+    assert d.filters[0].type == 1
+    d = aw.EqualizerAPOParser.parse("filter 2: on h\u017fc fc 1e3 hz gain -2 db q .7\u3000".encode(), "f.txt")
+    assert d.filters[0].type == 2 and d.filters[0].sourceNumber == 2
+    with pytest.raises(aw.EqualizerParseError) as e:
+        aw.EqualizerAPOParser.parse("Filter 1: ON P\u212a Fc 100 Hz Gain 3 dB Q 1".encode(), "f.txt")
+    assert e.value.issues == [(1, "unsupported filter type")]
+    for bad in ["F\u0131lter 1: ON PK Fc 100 Hz Gain 3 dB Q 1", "Filter 1: ON PK Fc 100 Hz Ga\u0131n 3 dB Q 1", "Filter 1: ON PK Fc 100 Hz Ga\u0130n 3 dB Q 1"]:
+        with pytest.raises(aw.EqualizerParseError):
+            aw.EqualizerAPOParser.parse(bad.encode(), "f.txt")
+    for text in [ok, ok.replace(" ", "\u2003"), ok.replace("Fc 100", "Fc\x1d100"), "Filter 1: ON L\u017fC Fc 100 Hz Gain 3 dB Q 1",
+                 "Filter 1: ON P\u212a Fc 100 Hz Gain 3 dB Q 1", "\x1fPreamp: 3 dB", "Preamp: 3 dB\x1f", "Preamp:\u00a03\u00a0dB\u2029Filter: ON PK Fc 1 Hz Gain 1 dB Q 1"]:
+        _same_parse(oracle, text.encode())
+
+
 def test_eq_needs_a_device_or_fails_loudly():
     import torch
     if torch.cuda.is_available():
