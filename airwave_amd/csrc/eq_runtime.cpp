@@ -143,7 +143,7 @@ struct aw_eq {
 
 extern "C" {
 
-aw_status aw_biquad_make(int32_t type, double gain_db, double f, double q, double fs, double out[5], int32_t *error_kind) {
+aw_status aw_biquad_make(int32_t type, double gain_db, double f, double q, double fs, double out[5], int32_t *error_kind) try {
     if (!out || type < 0 || type > 2) return fail(AW_ERR_INVALID_ARGUMENT, "bad argument");
     awh::Biquad c{};
     const int kind = awh::biquad_make(type, gain_db, f, q, fs, &c);
@@ -151,35 +151,35 @@ aw_status aw_biquad_make(int32_t type, double gain_db, double f, double q, doubl
     if (kind) return fail(AW_ERR_EQ_INVALID_FILTER, biquad_error_text(kind));
     out[0] = c.b0; out[1] = c.b1; out[2] = c.b2; out[3] = c.a1; out[4] = c.a2;
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
-aw_status aw_eq_definition_create(double preamp_db, aw_eq_definition **out) {
+aw_status aw_eq_definition_create(double preamp_db, aw_eq_definition **out) try {
     if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
     auto *d = new (std::nothrow) aw_eq_definition();
     if (!d) return fail(AW_ERR_OUT_OF_MEMORY, "allocation failed");
     d->def.preamp_db = preamp_db;
     *out = d;
     return AW_OK;
-}
-aw_status aw_eq_definition_add_filter(aw_eq_definition *d, int32_t enabled, int32_t type, double f, double g, double q) {
+} AW_NOEXCEPT_TAIL
+aw_status aw_eq_definition_add_filter(aw_eq_definition *d, int32_t enabled, int32_t type, double f, double g, double q) try {
     if (!d || type < 0 || type > 2) return fail(AW_ERR_INVALID_ARGUMENT, "bad argument");
     awh::EqFilter fl;
     fl.source_line = (int)d->def.filters.size() + 1;
     fl.enabled = enabled != 0; fl.type = type; fl.frequency_hz = f; fl.gain_db = g; fl.q = q;
     d->def.filters.push_back(fl);
     return AW_OK;
-}
-aw_status aw_eq_definition_set_source(aw_eq_definition *d, int32_t i, int32_t line, int64_t number) {
+} AW_NOEXCEPT_TAIL
+aw_status aw_eq_definition_set_source(aw_eq_definition *d, int32_t i, int32_t line, int64_t number) try {
     if (!d || i < 0 || i >= (int32_t)d->def.filters.size()) return fail(AW_ERR_INVALID_ARGUMENT, "filter index out of range");
     d->def.filters[i].source_line = line;
     d->def.filters[i].source_number = number;
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 void aw_eq_definition_destroy(aw_eq_definition *d) { delete d; }
 double aw_eq_definition_preamp_db(const aw_eq_definition *d) { return d ? d->def.preamp_db : 0.0; }
 int32_t aw_eq_definition_filter_count(const aw_eq_definition *d) { return d ? (int32_t)d->def.filters.size() : 0; }
 aw_status aw_eq_definition_filter(const aw_eq_definition *d, int32_t i, int32_t *line, int64_t *number, int32_t *enabled,
-                                  int32_t *type, double *f, double *g, double *q) {
+                                  int32_t *type, double *f, double *g, double *q) try {
     if (!d || i < 0 || i >= (int32_t)d->def.filters.size()) return fail(AW_ERR_INVALID_ARGUMENT, "filter index out of range");
     const auto &fl = d->def.filters[i];
     if (line) *line = fl.source_line;
@@ -190,9 +190,9 @@ aw_status aw_eq_definition_filter(const aw_eq_definition *d, int32_t i, int32_t 
     if (g) *g = fl.gain_db;
     if (q) *q = fl.q;
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
-aw_status aw_eq_parse(const void *data, size_t size, aw_eq_definition **out, char *issues_out, size_t cap) {
+aw_status aw_eq_parse(const void *data, size_t size, aw_eq_definition **out, char *issues_out, size_t cap) try {
     if (!out || (!data && size)) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     *out = nullptr;
     if (issues_out && cap) issues_out[0] = 0;
@@ -214,11 +214,11 @@ aw_status aw_eq_parse(const void *data, size_t size, aw_eq_definition **out, cha
     }
     *out = d.release();
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 /* ---- prepared state ------------------------------------------------------------------------ */
 aw_status aw_eq_state_create(aw_context *ctx, const aw_eq_definition *def, double sample_rate, int32_t n_streams,
-                             aw_eq_state **out) {
+                             aw_eq_state **out) try {
     if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     if (!ctx) return fail(AW_ERR_NO_DEVICE, "no context (no HIP device): there is no CPU fallback");
@@ -231,27 +231,27 @@ aw_status aw_eq_state_create(aw_context *ctx, const aw_eq_definition *def, doubl
     h->s = std::move(s);
     *out = h;
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 void aw_eq_state_destroy(aw_eq_state *s) {
     if (s && s->s) (void)hipSetDevice(s->s->ctx->device);
     delete s;
 }
-aw_status aw_eq_state_reset(aw_eq_state *s) {
+aw_status aw_eq_state_reset(aw_eq_state *s) try {
     if (!s) return fail(AW_ERR_INVALID_ARGUMENT, "state is NULL");
     AW_HIP_TRY(hipSetDevice(s->s->ctx->device));
     return state_reset(*s->s);
-}
-aw_status aw_eq_state_process(aw_eq_state *s, const float *in, float *out, int64_t frames) {
+} AW_NOEXCEPT_TAIL
+aw_status aw_eq_state_process(aw_eq_state *s, const float *in, float *out, int64_t frames) try {
     if (!s || !in || !out) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     if (frames < 0) return fail(AW_ERR_INVALID_ARGUMENT, "frames must be >= 0");
     AW_HIP_TRY(hipSetDevice(s->s->ctx->device));
     return state_process(*s->s, in, frames, out, frames, frames);
-}
+} AW_NOEXCEPT_TAIL
 int32_t aw_eq_state_filter_count(const aw_eq_state *s) { return s ? s->s->t.n_filters : 0; }
 double aw_eq_state_preamp_linear(const aw_eq_state *s) { return s ? s->s->t.preamp : 0.0; }
 
 /* ---- processor ----------------------------------------------------------------------------- */
-aw_status aw_eq_create(aw_context *ctx, double sample_rate, int32_t n_streams, int32_t max_frames, aw_eq **out) {
+aw_status aw_eq_create(aw_context *ctx, double sample_rate, int32_t n_streams, int32_t max_frames, aw_eq **out) try {
     if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     if (!ctx) return fail(AW_ERR_NO_DEVICE, "no context (no HIP device): there is no CPU fallback");
@@ -283,7 +283,7 @@ aw_status aw_eq_create(aw_context *ctx, double sample_rate, int32_t n_streams, i
     }
     *out = eq.release();
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 void aw_eq_destroy(aw_eq *eq) {
     if (!eq) return;
@@ -296,7 +296,7 @@ void aw_eq_destroy(aw_eq *eq) {
     delete eq;
 }
 
-aw_status aw_eq_set_target(aw_eq *eq, const aw_eq_definition *def) {                        // :226-228
+aw_status aw_eq_set_target(aw_eq *eq, const aw_eq_definition *def) try {                        // :226-228
     if (!eq) return fail(AW_ERR_INVALID_ARGUMENT, "eq is NULL");
     EqStatePtr s;
     const aw_status st = prepare_state(eq->ctx, def ? &def->def : nullptr, eq->sample_rate, eq->n_streams, s);
@@ -304,14 +304,14 @@ aw_status aw_eq_set_target(aw_eq *eq, const aw_eq_definition *def) {            
     std::lock_guard<std::mutex> g(eq->target_lock);                                         // publish :219-227
     eq->published = std::move(s);
     return AW_OK;
-}
-aw_status aw_eq_reset(aw_eq *eq) {                                                          // :230-234
+} AW_NOEXCEPT_TAIL
+aw_status aw_eq_reset(aw_eq *eq) try {                                                          // :230-234
     if (!eq) return fail(AW_ERR_INVALID_ARGUMENT, "eq is NULL");
     std::lock_guard<std::mutex> g(eq->reset_lock);
     eq->reset_requested = true;
     return AW_OK;
-}
-aw_status aw_eq_drain_retired(aw_eq *eq) {                                                  // :237-241
+} AW_NOEXCEPT_TAIL
+aw_status aw_eq_drain_retired(aw_eq *eq) try {                                                  // :237-241
     if (!eq) return fail(AW_ERR_INVALID_ARGUMENT, "eq is NULL");
     EqStatePtr gone;
     {
@@ -326,7 +326,7 @@ aw_status aw_eq_drain_retired(aw_eq *eq) {                                      
         gone.reset();
     }
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 static void eq_begin_transition(aw_eq *eq, const EqStatePtr &target) {                      // :349-354
     if (target == eq->active) return;
@@ -388,7 +388,7 @@ static void eq_flush_pending_retirement(aw_eq *eq) {                            
     eq_start_pending(eq);
 }
 
-aw_status aw_eq_process(aw_eq *eq, const float *in, float *out, int64_t frames) {           // :253-309
+aw_status aw_eq_process(aw_eq *eq, const float *in, float *out, int64_t frames) try {           // :253-309
     if (!eq || !in || !out) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     if (frames <= 0) return frames == 0 ? AW_OK : fail(AW_ERR_INVALID_ARGUMENT, "frames must be >= 0");
     if (eq->max_frames > 0 && frames > eq->max_frames)                                      // precondition :261
@@ -425,9 +425,9 @@ aw_status aw_eq_process(aw_eq *eq, const float *in, float *out, int64_t frames) 
         if (eq->transition_frame == eq->transition_length) eq_finish_transition(eq);
     }
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
-aw_status aw_eq_process_planar(aw_eq *eq, const float *in_l, const float *in_r, float *out_l, float *out_r, int32_t frames) {
+aw_status aw_eq_process_planar(aw_eq *eq, const float *in_l, const float *in_r, float *out_l, float *out_r, int32_t frames) try {
     if (!eq || !in_l || !out_l || !out_r) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     if (eq->n_streams != 1) return fail(AW_ERR_INVALID_ARGUMENT, "planar entry needs a 1-stream equalizer");
     if (frames <= 0) return frames == 0 ? AW_OK : fail(AW_ERR_INVALID_ARGUMENT, "frameCount must be >= 0");
@@ -463,15 +463,15 @@ aw_status aw_eq_process_planar(aw_eq *eq, const float *in_l, const float *in_r, 
     AW_HIP_TRY(hipMemcpyAsync(out_r, d_r, sizeof(float) * frames, hipMemcpyDeviceToHost, s));
     AW_HIP_TRY(hipStreamSynchronize(s));
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 // withPublicationLockForTesting (:229-233, DEBUG builds of the reference): hold = 1 takes the publication lock, 0 releases it
 // (same thread).  Lets a test show that a render call under contention keeps its prior target.
-aw_status aw_eq_debug_hold_publication_lock(aw_eq *eq, int32_t hold) {
+aw_status aw_eq_debug_hold_publication_lock(aw_eq *eq, int32_t hold) try {
     if (!eq) return fail(AW_ERR_INVALID_ARGUMENT, "eq is NULL");
     if (hold) eq->target_lock.lock(); else eq->target_lock.unlock();
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 int32_t aw_eq_transition_length(const aw_eq *eq) { return eq ? (int32_t)eq->transition_length : 0; }
 int32_t aw_eq_is_transitioning(const aw_eq *eq) { return eq && eq->from && eq->to ? 1 : 0; }

@@ -136,7 +136,7 @@ std::vector<std::string> split(const std::string &s, char sep) {
 extern "C" {
 
 /* ---- WAVLoader.load (WAVLoader.swift:26-99) ------------------------------------------------------ */
-aw_status aw_wav_load(const char *path, aw_wav **out) {
+aw_status aw_wav_load(const char *path, aw_wav **out) try {
     if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     if (!path) return fail(AW_ERR_INVALID_ARGUMENT, "path is NULL");
@@ -171,7 +171,7 @@ aw_status aw_wav_load(const char *path, aw_wav **out) {
     const bool is_float = tag == 3, is_pcm = tag == 1;
     if (!((is_float && (bits == 32 || bits == 64)) || (is_pcm && (bits == 8 || bits == 16 || bits == 24 || bits == 32))))
         return fail(AW_ERR_WAV_UNSUPPORTED_FORMAT, "Unsupported WAV format");                                // :89-91
-    aw_wav *w = new (std::nothrow) aw_wav();
+    awr::Owner<aw_wav> w(new (std::nothrow) aw_wav(), aw_wav_destroy);
     if (!w) return fail(AW_ERR_OUT_OF_MEMORY, "Failed to allocate audio buffer");                            // :49-54
     w->sample_rate = (double)rate; w->channels = ch; w->frames = (int)frames;
     w->planar.resize((size_t)ch * frames);
@@ -188,9 +188,9 @@ aw_status aw_wav_load(const char *path, aw_wav **out) {
             w->planar[(size_t)c * frames + i] = v;
         }
     }
-    *out = w;
+    *out = w.release();
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 void aw_wav_destroy(aw_wav *w) { delete w; }
 double aw_wav_sample_rate(const aw_wav *w) { return w ? w->sample_rate : 0.0; }
 int32_t aw_wav_channel_count(const aw_wav *w) { return w ? w->channels : 0; }
@@ -201,11 +201,11 @@ const float *aw_wav_channel(const aw_wav *w, int32_t c) {
 const float *aw_wav_planar(const aw_wav *w) { return w ? w->planar.data() : nullptr; }
 
 /* ---- InputLayout (VirtualSpeaker.swift:59-100) ---------------------------------------------------- */
-aw_status aw_layout_detect(int32_t n, aw_layout **out) {
+aw_status aw_layout_detect(int32_t n, aw_layout **out) try {
     if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     if (n < 0) return fail(AW_ERR_INVALID_ARGUMENT, "negative channel count");
-    aw_layout *l = new (std::nothrow) aw_layout();
+    awr::Owner<aw_layout> l(new (std::nothrow) aw_layout(), aw_layout_destroy);
     if (!l) return fail(AW_ERR_OUT_OF_MEMORY, "layout");
     switch (n) {                                                               // :88-99
         case 2: l->speakers = {"FL", "FR"}; l->name = "Stereo"; break;
@@ -216,23 +216,23 @@ aw_status aw_layout_detect(int32_t n, aw_layout **out) {
             for (int i = 0; i < n; ++i) l->speakers.push_back("Ch" + std::to_string(i));
             l->name = std::to_string(n) + " Channel";
     }
-    *out = l;
+    *out = l.release();
     return AW_OK;
-}
-aw_status aw_layout_create(const char *const *names, int32_t count, const char *name, aw_layout **out) {
+} AW_NOEXCEPT_TAIL
+aw_status aw_layout_create(const char *const *names, int32_t count, const char *name, aw_layout **out) try {
     if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     if (count < 0 || (count > 0 && !names)) return fail(AW_ERR_INVALID_ARGUMENT, "bad speaker list");
-    aw_layout *l = new (std::nothrow) aw_layout();
+    awr::Owner<aw_layout> l(new (std::nothrow) aw_layout(), aw_layout_destroy);
     if (!l) return fail(AW_ERR_OUT_OF_MEMORY, "layout");
     for (int i = 0; i < count; ++i) {
-        if (!names[i]) { delete l; return fail(AW_ERR_INVALID_ARGUMENT, "NULL speaker name"); }
+        if (!names[i]) return fail(AW_ERR_INVALID_ARGUMENT, "NULL speaker name");
         l->speakers.emplace_back(names[i]);
     }
     l->name = name ? name : "";
-    *out = l;
+    *out = l.release();
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 void aw_layout_destroy(aw_layout *l) { delete l; }
 int32_t aw_layout_count(const aw_layout *l) { return l ? (int32_t)l->speakers.size() : 0; }
 const char *aw_layout_speaker(const aw_layout *l, int32_t i) {
@@ -249,39 +249,42 @@ static aw_status map_new(aw_channel_map **out, aw_channel_map **m) {
     return AW_OK;
 }
 
-aw_status aw_map_hesuvi14(const aw_layout *spk, aw_channel_map **out) {       // :270-297
+aw_status aw_map_hesuvi14(const aw_layout *spk, aw_channel_map **out) try {       // :270-297
     aw_channel_map *m;
     aw_status st = map_new(out, &m);
     if (st != AW_OK) return st;
-    if (!spk) { delete m; return fail(AW_ERR_INVALID_ARGUMENT, "speakers is NULL"); }
+    awr::Owner<aw_channel_map> owner(m, aw_map_destroy);
+    if (!spk) return fail(AW_ERR_INVALID_ARGUMENT, "speakers is NULL");
     static const struct { const char *s; int l, r; } T[] = {{"FL", 0, 1}, {"FR", 8, 7}, {"FC", 6, 13}, {"LFE", 6, 13},
                                                              {"BL", 4, 5}, {"BR", 12, 11}, {"SL", 2, 3}, {"SR", 10, 9}};
     for (const auto &s : spk->speakers)
         for (const auto &t : T)
             if (s == t.s) m->set(s, t.l, t.r);
-    *out = m;
+    *out = owner.release();
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
-aw_status aw_map_hesuvi7(const aw_layout *spk, aw_channel_map **out) {        // :224-250
+aw_status aw_map_hesuvi7(const aw_layout *spk, aw_channel_map **out) try {        // :224-250
     aw_channel_map *m;
     aw_status st = map_new(out, &m);
     if (st != AW_OK) return st;
-    if (!spk) { delete m; return fail(AW_ERR_INVALID_ARGUMENT, "speakers is NULL"); }
+    awr::Owner<aw_channel_map> owner(m, aw_map_destroy);
+    if (!spk) return fail(AW_ERR_INVALID_ARGUMENT, "speakers is NULL");
     static const struct { const char *s; int l, r; } T[] = {{"FL", 0, 1}, {"FR", 1, 0}, {"FC", 2, 2}, {"LFE", 2, 2},
                                                              {"BL", 3, 4}, {"BR", 4, 3}, {"SL", 5, 6}, {"SR", 6, 5}};
     for (const auto &s : spk->speakers)
         for (const auto &t : T)
             if (s == t.s) m->set(s, t.l, t.r);
-    *out = m;
+    *out = owner.release();
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
-aw_status aw_map_interleaved_pairs(const aw_layout *spk, aw_channel_map **out) {   // :126-159
+aw_status aw_map_interleaved_pairs(const aw_layout *spk, aw_channel_map **out) try {   // :126-159
     aw_channel_map *m;
     aw_status st = map_new(out, &m);
     if (st != AW_OK) return st;
-    if (!spk) { delete m; return fail(AW_ERR_INVALID_ARGUMENT, "speakers is NULL"); }
+    awr::Owner<aw_channel_map> owner(m, aw_map_destroy);
+    if (!spk) return fail(AW_ERR_INVALID_ARGUMENT, "speakers is NULL");
     for (size_t i = 0; i < spk->speakers.size(); ++i) {
         const int base = (int)i * 2;
         const std::string &s = spk->speakers[i];
@@ -289,26 +292,28 @@ aw_status aw_map_interleaved_pairs(const aw_layout *spk, aw_channel_map **out) {
         else m->set(s, base, base + 1);                                          // left side and centre speakers
         (void)kLeftSide;
     }
-    *out = m;
+    *out = owner.release();
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
-aw_status aw_map_split_blocks(const aw_layout *spk, aw_channel_map **out) {    // :200-209
+aw_status aw_map_split_blocks(const aw_layout *spk, aw_channel_map **out) try {    // :200-209
     aw_channel_map *m;
     aw_status st = map_new(out, &m);
     if (st != AW_OK) return st;
-    if (!spk) { delete m; return fail(AW_ERR_INVALID_ARGUMENT, "speakers is NULL"); }
+    awr::Owner<aw_channel_map> owner(m, aw_map_destroy);
+    if (!spk) return fail(AW_ERR_INVALID_ARGUMENT, "speakers is NULL");
     const int n = (int)spk->speakers.size();
     for (int i = 0; i < n; ++i) m->set(spk->speakers[(size_t)i], i, i + n);
-    *out = m;
+    *out = owner.release();
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
-aw_status aw_map_parse_text(const char *text, aw_channel_map **out) {          // parseHeSuViFormat :301-346
+aw_status aw_map_parse_text(const char *text, aw_channel_map **out) try {          // parseHeSuViFormat :301-346
     aw_channel_map *m;
     aw_status st = map_new(out, &m);
     if (st != AW_OK) return st;
-    if (!text) { delete m; return fail(AW_ERR_INVALID_ARGUMENT, "text is NULL"); }
+    awr::Owner<aw_channel_map> owner(m, aw_map_destroy);
+    if (!text) return fail(AW_ERR_INVALID_ARGUMENT, "text is NULL");
     static const struct { const char *alias; const char *spk; } A[] = {
         {"FL", "FL"}, {"L", "FL"}, {"FR", "FR"}, {"R", "FR"}, {"FC", "FC"}, {"C", "FC"}, {"LFE", "LFE"}, {"SUB", "LFE"},
         {"BL", "BL"}, {"RL", "BL"}, {"BR", "BR"}, {"RR", "BR"}, {"SL", "SL"}, {"SR", "SR"}, {"TFL", "TFL"},
@@ -331,9 +336,9 @@ aw_status aw_map_parse_text(const char *text, aw_channel_map **out) {          /
             if (upper == a.alias) { speaker = a.spk; break; }
         m->set(speaker, idx[0], idx[1]);
     }
-    *out = m;
+    *out = owner.release();
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 void aw_map_destroy(aw_channel_map *m) { delete m; }
 int32_t aw_map_count(const aw_channel_map *m) { return m ? (int32_t)m->keys.size() : 0; }
@@ -347,7 +352,7 @@ int32_t aw_map_get(const aw_channel_map *m, const char *speaker, int32_t *l, int
 }
 
 aw_status aw_map_resolve(const aw_channel_map *m, const aw_layout *layout, int32_t n_tracks, int32_t *left,
-                         int32_t *right) {
+                         int32_t *right) try {
     if (!m || !layout || !left || !right) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     int mapped = 0;
     for (size_t i = 0; i < layout->speakers.size(); ++i) {
@@ -363,7 +368,7 @@ aw_status aw_map_resolve(const aw_channel_map *m, const aw_layout *layout, int32
     }
     if (mapped == 0) return fail(AW_ERR_CONVOLUTION_SETUP_FAILED, "No valid renderers created");   // :420-422
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 /* ---- Resampler (Resampler.swift:31-68) -------------------------------------------------------------- */
 int32_t aw_resample_output_count(int32_t count, double from_rate, double to_rate) {
@@ -373,7 +378,7 @@ int32_t aw_resample_output_count(int32_t count, double from_rate, double to_rate
 }
 
 aw_status aw_resample(const float *input, int32_t count, double from_rate, double to_rate, float *output,
-                      int32_t capacity, int32_t *output_count) {
+                      int32_t capacity, int32_t *output_count) try {
     if (!input || !output || !output_count || count < 0) return fail(AW_ERR_INVALID_ARGUMENT, "bad argument");
     const int n_out = aw_resample_output_count(count, from_rate, to_rate);
     *output_count = n_out > 0 ? n_out : 0;
@@ -389,13 +394,13 @@ aw_status aw_resample(const float *input, int32_t count, double from_rate, doubl
         output[i] = input[a] + frac * (input[b] - input[a]);
     }
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 // vDSP_vgenp as documented, on the control ramp of Resampler.swift:53-56 (float32, C[m] = m * step).  The ramp the
 // reference allocates has only outputCount entries while vgenp is told M = input.count knots; every evaluation point
 // n < outputCount is bracketed by knots below outputCount when stride > 1, so the entries past the array are never needed.
 aw_status aw_resample_vgenp(const float *input, int32_t count, double from_rate, double to_rate, float *output,
-                            int32_t capacity, int32_t *output_count) {
+                            int32_t capacity, int32_t *output_count) try {
     if (!input || !output || !output_count || count < 0) return fail(AW_ERR_INVALID_ARGUMENT, "bad argument");
     const int n_out = aw_resample_output_count(count, from_rate, to_rate);
     *output_count = n_out > 0 ? n_out : 0;
@@ -415,54 +420,55 @@ aw_status aw_resample_vgenp(const float *input, int32_t count, double from_rate,
         output[n] = input[m] + (input[m + 1] - input[m]) * ((x - b0) / (b1 - b0));
     }
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 /* ---- HRIRManager.activatePreset (HRIRManager.swift:347-446) ------------------------------------------ */
 aw_status aw_preset_activate(aw_context *ctx, const char *wav_path, double target_rate, const aw_layout *layout,
                              const aw_channel_map *custom_map, int32_t n_streams, aw_spatializer **sp_out,
-                             aw_hrir **hrir_out) {
+                             aw_hrir **hrir_out) try {
     if (!sp_out) return fail(AW_ERR_INVALID_ARGUMENT, "spatializer_out is NULL");
     *sp_out = nullptr;
     if (hrir_out) *hrir_out = nullptr;
     if (!ctx || !wav_path || !layout) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
-    aw_wav *wav = nullptr;
-    aw_status st = aw_wav_load(wav_path, &wav);                                  // :349
+    aw_wav *wav_raw = nullptr;
+    aw_status st = aw_wav_load(wav_path, &wav_raw);                              // :349
     if (st != AW_OK) return st;
-    aw_channel_map *own = nullptr;
+    const awr::Owner<aw_wav> wav(wav_raw, aw_wav_destroy);
+    awr::Owner<aw_channel_map> own(nullptr, aw_map_destroy);
     const aw_channel_map *map = custom_map;
     if (!map) {                                                                   // :355-360
-        st = wav->channels == 7 ? aw_map_hesuvi7(layout, &own) : aw_map_hesuvi14(layout, &own);
-        if (st != AW_OK) { aw_wav_destroy(wav); return st; }
-        map = own;
+        aw_channel_map *made = nullptr;
+        st = wav->channels == 7 ? aw_map_hesuvi7(layout, &made) : aw_map_hesuvi14(layout, &made);
+        if (st != AW_OK) return st;
+        own.reset(made);
+        map = made;
     }
     const int C = (int)layout->speakers.size();
     std::vector<int32_t> lt((size_t)std::max(C, 1)), rt((size_t)std::max(C, 1));
     st = aw_map_resolve(map, layout, wav->channels, lt.data(), rt.data());        // :366-379, :420-422
-    aw_map_destroy(own);
-    if (st != AW_OK) { aw_wav_destroy(wav); return st; }
+    if (st != AW_OK) return st;
     std::vector<float> tracks;
     int taps = wav->frames;
     if (target_rate > 0.0 && std::fabs(wav->sample_rate - target_rate) > 0.01) {  // :389-403
         taps = aw_resample_output_count(wav->frames, wav->sample_rate, target_rate);
-        if (taps <= 0) { aw_wav_destroy(wav); return fail(AW_ERR_CONVOLUTION_SETUP_FAILED, "resampled HRIR is empty"); }
+        if (taps <= 0) return fail(AW_ERR_CONVOLUTION_SETUP_FAILED, "resampled HRIR is empty");
         tracks.resize((size_t)wav->channels * taps);
         for (int c = 0; c < wav->channels; ++c) {
             int n = 0;
-            st = (awr::context_literal_resampler(ctx) ? aw_resample_vgenp : aw_resample)(aw_wav_channel(wav, c), wav->frames, wav->sample_rate, target_rate,
+            st = (awr::context_literal_resampler(ctx) ? aw_resample_vgenp : aw_resample)(aw_wav_channel(wav.get(), c), wav->frames, wav->sample_rate, target_rate,
                                                                                             tracks.data() + (size_t)c * taps, taps, &n);
-            if (st != AW_OK) { aw_wav_destroy(wav); return st; }
+            if (st != AW_OK) return st;
         }
     } else {
         tracks = wav->planar;
     }
-    aw_hrir *hrir = nullptr;
-    st = aw_hrir_create(ctx, tracks.data(), wav->channels, taps, target_rate > 0.0 ? target_rate : wav->sample_rate, &hrir);
-    aw_wav_destroy(wav);
+    aw_hrir *hrir_raw = nullptr;
+    st = aw_hrir_create(ctx, tracks.data(), wav->channels, taps, target_rate > 0.0 ? target_rate : wav->sample_rate, &hrir_raw);
     if (st != AW_OK) return st;
-    st = aw_spatializer_create(ctx, hrir, C, lt.data(), rt.data(), n_streams, 0, sp_out);   // :406-418
-    if (st != AW_OK || !hrir_out) aw_hrir_destroy(hrir);
-    else *hrir_out = hrir;
+    awr::Owner<aw_hrir> hrir(hrir_raw, aw_hrir_destroy);
+    st = aw_spatializer_create(ctx, hrir.get(), C, lt.data(), rt.data(), n_streams, 0, sp_out);   // :406-418
+    if (st == AW_OK && hrir_out) *hrir_out = hrir.release();
     return st;
-}
+} AW_NOEXCEPT_TAIL
 
 }  // extern "C"

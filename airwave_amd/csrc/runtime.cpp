@@ -10,6 +10,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <thread>
 
 #include "device/eq_kernels.hpp"
@@ -100,6 +101,19 @@ aw_status hip_fail(hipError_t e, const char *what) {
 
 bool context_literal_resampler(const aw_context *ctx) { return ctx && ctx->literal_resampler; }
 
+aw_status caught() noexcept {
+    aw_status code = AW_ERR_INVALID_ARGUMENT;
+    try {
+        try { throw; }
+        catch (const std::bad_alloc &) { code = AW_ERR_OUT_OF_MEMORY; g_last_error = "host memory exhausted"; }
+        catch (const std::length_error &) { code = AW_ERR_OUT_OF_MEMORY; g_last_error = "host container size limit"; }
+        catch (const std::exception &e) { g_last_error = std::string("internal error: ") + e.what(); }
+        catch (...) { g_last_error = "internal error"; }
+    } catch (...) {          // (the message itself could not be stored)
+    }
+    return code;
+}
+
 }  // namespace awr
 
 using awr::fail;
@@ -142,7 +156,8 @@ static aw_status context_create_impl(int32_t device, void *ext_stream, bool use_
         return fail(AW_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
     if (device < 0 || device >= count) return fail(AW_ERR_NO_DEVICE, "device ordinal out of range");
     AW_HIP_TRY(hipSetDevice(device));
-    aw_context *c = new (std::nothrow) aw_context();
+    awr::Owner<aw_context> owner(new (std::nothrow) aw_context(), aw_context_destroy);
+    aw_context *c = owner.get();
     if (!c) return fail(AW_ERR_OUT_OF_MEMORY, "context");
     c->device = device;
     if (use_ext) {
@@ -150,7 +165,7 @@ static aw_status context_create_impl(int32_t device, void *ext_stream, bool use_
         c->owns_stream = false;
     } else {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) { delete c; return awr::hip_fail(e, "hipStreamCreate"); }
+        if (e != hipSuccess) { c->stream = nullptr; return awr::hip_fail(e, "hipStreamCreate"); }
         c->owns_stream = true;
     }
     hipError_t e = hipEventCreate(&c->t0);
@@ -171,18 +186,15 @@ static aw_status context_create_impl(int32_t device, void *ext_stream, bool use_
     if (e == hipSuccess) e = upload(tw.twb, &c->d_twb);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_zeros), 4096);
     if (e == hipSuccess) e = hipMemset(c->d_zeros, 0, 4096);
-    if (e != hipSuccess) {
-        aw_context_destroy(c);
-        return awr::hip_fail(e, "context setup");
-    }
-    *out = c;
+    if (e != hipSuccess) return awr::hip_fail(e, "context setup");
+    *out = owner.release();
     return AW_OK;
 }
 
-aw_status aw_context_create(int32_t device, aw_context **out) { return context_create_impl(device, nullptr, false, out); }
-aw_status aw_context_create_on_stream(int32_t device, void *hip_stream, aw_context **out) {
+aw_status aw_context_create(int32_t device, aw_context **out) try { return context_create_impl(device, nullptr, false, out); } AW_NOEXCEPT_TAIL
+aw_status aw_context_create_on_stream(int32_t device, void *hip_stream, aw_context **out) try {
     return context_create_impl(device, hip_stream, true, out);
-}
+} AW_NOEXCEPT_TAIL
 
 void aw_context_destroy(aw_context *c) {
     if (!c) return;
@@ -206,38 +218,38 @@ void aw_context_destroy(aw_context *c) {
     delete c;
 }
 
-aw_status aw_context_synchronize(aw_context *c) {
+aw_status aw_context_synchronize(aw_context *c) try {
     if (!c) return fail(AW_ERR_INVALID_ARGUMENT, "ctx is NULL");
     AW_HIP_TRY(hipStreamSynchronize(c->stream));
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
-aw_status aw_context_set_resampler(aw_context *c, int32_t literal_vgenp) {
+aw_status aw_context_set_resampler(aw_context *c, int32_t literal_vgenp) try {
     if (!c) return fail(AW_ERR_INVALID_ARGUMENT, "ctx is NULL");
     c->literal_resampler = literal_vgenp != 0;
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 void *aw_context_stream(aw_context *c) { return c ? reinterpret_cast<void *>(c->stream) : nullptr; }
 
-aw_status aw_context_timer_start(aw_context *c) {
+aw_status aw_context_timer_start(aw_context *c) try {
     if (!c) return fail(AW_ERR_INVALID_ARGUMENT, "ctx is NULL");
     AW_HIP_TRY(hipEventRecord(c->t0, c->stream));
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
-aw_status aw_context_timer_stop(aw_context *c, float *ms) {
+aw_status aw_context_timer_stop(aw_context *c, float *ms) try {
     if (!c || !ms) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     AW_HIP_TRY(hipEventRecord(c->t1, c->stream));
     AW_HIP_TRY(hipEventSynchronize(c->t1));
     AW_HIP_TRY(hipEventElapsedTime(ms, c->t0, c->t1));
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 /* The context's scratch pool (runtime.hpp), sized ahead of time: a host that knows its largest batch pays the one large hipMalloc at
  * start-up (its wall time is erratic on these boxes: 0.2 ms ... 3.7 s, profiles/round5_v1/alloc_probe.txt) instead of inside the first
  * aw_spatializer_reserve / process that needs it.  Grow-only; bytes the pool already holds are kept. */
-aw_status aw_context_reserve_scratch(aw_context *c, size_t bytes) {
+aw_status aw_context_reserve_scratch(aw_context *c, size_t bytes) try {
     if (!c) return fail(AW_ERR_INVALID_ARGUMENT, "ctx is NULL");
     AW_HIP_TRY(hipSetDevice(c->device));
     std::lock_guard<std::mutex> lk(c->launch_mu);
@@ -249,12 +261,12 @@ aw_status aw_context_reserve_scratch(aw_context *c, size_t bytes) {
     c->device_allocs += 1;
     c->pool_capacity = need;
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 size_t aw_context_scratch_bytes(const aw_context *c) { return c ? c->pool_capacity * sizeof(awk::cf) : 0; }
 
 /* Measured ceilings of the device the context runs on ("confirm on the box and also quote a measured copy-kernel
  * ceiling"; bench.py's roofline.measured).  Own buffers, freed before returning; blocks; never on a process path. */
-aw_status aw_context_bandwidth_probe(aw_context *c, size_t bytes, int32_t repetitions, double *read_gbs, double *write_gbs, double *copy_gbs) {
+aw_status aw_context_bandwidth_probe(aw_context *c, size_t bytes, int32_t repetitions, double *read_gbs, double *write_gbs, double *copy_gbs) try {
     if (!c || !read_gbs || !write_gbs || !copy_gbs) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     if (bytes < ((size_t)64 << 20) || repetitions < 1) return fail(AW_ERR_INVALID_ARGUMENT, "probe needs >= 64 MiB and >= 1 repetition");
     AW_HIP_TRY(hipSetDevice(c->device));
@@ -286,11 +298,11 @@ aw_status aw_context_bandwidth_probe(aw_context *c, size_t bytes, int32_t repeti
     if (e != hipSuccess) return awr::hip_fail(e, "bandwidth probe");
     *read_gbs = best[0]; *write_gbs = best[1]; *copy_gbs = best[2];
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 /* Host link: page-locked host memory to the device and back with hipMemcpyAsync, each way alone and both ways at once (two streams).
  * The yardstick of the host entry's PCIe-inclusive rate (bench.py's secondary_end_to_end). */
-aw_status aw_context_pcie_probe(aw_context *c, size_t bytes, int32_t repetitions, double *h2d_gbs, double *d2h_gbs, double *duplex_gbs) {
+aw_status aw_context_pcie_probe(aw_context *c, size_t bytes, int32_t repetitions, double *h2d_gbs, double *d2h_gbs, double *duplex_gbs) try {
     if (!c || !h2d_gbs || !d2h_gbs || !duplex_gbs) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     if (bytes < ((size_t)16 << 20) || repetitions < 1) return fail(AW_ERR_INVALID_ARGUMENT, "probe needs >= 16 MiB and >= 1 repetition");
     AW_HIP_TRY(hipSetDevice(c->device));
@@ -322,47 +334,47 @@ aw_status aw_context_pcie_probe(aw_context *c, size_t bytes, int32_t repetitions
     if (e != hipSuccess) return awr::hip_fail(e, "pcie probe");
     *h2d_gbs = best[0]; *d2h_gbs = best[1]; *duplex_gbs = best[2];
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
-aw_status aw_device_alloc(aw_context *c, size_t bytes, void **dptr) {
+aw_status aw_device_alloc(aw_context *c, size_t bytes, void **dptr) try {
     if (!c || !dptr) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     AW_HIP_TRY(hipSetDevice(c->device));
     AW_HIP_TRY(hipMalloc(dptr, bytes ? bytes : 1));
     return AW_OK;
-}
-aw_status aw_device_free(aw_context *c, void *dptr) {
+} AW_NOEXCEPT_TAIL
+aw_status aw_device_free(aw_context *c, void *dptr) try {
     if (!c) return fail(AW_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (dptr) AW_HIP_TRY(hipFree(dptr));
     return AW_OK;
-}
-aw_status aw_memcpy_h2d(aw_context *c, void *dst, const void *src, size_t bytes) {
+} AW_NOEXCEPT_TAIL
+aw_status aw_memcpy_h2d(aw_context *c, void *dst, const void *src, size_t bytes) try {
     if (!c || (bytes && (!dst || !src))) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     AW_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     AW_HIP_TRY(hipStreamSynchronize(c->stream));
     return AW_OK;
-}
-aw_status aw_memcpy_d2h(aw_context *c, void *dst, const void *src, size_t bytes) {
+} AW_NOEXCEPT_TAIL
+aw_status aw_memcpy_d2h(aw_context *c, void *dst, const void *src, size_t bytes) try {
     if (!c || (bytes && (!dst || !src))) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     AW_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     AW_HIP_TRY(hipStreamSynchronize(c->stream));
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 /* ---- HRIR set ------------------------------------------------------------------------------- */
 aw_status aw_hrir_create(aw_context *ctx, const float *tracks, int32_t n_tracks, int32_t taps, double sample_rate,
-                         aw_hrir **out) {
+                         aw_hrir **out) try {
     if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     if (!ctx || !tracks) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n_tracks <= 0) return fail(AW_ERR_INVALID_CHANNEL_COUNT, "HRIR needs at least one track");
     if (taps <= 0) return fail(AW_ERR_WAV_EMPTY_FILE, "HRIR has no taps");
-    aw_hrir *h = new (std::nothrow) aw_hrir();
+    awr::Owner<aw_hrir> h(new (std::nothrow) aw_hrir(), aw_hrir_destroy);
     if (!h) return fail(AW_ERR_OUT_OF_MEMORY, "hrir");
     h->ctx = ctx; h->n_tracks = n_tracks; h->taps = taps; h->sample_rate = sample_rate;
     h->tracks.assign(tracks, tracks + (size_t)n_tracks * taps);
-    *out = h;
+    *out = h.release();
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 void aw_hrir_destroy(aw_hrir *h) { delete h; }
 int32_t aw_hrir_track_count(const aw_hrir *h) { return h ? h->n_tracks : 0; }
 int32_t aw_hrir_taps(const aw_hrir *h) { return h ? h->taps : 0; }
@@ -389,7 +401,7 @@ static int align_hop(const aw_context *ctx, int hop) {
 
 aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_in, const int32_t *left_track,
                                 const int32_t *right_track, int32_t n_streams, int32_t block_hint,
-                                aw_spatializer **out) {
+                                aw_spatializer **out) try {
     (void)block_hint;
     if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
@@ -409,7 +421,8 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
     if (mapped == 0) return fail(AW_ERR_CONVOLUTION_SETUP_FAILED, "No valid renderers created");   // :420-422
     AW_HIP_TRY(hipSetDevice(ctx->device));
 
-    aw_spatializer *sp = new (std::nothrow) aw_spatializer();
+    awr::Owner<aw_spatializer> owner(new (std::nothrow) aw_spatializer(), aw_spatializer_destroy);      // destroyed on every early return below
+    aw_spatializer *sp = owner.get();
     if (!sp) return fail(AW_ERR_OUT_OF_MEMORY, "spatializer");
     sp->ctx = ctx; sp->n_channels = n_in; sp->n_pairs = (n_in + 1) / 2; sp->n_streams = n_streams;
     sp->taps = hrir->taps;
@@ -500,7 +513,7 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
         if (n_in > 8) {                  // 32 floats for the wide split kernel's padded copy of a call's very last frame (tile_lw.hpp)
             hipError_t et = hipMalloc(reinterpret_cast<void **>(&sp->d_tail), 32 * sizeof(float));
             if (et == hipSuccess) et = hipMemsetAsync(sp->d_tail, 0, 32 * sizeof(float), ctx->stream);
-            if (et != hipSuccess) { aw_spatializer_destroy(sp); return awr::hip_fail(et, "spatializer setup"); }
+            if (et != hipSuccess) return awr::hip_fail(et, "spatializer setup");
         }
     }
     // The tables of the short-call kernels (fused tiles, partitioned delay line) are built in float64 on the host, the analogue of the
@@ -533,19 +546,19 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
     } catch (...) {
         tables_ok = false;
     }
-    if (!tables_ok) { aw_spatializer_destroy(sp); return fail(AW_ERR_OUT_OF_MEMORY, "filter tables: host memory"); }
+    if (!tables_ok) return fail(AW_ERR_OUT_OF_MEMORY, "filter tables: host memory");
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&sp->d_tab), all.size() * sizeof(awk::cf2));
     if (e == hipSuccess) e = hipMemcpy(sp->d_tab, all.data(), all.size() * sizeof(awk::cf2), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { aw_spatializer_destroy(sp); return awr::hip_fail(e, "filter tables"); }
+    if (e != hipSuccess) return awr::hip_fail(e, "filter tables");
     aw_status st = sp_alloc_hist(sp);
-    if (st != AW_OK) { aw_spatializer_destroy(sp); return st; }
+    if (st != AW_OK) return st;
     e = hipEventCreate(&sp->k0);
     if (e == hipSuccess) e = hipEventCreate(&sp->k1);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { aw_spatializer_destroy(sp); return awr::hip_fail(e, "spatializer setup"); }
-    *out = sp;
+    if (e != hipSuccess) return awr::hip_fail(e, "spatializer setup");
+    *out = owner.release();
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 void aw_spatializer_destroy(aw_spatializer *sp) {
     if (!sp) return;
@@ -610,7 +623,7 @@ int64_t aw_spatializer_info(const aw_spatializer *sp, int32_t what) {
 
 static void sp_drain_stages(aw_spatializer *sp);
 
-aw_status aw_spatializer_set_profiling(aw_spatializer *sp, int32_t enabled) {
+aw_status aw_spatializer_set_profiling(aw_spatializer *sp, int32_t enabled) try {
     if (!sp) return fail(AW_ERR_INVALID_ARGUMENT, "sp is NULL");
     sp->profiling = enabled != 0;
     sp->kernel_ms_sum = 0.0;
@@ -618,7 +631,7 @@ aw_status aw_spatializer_set_profiling(aw_spatializer *sp, int32_t enabled) {
     sp_drain_stages(sp);
     sp->stage_stats.clear();
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 static hipEvent_t sp_get_event(aw_spatializer *sp) {
     if (!sp->event_pool.empty()) {
@@ -691,7 +704,7 @@ int32_t aw_spatializer_kernel_time(aw_spatializer *sp, double *avg_ms, const cha
 }
 
 aw_status aw_spatializer_debug_stamps(aw_spatializer *sp, uint64_t *host_out, int64_t capacity_words,
-                                      int64_t *n_workgroups) {
+                                      int64_t *n_workgroups) try {
     if (!sp || !host_out || !n_workgroups) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
 #if defined(AW_STAMPS) && AW_STAMPS
     const int64_t words = (int64_t)sp->dbg_nwg * awk::kStamps;
@@ -706,7 +719,7 @@ aw_status aw_spatializer_debug_stamps(aw_spatializer *sp, uint64_t *host_out, in
     *n_workgroups = 0;
     return fail(AW_ERR_INVALID_ARGUMENT, "library not built with AW_STAMPS");
 #endif
-}
+} AW_NOEXCEPT_TAIL
 
 static void sp_fill_cfg(const aw_spatializer *sp, awk::TileParams &p) {
     const awk::LaunchCfg &c = sp->ctx->cfg;
@@ -1156,7 +1169,7 @@ static int64_t part_longest_call(const aw_spatializer *sp, int64_t max_frames) {
 
 // Sizes every grow-only device buffer for calls of up to max_frames frames, so that the process entries never
 // allocate afterwards ("process must not allocate"; creation may block).
-aw_status aw_spatializer_reserve(aw_spatializer *sp, int64_t max_frames) {
+aw_status aw_spatializer_reserve(aw_spatializer *sp, int64_t max_frames) try {
     if (!sp) return fail(AW_ERR_INVALID_ARGUMENT, "sp is NULL");
     if (max_frames <= 0) return fail(AW_ERR_INVALID_ARGUMENT, "max_frames must be positive");
     AW_HIP_TRY(hipSetDevice(sp->ctx->device));
@@ -1209,7 +1222,7 @@ aw_status aw_spatializer_reserve(aw_spatializer *sp, int64_t max_frames) {
     }
     sp->reserved_frames = std::max<int64_t>(sp->reserved_frames, max_frames);
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 // One call's launches for the streams [s_base, s_base + ns) (`in` / `out` at stream s_base), history carry included; the caller holds
 // the context's launch lock and flips hist_cur once every stream of the call has been through here.
@@ -1248,7 +1261,7 @@ static LwCallPlan sp_begin_call(aw_spatializer *sp, int64_t frames) {
     return lw;
 }
 
-aw_status aw_spatializer_process(aw_spatializer *sp, const float *in, float *out, int64_t frames) {
+aw_status aw_spatializer_process(aw_spatializer *sp, const float *in, float *out, int64_t frames) try {
     if (!sp || !in || !out) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     if (frames <= 0) return frames == 0 ? AW_OK : fail(AW_ERR_INVALID_ARGUMENT, "frames must be >= 0");
     AW_HIP_TRY(hipSetDevice(sp->ctx->device));
@@ -1258,15 +1271,15 @@ aw_status aw_spatializer_process(aw_spatializer *sp, const float *in, float *out
     if (st != AW_OK) return st;
     sp->hist_cur ^= 1;
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 /* ---- host entry ------------------------------------------------------------------------------------
  * The reference's callers hand over host buffers (AudioPipeline.swift:3-11: the four planar pointers of a render callback); an offline
  * batch host does too.  A multi-stream batch crosses PCIe in CHUNKS OF STREAMS (streams are independent: state is per stream), double
  * buffered on three HIP streams: H2D of chunk k+1 || kernels of chunk k || D2H of chunk k-1.  Page-locked caller buffers
- * (aw_host_alloc_pinned, hipHostMalloc, hipHostRegister) are read and written by the DMA engines directly; pageable ones go through
- * the HIP runtime's own staging (hipMemcpyAsync), still chunked.  aw_spatializer_reserve_host() sizes the device-side chunk buffers
- * ahead of time; without it they grow on the first call. */
+ * (aw_host_alloc_pinned, hipHostMalloc, hipHostRegister) are read and written by the DMA engines directly; pageable ones are bounced
+ * through page-locked chunks by the context's copy threads (below).  aw_spatializer_reserve_host() sizes the device-side chunk buffers
+ * and the bounce chunks ahead of time; without it they grow on the first call. */
 static int64_t host_chunk_streams(const aw_spatializer *sp, int64_t frames) {
     const size_t chunk_bytes = (size_t)sp->ctx->cfg.host_chunk_mb << 20;        // input bytes per staged chunk (LaunchCfg: read once per context)
     const size_t per_stream = (size_t)frames * sp->n_channels * sizeof(float);
@@ -1284,18 +1297,19 @@ static bool host_ptr_is_pinned(const void *p) {
 }
 
 static aw_status host_pipeline_objects(aw_context *c) {
-    if (c->s_h2d) return AW_OK;
+    if (c->s_h2d && c->s_d2h && c->ev_d2h[1]) return AW_OK;           // (ev_d2h[1] is the last object made below)
     if (!c->copy_pool) {
         const unsigned hw = std::thread::hardware_concurrency();
         c->copy_pool = new (std::nothrow) aw_context::CopyPool((int)std::min(12u, std::max(1u, hw / 4)));
         if (!c->copy_pool) return fail(AW_ERR_OUT_OF_MEMORY, "copy threads");
     }
-    AW_HIP_TRY(hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
-    AW_HIP_TRY(hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
+    // (a failure half-way leaves what exists in place: the next call makes the rest, aw_context_destroy frees whatever is there)
+    if (!c->s_h2d) AW_HIP_TRY(hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
+    if (!c->s_d2h) AW_HIP_TRY(hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
-        AW_HIP_TRY(hipEventCreateWithFlags(&c->ev_h2d[i], hipEventDisableTiming));
-        AW_HIP_TRY(hipEventCreateWithFlags(&c->ev_run[i], hipEventDisableTiming));
-        AW_HIP_TRY(hipEventCreateWithFlags(&c->ev_d2h[i], hipEventDisableTiming));
+        if (!c->ev_h2d[i]) AW_HIP_TRY(hipEventCreateWithFlags(&c->ev_h2d[i], hipEventDisableTiming));
+        if (!c->ev_run[i]) AW_HIP_TRY(hipEventCreateWithFlags(&c->ev_run[i], hipEventDisableTiming));
+        if (!c->ev_d2h[i]) AW_HIP_TRY(hipEventCreateWithFlags(&c->ev_d2h[i], hipEventDisableTiming));
     }
     return AW_OK;
 }
@@ -1313,7 +1327,7 @@ static aw_status host_stage_buffers(aw_spatializer *sp, int64_t frames, int64_t 
     return st;
 }
 
-aw_status aw_spatializer_reserve_host(aw_spatializer *sp, int64_t max_frames) {
+aw_status aw_spatializer_reserve_host(aw_spatializer *sp, int64_t max_frames) try {
     aw_status st = aw_spatializer_reserve(sp, max_frames);
     if (st != AW_OK) return st;
     std::lock_guard<std::mutex> lk(sp->ctx->launch_mu);
@@ -1322,9 +1336,9 @@ aw_status aw_spatializer_reserve_host(aw_spatializer *sp, int64_t max_frames) {
     st = host_stage_buffers(sp, max_frames, cs, /*bounce_in=*/true, /*bounce_out=*/true);
     if (st == AW_OK) { sp->host_chunk_streams = cs; sp->host_chunk_reserved = cs; sp->host_reserved_frames = std::max(sp->host_reserved_frames, max_frames); }
     return st;
-}
+} AW_NOEXCEPT_TAIL
 
-aw_status aw_spatializer_process_host(aw_spatializer *sp, const float *in, float *out, int64_t frames) {
+aw_status aw_spatializer_process_host(aw_spatializer *sp, const float *in, float *out, int64_t frames) try {
     if (!sp || !in || !out) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     if (frames <= 0) return frames == 0 ? AW_OK : fail(AW_ERR_INVALID_ARGUMENT, "frames must be >= 0");
     AW_HIP_TRY(hipSetDevice(sp->ctx->device));
@@ -1408,24 +1422,24 @@ aw_status aw_spatializer_process_host(aw_spatializer *sp, const float *in, float
     AW_HIP_TRY(he);
     sp->hist_cur ^= 1;
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 /* Page-locked host memory for the host entries (hipHostMalloc): buffers from here cross PCIe by DMA without the runtime's staging copy. */
-aw_status aw_host_alloc_pinned(aw_context *ctx, size_t bytes, void **ptr) {
+aw_status aw_host_alloc_pinned(aw_context *ctx, size_t bytes, void **ptr) try {
     if (!ctx || !ptr) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     AW_HIP_TRY(hipSetDevice(ctx->device));
     AW_HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
     ctx->device_allocs += 1;
     return AW_OK;
-}
-aw_status aw_host_free_pinned(aw_context *ctx, void *ptr) {
+} AW_NOEXCEPT_TAIL
+aw_status aw_host_free_pinned(aw_context *ctx, void *ptr) try {
     if (!ctx) return fail(AW_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (ptr) AW_HIP_TRY(hipHostFree(ptr));
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 aw_status aw_spatializer_process_planar(aw_spatializer *sp, const float *in_l, const float *in_r, float *out_l,
-                                        float *out_r, int32_t frames) {
+                                        float *out_r, int32_t frames) try {
     if (!sp || !in_l || !out_l || !out_r) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     if (sp->n_streams != 1 || sp->n_channels != 2)
         return fail(AW_ERR_INVALID_ARGUMENT, "planar entry needs a 1-stream, 2-channel spatializer");
@@ -1465,25 +1479,26 @@ aw_status aw_spatializer_process_planar(aw_spatializer *sp, const float *in_l, c
     AW_HIP_TRY(hipMemcpyAsync(out_r, d_or, sizeof(float) * frames, hipMemcpyDeviceToHost, s));
     AW_HIP_TRY(hipStreamSynchronize(s));
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
-aw_status aw_spatializer_reset(aw_spatializer *sp) {
+aw_status aw_spatializer_reset(aw_spatializer *sp) try {
     if (!sp) return fail(AW_ERR_INVALID_ARGUMENT, "sp is NULL");
     AW_HIP_TRY(hipSetDevice(sp->ctx->device));
     const size_t n = (size_t)sp->n_streams * sp->hist_len * sp->n_channels;
     for (int i = 0; i < 2; ++i)
         AW_HIP_TRY(hipMemsetAsync(sp->d_hist[i], 0, std::max<size_t>(n, 1) * sizeof(float), sp->ctx->stream));
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 /* ---- mono engine (ConvolutionEngine) ------------------------------------------------------- */
 aw_status aw_engine_create(aw_context *ctx, const float *hrir_samples, int32_t count, int32_t block_size,
-                           aw_engine **out) {
+                           aw_engine **out) try {
     if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     if (!ctx || !hrir_samples) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     if (count <= 0 || block_size <= 0) return fail(AW_ERR_CONVOLUTION_SETUP_FAILED, "empty HRIR or non-positive block size");
-    aw_engine *e = new (std::nothrow) aw_engine();
+    awr::Owner<aw_engine> owner(new (std::nothrow) aw_engine(), aw_engine_destroy);
+    aw_engine *e = owner.get();
     if (!e) return fail(AW_ERR_OUT_OF_MEMORY, "engine");
     e->ctx = ctx; e->block_size = block_size;
     aw_status st = aw_hrir_create(ctx, hrir_samples, 1, count, 0.0, &e->hrir);
@@ -1492,11 +1507,11 @@ aw_status aw_engine_create(aw_context *ctx, const float *hrir_samples, int32_t c
     // the engine processes exactly block_size frames per call: everything process needs is allocated here, like
     // ConvolutionEngine.init (ConvolutionEngine.swift:97-138) — process does not allocate
     if (st == AW_OK) st = aw_spatializer_reserve_host(e->sp, block_size);
-    if (st != AW_OK) { aw_engine_destroy(e); return st; }
+    if (st != AW_OK) return st;
     e->tmp_out.assign((size_t)block_size * 2, 0.f);
-    *out = e;
+    *out = owner.release();
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 void aw_engine_destroy(aw_engine *e) {
     if (!e) return;
@@ -1507,37 +1522,37 @@ void aw_engine_destroy(aw_engine *e) {
 
 int32_t aw_engine_block_size(const aw_engine *e) { return e ? e->block_size : 0; }
 
-aw_status aw_engine_process(aw_engine *e, const float *input, float *output) {
+aw_status aw_engine_process(aw_engine *e, const float *input, float *output) try {
     if (!e || !input || !output) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     aw_status st = aw_spatializer_process_host(e->sp, input, e->tmp_out.data(), e->block_size);
     if (st != AW_OK) return st;
     for (int i = 0; i < e->block_size; ++i) output[i] = e->tmp_out[2 * (size_t)i];
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
-aw_status aw_engine_process_n(aw_engine *e, const float *input, float *output, int32_t frame_count) {
+aw_status aw_engine_process_n(aw_engine *e, const float *input, float *output, int32_t frame_count) try {
     if (!e) return fail(AW_ERR_INVALID_ARGUMENT, "engine is NULL");
     if (frame_count != e->block_size)      // guard count == blockSize else { return }  ConvolutionEngine.swift:372
         return fail(AW_ERR_BLOCK_SIZE_MISMATCH, "frameCount != blockSize: block ignored");
     return aw_engine_process(e, input, output);
-}
+} AW_NOEXCEPT_TAIL
 
-aw_status aw_engine_process_accumulate(aw_engine *e, const float *input, float *acc) {
+aw_status aw_engine_process_accumulate(aw_engine *e, const float *input, float *acc) try {
     if (!e || !input || !acc) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     aw_status st = aw_spatializer_process_host(e->sp, input, e->tmp_out.data(), e->block_size);
     if (st != AW_OK) return st;
     for (int i = 0; i < e->block_size; ++i) acc[i] += e->tmp_out[2 * (size_t)i];    // vDSP_vadd, ConvolutionEngine.swift:393
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
-aw_status aw_engine_reset(aw_engine *e) {
+aw_status aw_engine_reset(aw_engine *e) try {
     if (!e) return fail(AW_ERR_INVALID_ARGUMENT, "engine is NULL");
     return aw_spatializer_reset(e->sp);
-}
+} AW_NOEXCEPT_TAIL
 
 /* ---- callback-size adapter (RealtimeAudioProcessor) ---------------------------------------- */
 aw_status aw_realtime_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_renderers, const int32_t *left_track,
-                             const int32_t *right_track, int32_t block_size, int32_t max_frames, aw_realtime **out) {
+                             const int32_t *right_track, int32_t block_size, int32_t max_frames, aw_realtime **out) try {
     if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     if (!ctx || !hrir) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -1545,7 +1560,8 @@ aw_status aw_realtime_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_ren
         return fail(AW_ERR_INVALID_ARGUMENT, "blockSize and maxFramesPerCallback must be positive");
     if (n_renderers < 0 || (n_renderers > 0 && (!left_track || !right_track)))
         return fail(AW_ERR_INVALID_ARGUMENT, "bad renderer list");
-    aw_realtime *p = new (std::nothrow) aw_realtime();
+    awr::Owner<aw_realtime> owner(new (std::nothrow) aw_realtime(), aw_realtime_destroy);
+    aw_realtime *p = owner.get();
     if (!p) return fail(AW_ERR_OUT_OF_MEMORY, "realtime");
     p->ctx = ctx; p->block_size = block_size; p->max_frames = max_frames; p->n_renderers = n_renderers;
     p->fifo_capacity = max_frames + block_size;                         // :41
@@ -1563,11 +1579,11 @@ aw_status aw_realtime_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_ren
         aw_status st = aw_spatializer_create(ctx, hrir, 2, lt, rt, 1, block_size, &p->sp);
         // device side: kernel scratch and the host entry's staging for the longest device call a callback can make (process must not allocate)
         if (st == AW_OK) st = aw_spatializer_reserve_host(p->sp, p->fifo_capacity);
-        if (st != AW_OK) { aw_realtime_destroy(p); return st; }
+        if (st != AW_OK) return st;
     }
-    *out = p;
+    *out = owner.release();
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 /* Introspection for the "process must not allocate" contract test: 0 bytes of host buffer capacity held (pending, ready, FIFO),
  * 1 bytes of grow-only device buffers (aw_spatializer_info 6), 2 device allocations made so far on the context (aw_spatializer_info 13). */
@@ -1588,7 +1604,7 @@ void aw_realtime_destroy(aw_realtime *p) {
 }
 
 aw_status aw_realtime_process(aw_realtime *p, const float *in_l, const float *in_r, float *out_l, float *out_r,
-                              int32_t frame_count) {
+                              int32_t frame_count) try {
     if (!p) return fail(AW_ERR_INVALID_ARGUMENT, "processor is NULL");
     if (frame_count <= 0) return AW_OK;                                 // guard frameCount > 0 else { return }  :84
     if (!in_l || !out_l || !out_r) return fail(AW_ERR_INVALID_ARGUMENT, "NULL buffer");
@@ -1638,9 +1654,9 @@ aw_status aw_realtime_process(aw_realtime *p, const float *in_l, const float *in
         }
     }
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
-aw_status aw_realtime_reset(aw_realtime *p) {                           // :121-139
+aw_status aw_realtime_reset(aw_realtime *p) try {                           // :121-139
     if (!p) return fail(AW_ERR_INVALID_ARGUMENT, "processor is NULL");
     if (p->sp) {
         aw_status st = aw_spatializer_reset(p->sp);
@@ -1651,16 +1667,16 @@ aw_status aw_realtime_reset(aw_realtime *p) {                           // :121-
     std::fill(p->fifo_right.begin(), p->fifo_right.end(), 0.f);
     p->pending_count = 0; p->fifo_read_index = 0; p->fifo_count = 0;
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 /* ---- synthetic input --------------------------------------------------------------------------- */
 aw_status aw_synth_fill(aw_context *ctx, float *dst, int32_t n_streams, int64_t frames, int32_t n_channels,
-                        uint64_t seed, uint64_t first_stream) {
+                        uint64_t seed, uint64_t first_stream) try {
     if (!ctx || !dst) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n_streams <= 0 || frames <= 0 || n_channels <= 0) return fail(AW_ERR_INVALID_ARGUMENT, "non-positive size");
     AW_HIP_TRY(hipSetDevice(ctx->device));
     AW_HIP_TRY(awk::launch_synth_fill(dst, n_streams, frames * n_channels, seed, first_stream, ctx->stream));
     return AW_OK;
-}
+} AW_NOEXCEPT_TAIL
 
 }  // extern "C"

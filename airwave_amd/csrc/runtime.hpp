@@ -4,6 +4,7 @@
 
 #include <atomic>
 #include <cstdint>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -17,12 +18,20 @@ void set_error(const std::string &msg);
 aw_status fail(aw_status code, const std::string &msg);
 aw_status hip_fail(hipError_t e, const char *what);
 bool context_literal_resampler(const aw_context *ctx);
+// The C ABI promises "no exceptions": every entry point that can allocate host memory (containers, strings, threads) is a
+// function-try-block whose handler returns caught() — std::bad_alloc / std::length_error become AW_ERR_OUT_OF_MEMORY, anything else
+// AW_ERR_INVALID_ARGUMENT with the exception's text in aw_last_error_message().  Handles under construction are held by Owner<> until
+// the entry hands them out, so an exception on the way leaks nothing.
+aw_status caught() noexcept;
+#define AW_NOEXCEPT_TAIL catch (...) { return ::awr::caught(); }
 
 #define AW_HIP_TRY(expr)                                          \
     do {                                                          \
         hipError_t _e = (expr);                                   \
         if (_e != hipSuccess) return ::awr::hip_fail(_e, #expr);  \
     } while (0)
+
+template <class T> using Owner = std::unique_ptr<T, void (*)(T *)>;
 
 }  // namespace awr
 

@@ -37,6 +37,39 @@ def test_no_environment_lookups_on_process_paths():
             assert src[start:start + 60].lstrip().startswith("hipError_t prepare_kernels("), (f, src[start:start + 60])
 
 
+def test_every_status_returning_entry_point_is_an_exception_barrier():
+    """include/airwave_hip.h promises "no exceptions": every `aw_status aw_*` definition is a function-try-block whose handler maps what
+    was thrown to a status (runtime.hpp: awr::caught), so std::bad_alloc out of a container never crosses the C ABI."""
+    n = 0
+    for rel in ("runtime.cpp", "eq_runtime.cpp", os.path.join("host", "host_api.cpp"), os.path.join("host", "eq.cpp"), os.path.join("host", "tables.cpp")):
+        src = open(os.path.join(ROOT, "airwave_amd", "csrc", rel)).read()
+        for m in re.finditer(r"^aw_status (aw_\w+)\(", src, re.M):
+            head = src[m.start():src.index("{", m.end())]
+            assert head.rstrip().endswith("try"), (rel, m.group(1))
+            n += 1
+        assert src.count("AW_NOEXCEPT_TAIL") == len(re.findall(r"^aw_status aw_\w+\(", src, re.M)), rel
+    assert n >= 60
+
+
+@pytest.mark.gpu
+def test_an_exception_inside_an_entry_point_comes_back_as_a_status():
+    """A track set whose size no std::vector can hold: vector::assign throws std::length_error before it reads a byte; the caller gets
+    AW_ERR_OUT_OF_MEMORY and a message, the process lives, and the context still works afterwards."""
+    import ctypes
+    import airwave_amd as aw
+    from airwave_amd import _capi
+    lib = _capi.load()
+    ctx = aw.Context()
+    h = ctypes.c_void_p()
+    one = np.zeros(4, np.float32)
+    st = lib.aw_hrir_create(ctx._h, one.ctypes.data_as(_capi.c_float_p), 2 ** 31 - 1, 2 ** 31 - 1, 48000.0, ctypes.byref(h))
+    assert lib.aw_status_string(st) == b"out of memory" and not h.value
+    assert lib.aw_last_error_message()
+    hr = aw.HRIR(np.ones((2, 8), np.float32), 48000.0, ctx=ctx)
+    sp = aw.Spatializer(hr, [0, 1], [1, 0], 1, ctx=ctx)
+    assert sp.process(np.ones((1, 64, 2), np.float32)).shape == (1, 64, 2)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("taps,channels", [(20000, 7), (40000, 14), (4320, 8)])
 def test_process_does_not_allocate_after_reserve(oracle, taps, channels):
