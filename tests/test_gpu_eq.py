@@ -230,23 +230,21 @@ def test_reset_clears_histories_and_mono_duplication(aw):
 
 
 def test_ten_filter_workload_stays_finite_across_callback_sizes(aw):
-    fl = [flt(aw, PK if i % 2 == 0 else HSC, 250 + i * 1000, (i % 3) - 1, 0.8) for i in range(10)]   # :331-357 (1 s instead of 10 s per size)
+    """ParametricEqualizerProcessorTests.swift:317-358 as written there: ten seconds of 0.25 per callback size through the planar
+    (render-callback shaped) entry of ONE prepared state.  Beyond the reference's assertions: the steady state of a constant input
+    is the cascade's DC gain."""
+    fl = [flt(aw, PK if i % 2 == 0 else HSC, 250 + i * 1000, (i % 3) - 1, 0.8) for i in range(10)]
+    st = aw.ParametricEqualizerProcessor.prepare(aw.EqualizerDefinition(-3.0, fl), 48000.0)
+    dc = 10 ** (-3 / 20) * np.prod([(c[0] + c[1] + c[2]) / (1 + c[3] + c[4]) for c in
+                                    [aw.BiquadCoefficientBuilder.make(f.type, f.gainDB, f.frequencyHz, f.q, 48000.0) for f in fl]])
     for size in (128, 512, 1024):
-        st = aw.ParametricEqualizerProcessor.prepare(aw.EqualizerDefinition(-3.0, fl), 48000.0)
-        x = np.full((size, 2), 0.25, np.float32)
-        ctx = st.ctx
-        d = ctx.alloc(x.nbytes)
-        for _ in range(48000 // size):
-            ctx.h2d(d, x)
-            st.process_device(d, d, size)
-        y = np.empty_like(x)
-        ctx.d2h(y, d)
-        ctx.free(d)
-        assert np.isfinite(y).all()
-        # steady state of a constant input = DC gain of the cascade
-        dc = 10 ** (-3 / 20) * np.prod([(c[0] + c[1] + c[2]) / (1 + c[3] + c[4]) for c in
-                                        [aw.BiquadCoefficientBuilder.make(f.type, f.gainDB, f.frequencyHz, f.q, 48000.0) for f in fl]])
-        assert abs(y[-1, 0] - 0.25 * dc) < 1e-5
+        x = np.full(size, 0.25, np.float32)
+        processed = 0
+        while processed < 48000 * 10:
+            left, right = st.process(x, x)
+            processed += size
+        assert np.isfinite(left).all() and np.isfinite(right).all()
+        assert np.max(np.abs(left - 0.25 * dc)) < 1e-5 and np.max(np.abs(right - 0.25 * dc)) < 1e-5
 
 
 def test_reference_fixture_curve(aw, golden_dir):

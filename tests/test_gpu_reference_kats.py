@@ -194,11 +194,18 @@ def test_realtime_random_callback_sequences_match_oracle(aw, oracle, golden_dir,
     assert oracle.peak_rel_error(g, o) < 1e-5
 
 
-def test_one_second_of_stereo_input_across_performance_callback_sizes(aw):
-    """RealtimeAudioProcessorTests.swift:128-... (ten seconds per size upstream; one second here keeps the suite short):
-    128-, 512- and 1024-frame callbacks stay finite and keep producing output."""
+def test_ten_seconds_of_stereo_input_across_performance_callback_sizes(aw):
+    """RealtimeAudioProcessorTests.swift:128-166 as written there: ten seconds of 0.25 on both inputs through one renderer, in 128-,
+    512- and 1024-frame callbacks; every callback's output stays finite.  (Round 5: a callback costs ~25 us, so the reference's full
+    ten seconds fit the suite — rounds 1-4 ran one second.)  Beyond the reference's assertions: with the one-tap gain-1 HRIR the
+    steady-state output IS the input, so the last callback is 0.25 on the left ear to float32 rounding."""
     for size in (128, 512, 1024):
-        p = make_processor(aw)
-        for _ in range(48000 // size):
-            l, r = run(p, size)
-        assert np.all(np.isfinite(l)) and np.all(np.isfinite(r)) and abs(float(l[-1])) > 0
+        p = make_processor(aw, renderer_count=1)
+        x = np.full(size, 0.25, np.float32)
+        frames = 0
+        while frames < 48000 * 10:
+            l, r = p.process(x, x)
+            frames += size
+            assert np.all(np.isfinite(l)) and np.all(np.isfinite(r))
+        assert frames >= 48000 * 10
+        assert np.max(np.abs(l - 0.25)) < 1e-6, size
