@@ -44,3 +44,23 @@ def test_bench_line_carries_every_contract_field():
     e = d["secondary_end_to_end"][0]
     assert e["pinned"] is True and e["value"] > 0 and e["h2d_GBs"] > 0 and e["pageable"]["pinned"] is False and e["parity_spot_err"] < 1e-5
     assert e["value"] < d["value"]                            # the PCIe-inclusive rate is a secondary: never the headline
+
+
+@pytest.mark.gpu
+def test_default_line_with_driver_style_flags_carries_the_secondaries():
+    """`python bench.py --steps K --warmup W` as the driver runs it: the headline (cfg 3) with K and W as given, the 14-channel-input reading,
+    cfg 2 (BASELINE configs[1]) with ITS OWN steady-state step counts — a millisecond step needs >= 25 ms of warm-up, K and W are the
+    headline's — and the PCIe-inclusive legs; one JSON line, every parity spot check below 1e-5."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--cpu-sample-streams", "8"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["steps"] == 6 and d["warmup"] == 2 and "cfg3" in d["config"]["workload"] and d["parity_spot_err"] < 1e-5
+    assert d["secondary"]["steps"] == 6 and d["secondary"]["parity_spot_err"] < 1e-5 and d["secondary"]["value"] < d["value"]
+    c2 = d["secondary_cfg2"]
+    assert c2["steps"] >= 100 and c2["warmup"] >= 40 and "cfg2" in c2["config"]["workload"] and c2["parity_spot_err"] < 1e-5
+    assert 0.15 < c2["roofline"]["frac"] < 0.40 and 0.12 < d["roofline"]["frac"] < 0.40
+    assert [e["name"] for e in d["secondary_end_to_end"]] == ["cfg3", "cfg2"]
+    assert d["roofline"]["traffic"] is not None, d["roofline"]["traffic_note"]          # a committed profile of THESE device sources exists
