@@ -55,6 +55,33 @@ HEADERS = sorted(os.path.relpath(os.path.join(d, f), CSRC) for d, _, fs in os.wa
 ]
 
 
+# environment variables that change what gets compiled: recorded (and digested) with the flags, so that two libraries built from the same
+# sources with different tuning cannot share a provenance (round-5 review: the digest covered sources, not flags)
+FLAG_ENV = ("AW_MARCH_SLP", "AW_KERNELS_SLP", "AW_OLS2_EVEN_SLP", "AW_EXTRA_HIPCC_FLAGS", "HIPCC")
+ABLATION_PREFIXES = ("AW_ABL", "AW_LW_ABL", "AW_EQ_ABL")
+
+
+def common_flags(defines=()):
+    return ["-O3", "-std=c++17", "-fPIC", "-pthread", "-fvisibility=hidden", f"--offload-arch={ARCH}",
+            "-Wall", "-Wno-unused-result", "-ffp-contract=fast"] + [f"-D{d}" for d in defines] + os.environ.get("AW_EXTRA_HIPCC_FLAGS", "").split()
+
+
+def flag_manifest(defines=()) -> dict:
+    """The full per-source flag list of a build plus the environment knobs behind it, and its digest (first 16 hex of sha256 over the
+    canonical JSON).  airwave_amd/.build_flags.json holds the manifest of the library that was last linked; provenance.py reads it."""
+    import hashlib
+    import json
+    by_source = {src: common_flags(defines) + EXTRA_FLAGS.get(src, []) for src in SOURCES}
+    env = {k: os.environ.get(k, "") for k in FLAG_ENV if os.environ.get(k)}
+    body = {"arch": ARCH, "flags_by_source": by_source, "env": env}
+    body["build_flags_sha16"] = hashlib.sha256(json.dumps(body, sort_keys=True).encode()).hexdigest()[:16]
+    return body
+
+
+def has_ablation(flags) -> bool:
+    return any(f.startswith("-D") and f[2:].startswith(ABLATION_PREFIXES) and not f.endswith("=0") for f in flags)
+
+
 def hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
@@ -89,6 +116,12 @@ def build(force: bool = False, verbose: bool = False, stamps: bool = False, defi
     for A/B runs.  Variants are never loaded unless AIRWAVE_HIP_LIBRARY points at them."""
     global OUT, OBJ
     defines = list(defines)
+    # a timing ablation (wrong results) is only ever built as a suffixed variant that says what it is; cplx.hpp #errors on the macros otherwise
+    if has_ablation(common_flags(defines)):
+        if not suffix:
+            raise RuntimeError("timing-ablation macros (AW_ABL_* / AW_LW_ABL_* / AW_EQ_ABL) give wrong results: build them as a variant "
+                               "(suffix=..., libairwave_hip_<suffix>.so), never as libairwave_hip.so")
+        defines.append("AW_ABLATION_BUILD=1")
     if stamps:
         suffix = suffix or "stamps"
         defines.append("AW_STAMPS=1")
@@ -104,29 +137,45 @@ def build(force: bool = False, verbose: bool = False, stamps: bool = False, defi
             if src not in only and os.path.exists(os.path.join(main_obj, o)):
                 shutil.copy2(os.path.join(main_obj, o), os.path.join(OBJ, o))
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    common = ["-O3", "-std=c++17", "-fPIC", "-pthread", "-fvisibility=hidden", f"--offload-arch={ARCH}",
-              "-Wall", "-Wno-unused-result", "-ffp-contract=fast"] + [f"-D{d}" for d in defines] + os.environ.get("AW_EXTRA_HIPCC_FLAGS", "").split()
+    import json
+    manifest = flag_manifest(defines)
     objs, jobs = [], []
     for src in SOURCES:
         spath = os.path.join(CSRC, src)
         opath = os.path.join(OBJ, src.replace("/", "_") + ".o")
         objs.append(opath)
-        if (force and (not only or src in only)) or (src in only) or _stale(opath, [spath] + hdrs):
-            jobs.append([hipcc()] + common + EXTRA_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", spath, "-o", opath])
+        flags = manifest["flags_by_source"][src]
+        # an object is stale when a source or header is newer — or when it was compiled with other flags (its .flags stamp)
+        try:
+            same_flags = open(opath + ".flags").read() == " ".join(flags) or (suffix and only and src not in only)
+        except OSError:
+            same_flags = bool(suffix and only and src not in only)
+        if (force and (not only or src in only)) or (src in only) or not same_flags or _stale(opath, [spath] + hdrs):
+            jobs.append((opath, flags, [hipcc()] + flags + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", spath, "-o", opath]))
     if jobs:          # the translation units are independent: a few hipcc processes side by side (each peaks at ~2 GB)
         from concurrent.futures import ThreadPoolExecutor
-        def run(cmd):
+        def run(job):
+            opath, flags, cmd = job
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
+            with open(opath + ".flags", "w") as f:
+                f.write(" ".join(flags))
         with ThreadPoolExecutor(max_workers=int(os.environ.get("AW_BUILD_JOBS", "8"))) as ex:
             list(ex.map(run, jobs))
     _record_head()
-    if force or _stale(OUT, objs):
+    flags_file = os.path.join(HERE, ".build_flags.json" if not suffix else f".build_flags_{suffix}.json")
+    try:
+        recorded = json.load(open(flags_file)).get("build_flags_sha16")
+    except (OSError, ValueError):
+        recorded = None
+    if force or jobs or _stale(OUT, objs) or recorded != manifest["build_flags_sha16"]:
         cmd = [hipcc(), "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", "-o", OUT] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
+        with open(flags_file, "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
     return OUT
 
 

@@ -5,6 +5,19 @@
 // Everything is fully unrolled with compile-time indices so arrays stay in VGPRs.
 #pragma once
 
+// Timing-ablation macros (AW_ABL_*, AW_LW_ABL_*, AW_ABL2, AW_EQ_ABL != 0) remove work from the kernels to time what is left: they produce
+// WRONG RESULTS (or races).  They may only be compiled into a library that says so: build.py passes -DAW_ABLATION_BUILD=1 together with a
+// library suffix (libairwave_hip_<suffix>.so, never loaded unless AIRWAVE_HIP_LIBRARY points at it); in any other build they are an error,
+// so a stray define or AW_EXTRA_HIPCC_FLAGS on a build box cannot yield a wrong-result libairwave_hip.so (tests/test_build_provenance.py).
+#if !defined(AW_ABLATION_BUILD)
+#if defined(AW_ABL_NOLOAD) || defined(AW_ABL_NOTAB) || defined(AW_ABL_NOCMAC) || defined(AW_ABL_NOPARTNER) || defined(AW_ABL_NOSTORE) || \
+    defined(AW_ABL_FWD_NOSTORE) || defined(AW_ABL2) || defined(AW_ABL_NOFFT) || defined(AW_ABL_NOBARRIER) || defined(AW_ABL_MARCH_NOSTORE) || \
+    defined(AW_ABL_MARCH_NOLOAD) || defined(AW_LW_ABL_SPLIT_NOLOAD) || defined(AW_LW_ABL_SPLIT_NOSTORE) || defined(AW_LW_ABL_ROWS_NOLOAD) || \
+    defined(AW_LW_ABL_ROWS_NOTAB) || defined(AW_LW_ABL_ROWS_NOSTORE) || (defined(AW_EQ_ABL) && AW_EQ_ABL != 0)
+#error "timing-ablation macro in a product build: ablations give wrong results; build them with -DAW_ABLATION_BUILD=1 and a library suffix (airwave_amd/build.py)"
+#endif
+#endif
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define AW_HD __host__ __device__ __forceinline__

@@ -29,3 +29,36 @@ def build_head() -> str:
         return open(os.path.join(HERE, ".build_head")).read().strip() or "unknown"
     except OSError:
         return "unknown"
+
+
+
+CSRC_DIR = os.path.join(HERE, "csrc")
+
+
+def host_source_digest() -> str:
+    """sha256 over the host side of the library (runtime.cpp, eq_runtime.cpp, host/*): the launch policy, chunking and table builders
+    that decide which kernels run and how many bytes a step moves — a traffic profile is only current if these agree too."""
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC_DIR, f) for f in sorted(os.listdir(CSRC_DIR)) if f.endswith((".cpp", ".hpp", ".h"))]
+    host = os.path.join(CSRC_DIR, "host")
+    files += [os.path.join(host, f) for f in sorted(os.listdir(host))]
+    for p in files:
+        h.update(os.path.relpath(p, CSRC_DIR).encode())
+        h.update(b"\0")
+        h.update(open(p, "rb").read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
+def build_flags() -> dict:
+    """The flag manifest of the library that was last linked (airwave_amd/.build_flags.json, written by build.py): per-source hipcc
+    flags, the environment knobs that shaped them and their digest.  {} if no build recorded one."""
+    import json
+    try:
+        return json.load(open(os.path.join(HERE, ".build_flags.json")))
+    except (OSError, ValueError):
+        return {}
+
+
+def build_flags_digest() -> str:
+    return build_flags().get("build_flags_sha16", "unrecorded")

@@ -35,3 +35,35 @@ def aggregate_throughput(frames_done: float, elapsed_s: float, device=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(f, op=dist.ReduceOp.SUM)
     return float(f.item()), float(t.item()), float(f.item()) / float(t.item())
+
+
+def rate_of_stream(i: int, total: int, rates) -> float:
+    """BASELINE cfg 5 buckets the batch by sample rate: stream i of `total` gets rates[i * len(rates) // total] (contiguous buckets)."""
+    return rates[i * len(rates) // total]
+
+
+def plan_streams(streams: int, rates, world_size: int, rank: int, scaling: str = "weak"):
+    """Which streams this rank owns, as (global_stream_ids, rates) in processing order.
+
+    weak   — `streams` is the PER-GPU count: every rank owns that many, ids rank-major, rates bucketed within the rank's batch
+             (per-GPU work fixed as N grows; bench.py's default and what the driver's N = 1, 2, 4, 8 runs measure).
+    strong — `streams` is the JOB TOTAL (BASELINE cfg 3 / 4 / 5: 1024 / 4096 / 8192 streams over the node): the batch is bucketed by
+             rate FIRST and every bucket is split across the ranks with shard_streams, so each rank gets an equal share of every
+             rate (a rank that owned only 96 kHz streams would finish last); a bucket's remainder streams are dealt round robin across buckets, so rank totals differ by at most one.
+    The union over ranks is exactly range(total) with no overlap; nothing here needs a collective."""
+    rates = list(rates)
+    if scaling == "weak":
+        first, count = weak_shard(streams, world_size, rank)
+        return [first + i for i in range(count)], [rate_of_stream(i, count, rates) for i in range(count)]
+    if scaling != "strong":
+        raise ValueError(f"scaling must be 'weak' or 'strong', not {scaling!r}")
+    ids, out_rates = [], []
+    bounds = [next((i for i in range(streams) if rate_of_stream(i, streams, rates) == r), streams) for r in rates] + [streams] if streams else [0] * (len(rates) + 1)
+    extra = 0           # remainder streams handed out so far: the next bucket's go to the ranks after them (round robin), totals differ by <= 1
+    for k, r in enumerate(rates):
+        a, b = bounds[k], bounds[k + 1]
+        first, count = shard_streams(b - a, world_size, (rank - extra) % world_size)
+        extra += (b - a) % world_size
+        ids += [a + first + i for i in range(count)]
+        out_rates += [r] * count
+    return ids, out_rates

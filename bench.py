@@ -61,6 +61,9 @@ WORKLOADS = {
     "cfg5": dict(streams=1024, channels=7, hrir="StageSH1.0.wav", taps=4320, seconds=10.0, steps=5, warmup=1, rates=[44100, 48000, 96000],
                  desc="cfg5: 7 speakers, streams split evenly over 44.1/48/96 kHz -> StageSH1.0 resampled per rate, 1024 streams/GPU x 10 s"),
 }
+# --scaling strong: BASELINE.json quotes cfg 3 / 4 / 5 as JOB totals (1024 / 4096 / 8192 streams over the GPUs of one node); weak scaling (the
+# default, what the driver's N = 1, 2, 4, 8 runs use) fixes the per-GPU count above instead
+TOTAL_STREAMS = {"cfg1": 1, "cfg2": 128, "cfg2-14ch": 128, "cfg3": 1024, "cfg3-14ch": 1024, "cfg4": 4096, "cfg5": 8192}
 SECONDARY = {"cfg3": "cfg3-14ch"}          # measured in the same run, reported inside the primary's JSON line
 SPEAKERS7 = ["FL", "FR", "FC", "BL", "BR", "SL", "SR"]
 
@@ -118,11 +121,13 @@ def committed_traffic(workload: str, S: int, F: int, C: int):
     same workload (profiles/*/traffic_<workload>.json, made by tools/profile_round5.sh: separate --pmc passes, read bytes
     from TCC_EA0_RDREQ_{32,64,128}B because FETCH_SIZE counts a 128-B request as 64 B on gfx950).  PMC counters cannot be
     collected from inside this process, so this is the last committed measurement — and only one made on THESE kernels: a
-    profile records a digest of csrc/device at the time it was taken (and the git HEAD of that build), and a profile whose
-    digest differs from the tree's is refused (returns (None, why)) instead of silently going stale."""
+    profile records digests of csrc/device, of the host side of the library (runtime.cpp: launch policy, chunking; host/: table
+    builders) and of the build's compiler flags at the time it was taken (and the git HEAD of that build), and a profile whose
+    digests differ from the tree's is refused (returns (None, why)) instead of silently going stale."""
     import glob
-    from airwave_amd.provenance import device_source_digest
+    from airwave_amd.provenance import build_flags_digest, device_source_digest, host_source_digest
     digest = device_source_digest()
+    ident = {"device_src_sha16": digest, "host_src_sha16": host_source_digest(), "build_flags_sha16": build_flags_digest()}
     best, why = None, "no committed profile of this workload"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"traffic_{workload}.json"))):
         try:
@@ -131,9 +136,10 @@ def committed_traffic(workload: str, S: int, F: int, C: int):
             continue
         if (d["streams_per_gpu"], d["frames_per_stream"], d["input_channels"]) != (S, F, C):
             continue
-        if d.get("device_src_sha16") != digest:
-            why = (f"newest profile of this shape ({os.path.relpath(path, ROOT)}, device sources {d.get('device_src_sha16', 'unrecorded')}, "
-                   f"HEAD {d.get('git_head', 'unrecorded')}) predates the current device sources ({digest}): re-profile")
+        stale = [k for k, v in ident.items() if d.get(k) != v]          # kernels, launch policy / table builders, compiler flags: all three
+        if stale:
+            why = (f"newest profile of this shape ({os.path.relpath(path, ROOT)}, HEAD {d.get('git_head', 'unrecorded')}) was made on another build: "
+                   + ", ".join(f"{k} {d.get(k, 'unrecorded')} != {ident[k]}" for k in stale) + ": re-profile")
             best = None
             continue
         best, why = (path, d), ""
@@ -243,25 +249,35 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
     import torch
     import torch.distributed as dist
     import airwave_amd as aw
-    from airwave_amd.sharding import aggregate_throughput, weak_shard
+    from airwave_amd import provenance as prov
+    from airwave_amd.sharding import aggregate_throughput, plan_streams
 
     wl = dict(WORKLOADS[name])
-    S = args.streams or wl["streams"]
+    scaling = getattr(args, "scaling", "weak")
+    rates = wl.get("rates", [48000])
+    # weak: `streams` per GPU; strong: the job total split over the ranks, every rate bucket evenly (sharding.plan_streams)
+    S_req = args.streams or (TOTAL_STREAMS[name] if scaling == "strong" else wl["streams"])
+    global_ids, stream_rates = plan_streams(S_req, rates, world, rank, scaling)
+    S = len(global_ids)
+    streams_total = S_req if scaling == "strong" else S_req * world
+    if S == 0:
+        raise SystemExit(f"bench.py: rank {rank} of {world} owns no stream of {name} ({S_req} streams, strong scaling)")
     C = wl["channels"]
     seconds = args.seconds or wl["seconds"]
     steps = args.steps if args.steps is not None else wl["steps"]
     warmup = args.warmup if args.warmup is not None else wl["warmup"]
-    rates = wl.get("rates", [48000])
     n_lanes = max(1, min(args.lanes if args.lanes else wl.get("lanes", 1), S))
     tracks, hrir_src = load_hrir(wl["hrir"], wl["taps"])
 
     layout = aw.InputLayout.detect(C) if C != 7 else aw.InputLayout(SPEAKERS7, "7 speakers")
-    first_stream, _ = weak_shard(S, world, rank)                                  # stream ids are global
+    # in + out bytes of this rank's batch must fit beside the scratch pool: refuse early instead of driving the box out of memory
+    need = sum((4 * C + 8) * int(round(seconds * r)) for r in stream_rates)
+    if need > 0.85 * torch.cuda.mem_get_info()[0]:
+        raise SystemExit(f"bench.py: {name} with {S} streams on this rank needs {need / 2**30:.0f} GiB of PCM in HBM; use more GPUs or --streams")
 
     # One leg per (lane, sample rate).  cfg 5 buckets streams by rate; a workload with `lanes` > 1 (cfg 4) runs its batch as that many
     # chunks of streams, each on a context — a HIP stream — of its own, so that one chunk's EQ kernel (FP64-vector bound) can execute
     # beside another chunk's split / merge kernels (fabric bound); every other workload is one lane on the bench's context.
-    stream_rates = [rates[i * len(rates) // S] for i in range(S)] if len(rates) > 1 else [rates[0]] * S
     cmap = None
     if wl.get("text_map"):            # the 14-channel reading of cfg 3: custom channels mapped by a HeSuVi-style text map
         cmap = aw.HRIRChannelMap.parseHeSuViFormat(open(os.path.join(ROOT, "tests", "golden", wl["text_map"])).read())
@@ -282,7 +298,7 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
             n, F = len(b.stream_ids), int(round(seconds * rate))
             x = torch.empty((n, F, C), dtype=torch.float32, device="cuda")
             y = torch.empty((n, F, 2), dtype=torch.float32, device="cuda")
-            lane_ctx[li].synth_fill(x.data_ptr(), n, F, C, seed=0xA17AE, first_stream=first_stream + lo + b.stream_ids[0])
+            lane_ctx[li].synth_fill(x.data_ptr(), n, F, C, seed=0xA17AE, first_stream=global_ids[lo + b.stream_ids[0]])       # (a bucket's ids are contiguous)
             t_act = time.perf_counter()
             b.spatializer.reserve(F)  # every internal buffer is sized here (and the long-window tables built): process never allocates
             torch.cuda.synchronize()
@@ -431,12 +447,12 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
             "warmup": warmup,
             "ms_per_step": elapsed_max / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32" if eq_def is None else "f32 (convolution) + f64 (EQ)",
             "data": f"synthetic U(-0.5,0.5) counter RNG seed 0xA17AE+stream, resident in HBM; HRIR: {hrir_src}",
             "config": {
-                "workload": wl["desc"], "name": name, "streams_per_gpu": S, "frames_per_stream": g0["F"], "sample_rate": g0["rate"],
+                "workload": wl["desc"], "name": name, "streams_per_gpu": S, "streams_total": streams_total, "streams_this_rank": S, "frames_per_stream": g0["F"], "sample_rate": g0["rate"],
                 "input_channels": C, "hrir_tracks": int(tracks.shape[0]), "hrir_taps": g0["taps"],
                 "convolutions_per_stream": int((lt >= 0).sum() + (rt >= 0).sum()),
                 "parallelism": f"streams sharded x{world}, no data-path collective" + (f"; {n_lanes} stream chunks per GPU on {n_lanes} HIP streams" if n_lanes > 1 else ""),
@@ -449,8 +465,9 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
                 "device_memory": {"used_by_workload_bytes": int(mem_free0 - mem_free1), "free_before_bytes": int(mem_free0), "total_bytes": int(mem_total)},
                 "activation": activation,
                 "activation_ms": [a["total_ms"] for a in activation],
-                "device_src_sha16": __import__("airwave_amd.provenance", fromlist=["x"]).device_source_digest(),
-                "build_head": __import__("airwave_amd.provenance", fromlist=["x"]).build_head(),
+                "device_src_sha16": prov.device_source_digest(), "host_src_sha16": prov.host_source_digest(),
+                "build_flags_sha16": prov.build_flags_digest(), "build_flags_env": prov.build_flags().get("env", {}),
+                "build_head": prov.build_head(),
             },
             "roofline": roof,
         }
@@ -573,21 +590,142 @@ def end_to_end(name: str, args, ctx, streams: int = 0, pcie: dict = None):
     return res
 
 
+# ---------------------------------------------------------------------------------------------- the stdout line
+LINE_LIMIT = 8000          # bytes: the driver keeps an 8 KB tail of stdout; a line that does not fit in it whole is a line nobody parsed (round 5)
+DETAIL_FILE = "bench_detail.json"
+
+
+def _r(v, nd=6):
+    """Numbers on the line carry what a reader compares, not 17 digits."""
+    if isinstance(v, float):
+        return float(f"{v:.{nd}g}")
+    return v
+
+
+def _pick(d: dict, keys, nd=6) -> dict:
+    return {k: _r(d[k], nd) for k in keys if k in d and d[k] is not None}
+
+
+def compact_roofline(r: dict, full: bool) -> dict:
+    keys = ["bound", "achieved", "peak", "unit", "frac", "step_ms", "kernel", "kernel_avg_ms", "kernel_frac", "dominant_kernel_share"]
+    out = _pick(r, keys)
+    out["traffic"] = r.get("traffic")              # bytes per step (PMC, committed profile of these sources) or null — the key is always there
+    if r.get("traffic") is not None and r.get("algorithmic_bytes_per_step"):
+        out["traffic_over_algorithmic"] = _r(r["traffic"] / r["algorithmic_bytes_per_step"], 4)
+    if full:
+        out.update(_pick(r, ["algorithmic_bytes_per_step", "bytes_per_frame", "frames_per_step", "launches_timed", "traffic_source",
+                             "frac_of_measured", "frac_of_measured_mix", "eq_kernel_ms_per_step"]))
+        if r.get("traffic") is None and r.get("traffic_note"):
+            out["traffic_note"] = r["traffic_note"][:200]
+        out["stages_ms_per_step"] = r.get("stages_ms_per_step", {})
+        if "measured" in r:
+            out["measured"] = _pick(r["measured"], ["read", "write", "copy", "mix", "unit"], 5)
+    else:
+        out.update(_pick(r, ["frac_of_measured_mix"]))
+    return out
+
+
+def compact_config(c: dict, full: bool) -> dict:
+    keys = ["workload", "name", "streams_per_gpu", "frames_per_stream", "sample_rate", "input_channels", "hrir_tracks", "hrir_taps",
+            "convolutions_per_stream", "parallelism", "fft", "hop", "path"]
+    if full:
+        keys += ["streams_total", "streams_this_rank", "lanes", "outputs_finite", "activation_ms", "device_src_sha16", "host_src_sha16", "build_flags_sha16", "build_head"]
+    out = _pick(c, keys)
+    if not full:
+        out["workload"] = out["workload"][:120]
+    if len(c.get("legs", [])) > 1:
+        out["legs"] = [_pick(l, ["rate", "streams", "frames", "taps", "fft", "hop", "partitions"]) for l in c["legs"]]
+    return out
+
+
+def compact_secondary(r: dict) -> dict:
+    out = _pick(r, ["value", "unit", "steps", "warmup", "ms_per_step", "parity_spot_err", "note"])
+    out["config"] = compact_config(r["config"], full=False)
+    out["roofline"] = compact_roofline(r["roofline"], full=False)
+    if "fp32_roof" in r:
+        out["fp32_frac"] = _r(r["fp32_roof"]["frac"], 4)
+    return out
+
+
+def compact_line(result: dict) -> dict:
+    """The ONE stdout line: the contract keys, `roofline`, `cpu_baseline`, the parity spot check and a few numbers per secondary.
+    Everything else this run measured (per-kernel PMC counters, activation breakdown, PCIe detail, scopes and notes) is in
+    bench_detail.json next to bench.py.  tests/test_bench_line.py holds the length bound on a canned worst case."""
+    head = ["metric", "value", "unit", "n_gpus", "ranks_seen", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"]
+    line = _pick(result, head, 9)
+    line["vs_baseline"] = result.get("vs_baseline")          # null is part of the contract
+    line["config"] = compact_config(result["config"], full=True)
+    line["roofline"] = compact_roofline(result["roofline"], full=True)
+    if "fp32_roof" in result:
+        line["fp32_roof"] = _pick(result["fp32_roof"], ["achieved", "peak", "unit", "frac", "intensity_flop_per_byte", "ridge_flop_per_byte"], 5)
+    if "cpu_baseline" in result:
+        line["cpu_baseline"] = _pick(result["cpu_baseline"], ["value", "unit", "cores", "kind", "single_thread_value", "sample", "seconds"])
+    if "parity_spot_err" in result:
+        line["parity_spot_err"] = _r(result["parity_spot_err"], 4)
+        line["parity_tolerance"] = 1e-5
+    for k in ("secondary", "secondary_cfg2"):
+        if k in result:
+            line[k] = compact_secondary(result[k])
+    if "secondary_end_to_end" in result:
+        line["secondary_end_to_end"] = [dict(_pick(e, ["name", "streams", "value", "ms_per_batch", "h2d_GBs", "d2h_GBs", "frac_of_pcie", "parity_spot_err"]),
+                                             pinned=True, pageable_value=_r(e["pageable"]["value"]), unit="stereo frames/s, host buffers in and out (PCIe inclusive)")
+                                        for e in result["secondary_end_to_end"]]
+    line["detail"] = DETAIL_FILE
+    return line
+
+
+def emit(result: dict) -> str:
+    """Writes the full result to bench_detail.json (next to bench.py, and under gpurun_out/ when that exists) and returns the compact
+    stdout line.  A line over LINE_LIMIT is a bug: secondaries are dropped from it (they stay in the detail file) rather than printed."""
+    full = json.dumps(result, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, DETAIL_FILE), "w") as f:
+                    f.write(full + "\n")
+            except OSError:
+                pass
+    line = compact_line(result)
+    text = json.dumps(line, separators=(", ", ": "))
+    for k in ("secondary_end_to_end", "secondary_cfg2", "secondary"):
+        if len(text) < LINE_LIMIT:
+            break
+        if line.pop(k, None) is not None:
+            line["dropped_for_length"] = line.get("dropped_for_length", []) + [k]
+        text = json.dumps(line, separators=(", ", ": "))
+    return text
+
+
 # ---------------------------------------------------------------------------------------------- main
 def dry_run(args, world: int, rank: int) -> None:
     """GPU-less rehearsal of the launch / rendezvous / aggregate path (tests/test_multi_rank.py): every rank "processes"
     its shard for a fixed time.  The line it prints says so and carries no measurement."""
+    import torch
     import torch.distributed as dist
-    from airwave_amd.sharding import aggregate_throughput, weak_shard
+    from airwave_amd.sharding import aggregate_throughput, plan_streams
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    first, count = weak_shard(args.streams or 4, world, rank)
+    wl = WORKLOADS[args.workload]
+    rates = wl.get("rates", [48000])
+    S_req = args.streams or (TOTAL_STREAMS[args.workload] if args.scaling == "strong" else 4)
+    ids, stream_rates = plan_streams(S_req, rates, world, rank, args.scaling)
     if world > 1:
         dist.barrier()
-    frames, elapsed, _ = aggregate_throughput(float(count * 1000), 0.25, device="cpu")
+    frames, elapsed, _ = aggregate_throughput(float(len(ids) * 1000), 0.25, device="cpu")
+    # every rank's shard, gathered for the line (tests/test_multi_rank.py asserts the split): counts, first / last global id, id checksum
+    mine = torch.tensor([len(ids), ids[0] if ids else -1, ids[-1] if ids else -1, sum(ids)] + [stream_rates.count(r) for r in rates], dtype=torch.int64)
+    shards = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(shards, mine)
+    else:
+        shards = [mine]
     if rank == 0:
         print(json.dumps({"metric": "DRY RUN (no GPU work, no measurement)", "dry_run": True, "value": 0.0, "unit": "stereo frames/s",
                           "n_gpus": world, "ranks_seen": dist.get_world_size() if world > 1 else 1, "frames_all_ranks": frames,
+                          "scaling": args.scaling, "streams_total": S_req if args.scaling == "strong" else S_req * world,
+                          "streams_by_rank": [int(t[0]) for t in shards], "first_id_by_rank": [int(t[1]) for t in shards],
+                          "last_id_by_rank": [int(t[2]) for t in shards], "id_sum": int(sum(int(t[3]) for t in shards)),
+                          "streams_by_rank_and_rate": [[int(v) for v in t[4:]] for t in shards], "rates": rates,
                           "self_launched": os.environ.get("AW_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -599,7 +737,9 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=None, help="default per workload (cfg3: 10)")
     ap.add_argument("--warmup", type=int, default=None, help="default per workload (cfg3: 2)")
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
+    ap.add_argument("--streams", type=int, default=0, help="override streams per GPU (weak) or the job total (strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): per-GPU batch fixed as N grows; strong: BASELINE's job-total stream counts (cfg3 1024 / cfg4 4096 / cfg5 8192) split over the ranks")
     ap.add_argument("--seconds", type=float, default=0.0, help="override seconds per stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second reading of the workload (cfg3: the 14-channel-input run)")
@@ -688,7 +828,7 @@ def main() -> int:
         result["secondary_end_to_end"] = [end_to_end(n, args, ctx, streams=k, pcie=pcie) for n, k in e2e_of[args.workload]]
     rc = 0
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        print(emit(result), flush=True)
         errs = [e for e in [result.get("parity_spot_err"), result.get("secondary", {}).get("parity_spot_err"), result.get("secondary_cfg2", {}).get("parity_spot_err")]
                 + [r.get("parity_spot_err") for r in result.get("secondary_end_to_end", [])] if e is not None]
         if any(not (e < 1e-5) for e in errs):

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from airwave_amd.sharding import aggregate_throughput, shard_streams, weak_shard
+from airwave_amd.sharding import aggregate_throughput, plan_streams, shard_streams, weak_shard
 
 
 def test_shard_partition_is_exact():
@@ -93,3 +93,48 @@ def test_bench_refuses_a_world_that_disagrees_with_gpus():
     assert rc == 2 and line is None and "disagrees" in err
     rc, line, err = _bench("--gpus", "1", "--dry-run")
     assert rc == 0 and line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["self_launched"] is False
+
+
+def test_strong_scaling_plan_partitions_every_rate_bucket():
+    """--scaling strong: BASELINE's job totals split over the ranks, bucketed by rate first; the union over ranks is the whole batch
+    exactly once and every rank gets its share of every rate (counts differ by at most one per bucket, by at most one in total)."""
+    for total in [0, 1, 5, 10, 1024, 4096, 8192]:
+        for rates in ([48000], [44100, 48000, 96000]):
+            whole_ids, whole_rates = plan_streams(total, rates, 1, 0, "strong")
+            assert whole_ids == list(range(total)) and sorted(whole_rates) == whole_rates
+            for world in [1, 2, 3, 8]:
+                plans = [plan_streams(total, rates, world, r, "strong") for r in range(world)]
+                ids = sorted(i for p in plans for i in p[0])
+                assert ids == list(range(total)), (total, rates, world)
+                for p in plans:
+                    assert all(whole_rates[i] == r for i, r in zip(*p))              # a stream keeps its rate whatever the world size
+                    for r in rates:
+                        mine = [i for i, rr in zip(*p) if rr == r]
+                        assert mine == list(range(mine[0], mine[0] + len(mine))) if mine else True   # contiguous inside a bucket
+                for r in rates:
+                    per = [p[1].count(r) for p in plans]
+                    assert max(per) - min(per) <= 1
+                if total >= world * len(rates):
+                    tot = [len(p[0]) for p in plans]
+                    assert max(tot) - min(tot) <= 1, (total, rates, world, tot)
+    # weak: the per-GPU count, rank-major global ids
+    assert plan_streams(4, [44100, 48000, 96000], 2, 1, "weak") == ([4, 5, 6, 7], [44100, 44100, 48000, 96000])
+    with pytest.raises(ValueError):
+        plan_streams(4, [48000], 2, 0, "medium")
+
+
+def test_bench_strong_scaling_dry_run_splits_the_baseline_totals():
+    """`bench.py --gpus 2 --scaling strong --workload cfg5 --dry-run`: 8192 streams in three rate buckets over two ranks (uneven: 2731 /
+    2731 / 2730), aggregated exactly; cfg 4: 4096 over two ranks; the line says which scaling it is."""
+    rc, line, err = _bench("--gpus", "2", "--dry-run", "--scaling", "strong", "--workload", "cfg5")
+    assert rc == 0, err
+    assert line["scaling"] == "strong" and line["streams_total"] == 8192 and sum(line["streams_by_rank"]) == 8192
+    assert line["streams_by_rank"] == [4096, 4096] and line["id_sum"] == 8191 * 8192 // 2
+    assert [sum(c) for c in zip(*line["streams_by_rank_and_rate"])] == [2731, 2731, 2730]
+    assert line["frames_all_ranks"] == 8192 * 1000
+    rc, line, err = _bench("--gpus", "2", "--dry-run", "--scaling", "strong", "--workload", "cfg4")
+    assert rc == 0 and line["streams_by_rank"] == [2048, 2048] and line["rates"] == [96000]
+    rc, line, err = _bench("--gpus", "2", "--dry-run", "--scaling", "strong", "--workload", "cfg3", "--streams", "7")
+    assert rc == 0 and line["streams_by_rank"] == [4, 3] and line["first_id_by_rank"] == [0, 4] and line["frames_all_ranks"] == 7000
+    rc, line, err = _bench("--gpus", "2", "--dry-run", "--workload", "cfg3")          # weak stays the default
+    assert rc == 0 and line["scaling"] == "weak" and line["streams_by_rank"] == [4, 4]

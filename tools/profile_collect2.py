@@ -4,7 +4,7 @@ bench_<w>.json (the bench line), kernel_stats_<w>.csv (rocprofv3 --stats), traff
 per step from the TCC_EA0 request counters + SQ counters; bench.py reads it for roofline.traffic)."""
 import collections, csv, glob, json, os, shutil, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from airwave_amd.provenance import build_head, device_source_digest
+from airwave_amd.provenance import build_flags_digest, build_head, device_source_digest, host_source_digest
 name, w = sys.argv[1], sys.argv[2]
 src = f"gpurun_out/profile_{name}/{w}"
 dst = os.path.join("profiles", name)
@@ -12,6 +12,8 @@ os.makedirs(dst, exist_ok=True)
 bench = [l for l in open(f"{src}/bench.json") if l.startswith("{")]
 line = json.loads(bench[-1])
 json.dump(line, open(os.path.join(dst, f"bench_{w}.json"), "w"), indent=1)
+if os.path.exists(f"{src}/bench_detail.json"):        # round 6: the stdout line is compact, the full result sits beside it
+    shutil.copy(f"{src}/bench_detail.json", os.path.join(dst, f"bench_detail_{w}.json"))
 for f in glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True):
     shutil.copy(f, os.path.join(dst, f"kernel_stats_{w}.csv"))
 pmc = collections.defaultdict(list)                # (kernel, counter) -> per-dispatch values
@@ -36,7 +38,7 @@ for k in kernels:
     by_kernel[k] = {"read_bytes_per_step": rd, "write_bytes_per_step": wr, "launches_per_step": len(pmc.get((k, "TCC_EA0_RDREQ_sum"), [])) / steps, "sq_per_step": sq}
     tot_r += rd; tot_w += wr
 cfg = line["config"]
-out = {"workload": w, "device_src_sha16": device_source_digest(), "git_head": build_head(), "streams_per_gpu": cfg["streams_per_gpu"], "frames_per_stream": cfg["frames_per_stream"], "input_channels": cfg["input_channels"],
+out = {"workload": w, "device_src_sha16": device_source_digest(), "host_src_sha16": host_source_digest(), "build_flags_sha16": build_flags_digest(), "git_head": build_head(), "streams_per_gpu": cfg["streams_per_gpu"], "frames_per_stream": cfg["frames_per_stream"], "input_channels": cfg["input_channels"],
        "total_bytes_per_step": tot_r + tot_w, "read_bytes_per_step": tot_r, "write_bytes_per_step": tot_w,
        "algorithmic_bytes_per_step": line["roofline"]["algorithmic_bytes_per_step"],
        "ratio_to_algorithmic": (tot_r + tot_w) / line["roofline"]["algorithmic_bytes_per_step"],
