@@ -387,7 +387,9 @@ class Spatializer:
                 "reserve_tables_ms": g(10) / 1e3, "reserve_upload_ms": g(11) / 1e3, "reserve_scratch_ms": g(12) / 1e3,
                 "device_allocs": g(13),         # device / page-locked allocations made so far on behalf of the context's handles
                 "sync_copies": g(14),           # blocking table uploads likewise
-                "host_chunk_streams": g(15)}    # streams per staged chunk of the last host-entry call (0: one piece)
+                "host_chunk_streams": g(15),    # streams per staged chunk of the last host-entry call (0: one piece)
+                "overlap_add_rows": g(16),      # the last call ran the overlap-add tile on blocks of 512 x this many frames (0: it did not)
+                "overlap_add_rows_policy": g(17)}   # ... which this spatializer's calls do when they have enough blocks (0: never)
 
     def process_device(self, in_ptr: int, out_ptr: int, frames: int) -> None:
         _check(self._lib.aw_spatializer_process(self._h, ctypes.c_void_p(in_ptr), ctypes.c_void_p(out_ptr), frames))

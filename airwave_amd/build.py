@@ -27,6 +27,12 @@ SOURCES = [
     "device/lw_split_d.hip",
     "device/lw_split_e.hip",
     "device/ols2_even_kernels.hip",
+    "device/ola_kernels.hip",
+    "device/ola_kernels_a.hip",
+    "device/ola_kernels_b.hip",
+    "device/ola_kernels_c.hip",
+    "device/ola_kernels_d.hip",
+    "device/ola_kernels_e.hip",
     "device/eq_kernels.hip",
     "device/probe_kernels.hip",
     "device/prep_kernels.hip",
@@ -46,6 +52,9 @@ EXTRA_FLAGS = {"device/march_kernels.hip": [] if os.environ.get("AW_MARCH_SLP") 
                "device/lw_kernels.hip": ["-fno-slp-vectorize", "-DAW_XA_REG=1", "-DAW_LDS_ATOMIC_READS=1"],
                "device/lw_split_a.hip": ["-fno-slp-vectorize"], "device/lw_split_b.hip": ["-fno-slp-vectorize"], "device/lw_split_c.hip": ["-fno-slp-vectorize"],
                "device/lw_split_d.hip": ["-fno-slp-vectorize"], "device/lw_split_e.hip": ["-fno-slp-vectorize"],
+               # the overlap-add tile kernels: the same tile code, the same reason
+               "device/ola_kernels.hip": ["-fno-slp-vectorize"], "device/ola_kernels_a.hip": ["-fno-slp-vectorize"], "device/ola_kernels_b.hip": ["-fno-slp-vectorize"],
+               "device/ola_kernels_c.hip": ["-fno-slp-vectorize"], "device/ola_kernels_d.hip": ["-fno-slp-vectorize"], "device/ola_kernels_e.hip": ["-fno-slp-vectorize"],
                "device/kernels.hip": [] if os.environ.get("AW_KERNELS_SLP") else ["-fno-slp-vectorize"],
                # the even 16384-frame layouts kept SLP through round 3 (their 8 x 8 x 8 form measured faster with it); on the half-wave row
                # transform they do not: 4 / 6 / 8 channels 66.8 / 46.5 / 33.4 -> 68.8 / 52.9 / 35.4 G frames/s (tools/ols2_ab.py)

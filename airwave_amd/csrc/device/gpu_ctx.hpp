@@ -226,6 +226,26 @@ struct GpuCtx {
         asm volatile("" : "+v"(v.x), "+v"(v.y));
         return v;
     }
+    // Buffer loads (tile_ola.hpp): a descriptor carries its byte size and the hardware returns zeros for every dword at or past it — the
+    // ragged end of a stream, and the rows before a history window, cost no compare, no select and no zero page.  Raw buffer
+    // (stride 0), 32-bit data format; `off` = per-lane byte offset (offen), `imm` = compile-time byte offset of the instruction.
+    typedef __amdgpu_buffer_rsrc_t Buf;
+    __device__ __forceinline__ Buf buf(const void *base, unsigned bytes) const {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+    }
+    template <int N> __device__ __forceinline__ void buf_ld(const Buf &b, unsigned off, int imm, float *dst) const {
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        if constexpr (N == 4) {
+            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(b, (int)(off + (unsigned)imm), 0, 0);
+            dst[0] = __uint_as_float(v.x); dst[1] = __uint_as_float(v.y); dst[2] = __uint_as_float(v.z); dst[3] = __uint_as_float(v.w);
+        } else if constexpr (N == 2) {
+            const v2u v = __builtin_amdgcn_raw_buffer_load_b64(b, (int)(off + (unsigned)imm), 0, 0);
+            dst[0] = __uint_as_float(v.x); dst[1] = __uint_as_float(v.y);
+        } else {
+            dst[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b, (int)(off + (unsigned)imm), 0, 0));
+        }
+    }
     // Exchanges inside one wave need no s_barrier: a wave's LDS instructions execute in issue
     // order.  The fences only stop the compiler from moving LDS accesses across the exchange.
     __device__ __forceinline__ void wave_sync() const {

@@ -5,6 +5,7 @@
 #include <cstdint>
 
 #include "tile_ols2.hpp"
+#include "tile_ola.hpp"
 #include "tile_march.hpp"
 #include "tile_lw.hpp"
 #include "tile_lw16.hpp"
@@ -29,6 +30,13 @@ const char *fused_ols_kernel_name(int n_channels);
 hipError_t launch_fused_ols2(const TileParams &p, int n_streams, hipStream_t stream, hipEvent_t ev0 = nullptr,
                              hipEvent_t ev1 = nullptr, long long *dominant_tiles = nullptr);
 const char *fused_ols2_kernel_name(int n_channels);
+
+// Overlap-add form of the fused tile (tile_ola.hpp, ola_kernels*.hip): blocks of 512 H frames, the carry in registers, ONE launch for the whole
+// call.  fused_ola_rows(): H for a layout and HRIR length, 0 when the library carries no such kernel.
+int fused_ola_rows(int n_channels, int taps);
+hipError_t prepare_ola_kernels();
+hipError_t launch_fused_ola(const TileParams &p, int H, int n_streams, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+const char *fused_ola_kernel_name(int n_channels, int H);
 
 // Partitioned (long-HRIR) path: window spectra -> scratch; per-bin CMAC over partitions for groups of
 // consecutive blocks -> W scratch; inverse transform of every block's W.
@@ -79,6 +87,7 @@ struct LaunchCfg {
     int lw_rows16_wgs = 3;        // workgroups per CU of the 16-point rows kernel's persistent grid (AW_LW_ROWS16_WGS)
     int hop_align = 64;           // fused windows start on multiples of this many frames (AW_HOP_ALIGN; 1 = off)
     int lw_tables_on_gpu = 1;     // long-window filter tables built by the prep kernels (prep_kernels.hip); 0 = the float64 host builder (AW_LW_TABLES=host)
+    int ola_min_blocks_per_wg = -1; // overlap-add tile: calls with fewer blocks per persistent workgroup run the overlap-save tile (AW_OLA_MIN_BLOCKS; -1 = per layout, runtime.cpp ola_min_blocks(); 0 = always the overlap-add tile)
     int host_chunk_mb = 96;       // host entry of a multi-stream batch: input megabytes per staged chunk of streams (AW_HOST_CHUNK_MB; a few ms of PCIe Gen5 = the pipeline's fill / drain)
 };
 hipError_t prepare_kernels(LaunchCfg *cfg);   // fills cfg from the current device + environment; sets the dynamic-LDS attribute on every tile kernel

@@ -171,6 +171,7 @@ static aw_status context_create_impl(int32_t device, void *ext_stream, bool use_
     hipError_t e = hipEventCreate(&c->t0);
     if (e == hipSuccess) e = hipEventCreate(&c->t1);
     if (e == hipSuccess) e = awk::prepare_kernels(&c->cfg);
+    if (e == hipSuccess) e = awk::prepare_ola_kernels();
     if (e == hipSuccess) e = awk::prepare_lw_kernels();
     if (e == hipSuccess) e = awk::prepare_eq_kernels();
     if (e == hipSuccess) e = awk::prepare_prep_kernels();
@@ -394,6 +395,50 @@ static aw_status sp_alloc_hist(aw_spatializer *sp) {
 
 // Tiles start on 64-frame boundaries of the timeline: a shorter hop costs < 2 % more tiles and makes every tile's
 // loads and stores start line-aligned (measured cfg 2: 1.555 -> 1.530 ms per call).  AW_HOP_ALIGN (read at aw_context_create) overrides (1 = off).
+// Overlap-add tile or overlap-save tile for a path-0 spatializer?  Returns the block rows H (0: overlap-save).  `hist_len` = rows of the
+// history buffer the spatializer will keep (N - the aligned overlap-save hop >= taps - 1): the block's tail must fit behind its hop.
+// The overlap-add block is cheaper per transform (whole frames in registers, every input line read once, no boundary launch) but
+// shorter than the overlap-save hop (512 H against 8193 - taps rounded down to 64), so it wins from a layout-specific ratio of the two
+// on — measured, profiles/round6_v1/ola_sweep.txt (128 streams x 10 s, G frames/s overlap-save / overlap-add / long-window):
+//   4 ch   3585 taps 92.2 / 87.3, 3969: 86.3 / 86.6, 4320: 79.5 / 79.5, 4609: 74.6 / 79.2            -> from hop_ola >= 0.94 hop_ols
+//   6 ch   3585: 64.7 / 64.4, 3969: 60.9 / 65.2, 4098: 58.4 / 58.0, 4320: 56.5 / 57.8                 -> 0.90
+//   7 ch   3000: 58.7 / 54.5, 3585: 53.3 / 54.2, 4320: 46.0 / 48.8, 4609: 42.9 (16384-frame tile) / 48.7   -> 0.875
+//   8 ch   3585: 53.5 / 53.4, 3969: 49.4 / 53.3, 4320: 46.7 / 47.7, 5121: 34.6 / 41.7 / 39.0          -> 0.89
+//   10 ch  2048: 45.6 / 42.7, 3000: 40.7 / 42.7, 4320: 32.4 / 38.7 / 30.0                             -> 0.74
+//   12 ch  3000: 36.7 / 36.4, 3585: 34.1 / 36.2, 4320: 29.8 / 32.9 / 25.7                             -> 0.80
+//   14 ch  3000: 29.7 / 27.5, 3585: 27.5 / 27.6, 4320: 23.5 / 27.7 / 23.8, 5121: 20.1 / 25.4 / 23.7   -> 0.89
+//   16 ch  2048: 24.1 / 24.5, 4320: 17.6 / 22.7 / 20.6, 5121: 14.9 / 21.3 / 20.4                      -> 0.66
+// (tools/ola_sweep.py regenerates the table).  AW_OLA=0 never, AW_OLA=1 wherever a kernel exists.
+static int ola_policy(int n_channels, int taps, int hist_len) {
+    int mode = -1;
+    if (const char *e = getenv("AW_OLA")) mode = atoi(e);
+    if (mode == 0) return 0;
+    int H = awk::fused_ola_rows(n_channels, taps);
+    while (H >= 6 && hist_len > awk::kN - 512 * H) --H;          // (the aligned history may be a few rows longer than taps - 1)
+    if (H < 6) return 0;
+    if (mode > 0) return H;
+    const int hop_ols = awk::kN - hist_len;
+    double need;
+    switch (n_channels) {
+        case 4: need = 0.94; break;
+        case 6: need = 0.90; break;
+        case 7: need = 0.875; break;
+        case 8: need = 0.89; break;
+        case 10: need = 0.74; break;
+        case 12: need = 0.80; break;
+        case 14: need = 0.89; break;
+        default: need = 0.66; break;      // 16 channels
+    }
+    return 512.0 * H >= need * hop_ols ? H : 0;
+}
+// Blocks per persistent workgroup from which a call runs the overlap-add tile: every run pays ceil(hist / hop) <= 2 warm-up blocks, which
+// must stay below what the tile gains over the overlap-save tile — 2 - 10 % for layouts of up to eight channels, 10 - 40 % for wider ones.
+static int ola_min_blocks(const aw_spatializer *sp) {
+    const int forced = sp->ctx->cfg.ola_min_blocks_per_wg;       // AW_OLA_MIN_BLOCKS (read at context creation); < 0: per layout
+    if (forced >= 0) return forced;
+    return sp->n_channels <= 8 ? 48 : 16;
+}
+
 static int align_hop(const aw_context *ctx, int hop) {
     const int al = ctx->cfg.hop_align;          // read once at aw_context_create (LaunchCfg), like every other knob
     return (al > 1 && hop > 16 * al) ? hop - hop % al : hop;
@@ -447,6 +492,15 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
     //     (11 000: 17.4 / 17.2; 11 800: 15.5 / 17.3).
     const int upto = (n_in <= 3 || n_in == 5 || n_in == 6) ? 12289 : n_in == 4 ? 10500 : n_in == 8 ? 11200 : n_in == 7 ? 11500 : 0;
     const bool fused2_ok = fits2 && hrir->taps <= upto;
+    // (0) Round 6: the overlap-add form of the 8192-frame tile (device/tile_ola.hpp) where the library carries a kernel for the layout and
+    //     the HRIR length (blocks of 512 H frames, H = 5 .. 8: 3585 .. 5633 taps and shorter ones on H = 8).  It reads every input line
+    //     once and holds whole frames of every layout, so it is measured against BOTH overlap-save windows (ola_policy()); the choice is
+    //     per call: calls with too few blocks per workgroup to amortise a run's warm-up blocks stay on the overlap-save tile.
+    //     AW_OLA=0 never, AW_OLA=1 wherever a kernel exists.
+    const int ola_h = (window == 0 || window == N) ? ola_policy(n_in, hrir->taps, N - align_hop(ctx, N - (hrir->taps - 1))) : 0;
+    // batches of fewer than 48 streams keep the window policy below: their calls rarely have the blocks per workgroup the overlap-add tile
+    // needs (ola_min_blocks), and then run the overlap-save tile of the window chosen here
+    if (ola_h && window == 0 && n_streams >= 48) window = N;
     if (window == 0) {
         // (2) 8192- against 16384-frame windows where both can hold the HRIR (8192 / 16384): mono always 16384 (4320 taps 93 / 202),
         //     stereo from ~2000 taps (2048: 157 / 160; 4320: 105 / 143), 3 channels from ~1800 (1024: 120 / 113; 2048: 107 / 111;
@@ -485,6 +539,7 @@ aw_status aw_spatializer_create(aw_context *ctx, const aw_hrir *hrir, int32_t n_
         sp->hop = align_hop(ctx, N - (hrir->taps - 1));
         sp->hist_len = N - sp->hop;
         sp->partitions = 1;
+        sp->ola_h = ola_h;
     } else {
         sp->path = 1;
         sp->hop = N / 2;
@@ -617,6 +672,8 @@ int64_t aw_spatializer_info(const aw_spatializer *sp, int32_t what) {
         case 13: return sp->ctx->device_allocs;   // device / pinned allocations made so far on behalf of this context's handles
         case 14: return sp->ctx->sync_copies;     // blocking host-to-device table uploads likewise
         case 15: return sp->host_chunk_streams;   // streams per staged chunk of the host entry (0: the whole batch in one piece)
+        case 16: return sp->last_ola_h;           // rows H of the overlap-add blocks (512 H frames) the last call ran on; 0: it ran another tile
+        case 17: return sp->ola_h;                // rows H this spatializer's long-enough calls use (0: the overlap-add tile is not used)
         default: return -1;
     }
 }
@@ -696,7 +753,7 @@ int32_t aw_spatializer_kernel_time(aw_spatializer *sp, double *avg_ms, const cha
     }
     sp->pending.clear();
     if (avg_ms) *avg_ms = sp->kernel_launches ? sp->kernel_ms_sum / sp->kernel_launches : 0.0;
-    if (kernel_name) *kernel_name = sp->last_lw_R ? "aw_lw_split_kernel + aw_lw_rows_kernel + aw_lw_merge_kernel" : sp->path == 0 ? (sp->fused2 ? awk::fused_ols2_kernel_name(sp->n_channels) : awk::fused_ols_kernel_name(sp->n_channels)) : (sp->cmac_group ? "aw_part_forward_kernel + aw_part_cmac_kernel + aw_part_inverse_kernel" : "aw_part_forward_kernel + aw_part_march_kernel + aw_part_inverse_kernel");
+    if (kernel_name) *kernel_name = sp->last_lw_R ? "aw_lw_split_kernel + aw_lw_rows_kernel + aw_lw_merge_kernel" : sp->path == 0 ? (sp->fused2 ? awk::fused_ols2_kernel_name(sp->n_channels) : sp->last_ola_h ? awk::fused_ola_kernel_name(sp->n_channels, sp->last_ola_h) : awk::fused_ols_kernel_name(sp->n_channels)) : (sp->cmac_group ? "aw_part_forward_kernel + aw_part_cmac_kernel + aw_part_inverse_kernel" : "aw_part_forward_kernel + aw_part_march_kernel + aw_part_inverse_kernel");
     const int n = sp->kernel_launches;
     sp->kernel_ms_sum = 0.0;
     sp->kernel_launches = 0;
@@ -758,6 +815,26 @@ static aw_status sp_process_fused(aw_spatializer *sp, int s_base, int ns_total, 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (sp->profiling) { e0 = sp_get_event(sp); e1 = sp_get_event(sp); }
     long long dom_tiles = 0;
+    sp->last_ola_h = 0;
+    if (sp->ola_h && !sp->fused2) {
+        // Overlap-add tile: every workgroup walks ONE contiguous run of blocks and pays ceil(hist / hop) warm-up blocks per run and per
+        // stream start; a call needs ola_min_blocks() blocks per workgroup for that to stay a few per cent (cfg 2: 67).  Shorter
+        // calls, and streams too long for 32-bit byte offsets, run the overlap-save tile on the same tables and history.
+        const int hop_ola = 512 * sp->ola_h;
+        // (the CALL's block count — every stream of the spatializer — not this chunk's: the staged chunks of a host-entry call run the
+        // very tile the device entry runs on the whole batch, so both entries give the same bits)
+        const long long blocks = (long long)sp->n_streams * ((frames + hop_ola - 1) / hop_ola);
+        const long long wgs = std::max(1, sp->ctx->cfg.persistent_wgs);
+        if (blocks >= (long long)ola_min_blocks(sp) * wgs && frames * sp->n_channels * 4LL <= awk::kOlaMaxBytes) {
+            p.hop = hop_ola;
+            p.tiles_per_stream = (int)((frames + hop_ola - 1) / hop_ola);
+            AW_HIP_TRY(awk::launch_fused_ola(p, sp->ola_h, ns_total, sp->ctx->stream, e0, e1));
+            sp->last_ola_h = sp->ola_h;
+            sp->dominant_frames = (long long)ns_total * frames;              // one launch covers the whole call
+            if (sp->profiling) sp->pending.emplace_back(e0, e1);
+            return AW_OK;
+        }
+    }
     if (sp->fused2) AW_HIP_TRY(awk::launch_fused_ols2(p, ns_total, sp->ctx->stream, e0, e1, &dom_tiles));
     else AW_HIP_TRY(awk::launch_fused_ols(p, ns_total, sp->ctx->stream, e0, e1, &dom_tiles));
     // output frames the timed launch produced (tiles x hop, the last tile of a stream may be short)
@@ -875,7 +952,9 @@ static aw_status sp_process_partitioned(aw_spatializer *sp, int s_base, int ns_t
 //   C=5  6145: 52 / 49, 8640: 41 / 48;   C=6  4320: 47 / 43, 5300: 38 / 43;   C=7  4320: 40.6 / 39.9, 5300: 37 / 40;   C=8  4320: 40 / 36, 5300: 32 / 36;
 //   C=9  4320: 30.2 / 29.4, 6145: 19 / 29;   C=10, 12  4320: 29 / 27, 26 / 24;   C=14  3000: 25.8 / 22.3, 4320: 20.5 / 22.3;   C=16  3000: 20.1 / 19.7, 4320: 16.4 / 19.6
 // The long-window kernels' rate does not depend on the HRIR length; the fused tiles' hop shrinks with it.
-static int lw_fused_crossover_taps(int channels) {
+static int lw_fused_crossover_taps(int channels, int ola_h) {
+    if (ola_h) return 5122;      // Round 6, spatializers on the overlap-add tile (blocks of 8 / 7 / 6 rows up to 4097 / 4609 / 5121 taps): faster than the
+                                 // long-window kernels on every layout and length it is chosen for (ola_policy(); profiles/round6_v1/ola_sweep.txt)
     switch (channels) {          // profiles/round4_v2/policy_sweeps_final.txt and lw_sweep.txt (both fused kernels on the half-wave row transform)
         case 1: return 10800;
         case 2: return 9300;
@@ -905,7 +984,7 @@ static_assert(sizeof(kLwRowChoices) / sizeof(kLwRowChoices[0]) <= kLwPlanSlots, 
 static LwCallPlan lw_choose(const aw_spatializer *sp, int64_t frames, bool for_reserve = false) {
     LwCallPlan none{};
     if (sp->lw_mode == 0 || sp->n_channels > 16) return none;
-    if (sp->path == 0 && sp->lw_mode < 0 && sp->taps < lw_fused_crossover_taps(sp->n_channels)) return none;
+    if (sp->path == 0 && sp->lw_mode < 0 && sp->taps < lw_fused_crossover_taps(sp->n_channels, sp->ola_h)) return none;
     // calls inside what aw_spatializer_reserve() sized never build tables: only window lengths whose tables exist are candidates
     const bool existing_only = !for_reserve && frames <= sp->reserved_frames;
     auto have = [&](int R) { for (const auto &pl : sp->lw_plans) if (pl.R == R) return true; return false; };
@@ -984,17 +1063,26 @@ static aw_status lw_get_plan(aw_spatializer *sp, int R, const aw_spatializer::Lw
     pl.R = R;
     auto up = [&](const void *src, size_t bytes, void **d) -> hipError_t {
         hipError_t r = hipMalloc(d, bytes);
-        if (r != hipSuccess) return r;
+        if (r != hipSuccess) { *d = nullptr; return r; }
         sp->ctx->device_allocs += 1; sp->ctx->sync_copies += 1;
-        return hipMemcpy(*d, src, bytes, hipMemcpyHostToDevice);
+        r = hipMemcpy(*d, src, bytes, hipMemcpyHostToDevice);
+        if (r != hipSuccess) { (void)hipFree(*d); *d = nullptr; }        // a buffer that was never written is not left behind as if it had been
+        return r;
     };
     hipError_t e = hipSuccess;
     if (on_gpu) {
         const int n_pairs = (sp->n_channels + 1) / 2;
-        if (!sp->d_lw_tracks) {              // the impulse responses and the channel map, once per spatializer
+        if (!sp->d_lw_tracks || !sp->d_lw_left || !sp->d_lw_right) {     // the impulse responses and the channel map, once per spatializer
+            // all three or none: a failure part way (out of memory) frees what was uploaded, so that the next long call uploads again
+            // instead of handing the prep kernel a null or never-written channel map (round-5 advice)
+            for (void **d : {reinterpret_cast<void **>(&sp->d_lw_tracks), reinterpret_cast<void **>(&sp->d_lw_left), reinterpret_cast<void **>(&sp->d_lw_right)})
+                if (*d) { (void)hipFree(*d); *d = nullptr; }
             e = up(sp->lw_tracks.data(), sp->lw_tracks.size() * sizeof(float), reinterpret_cast<void **>(&sp->d_lw_tracks));
             if (e == hipSuccess) e = up(sp->lw_left.data(), sp->lw_left.size() * sizeof(int32_t), reinterpret_cast<void **>(&sp->d_lw_left));
             if (e == hipSuccess) e = up(sp->lw_right.data(), sp->lw_right.size() * sizeof(int32_t), reinterpret_cast<void **>(&sp->d_lw_right));
+            if (e != hipSuccess)
+                for (void **d : {reinterpret_cast<void **>(&sp->d_lw_tracks), reinterpret_cast<void **>(&sp->d_lw_left), reinterpret_cast<void **>(&sp->d_lw_right)})
+                    if (*d) { (void)hipFree(*d); *d = nullptr; }
         }
         void *d_tmp = nullptr;
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pl.d_tab16), (size_t)(R / 2) * n_pairs * 2 * awk::kLwM * sizeof(awk::LwTab2));

@@ -73,6 +73,8 @@ struct aw_spatializer {
     int n_channels = 0, n_pairs = 0, n_streams = 0, taps = 0;
     int path = 0;             // 0 fused single-partition overlap-save, 1 partitioned
     bool fused2 = false;      // path 0 on 16384-frame windows (polyphase, two output spectra): device/tile_ols2.hpp
+    int ola_h = 0;            // path 0 on 8192-frame windows: calls with enough blocks run the overlap-add tile with blocks of 512 ola_h frames (device/tile_ola.hpp); 0: never
+    int last_ola_h = 0;       // ola_h of the last call if it ran that tile, else 0
     int hop = 0, hist_len = 0, partitions = 1;
     awk::cf2 *d_tab = nullptr;          // [partitions][pairs][N]
     float *d_hist[2] = {nullptr, nullptr};

@@ -387,12 +387,15 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
             if lw:        # the long-window kernels ran (tile_lw.hpp): windows of lw x 4096 frames, hop = window - history
                 paths.append({"lane": g["lane"], "rate": g["rate"], "streams": g["n"], "frames": g["F"], "taps": g["taps"], "fft": lw * 4096, "hop": lw * 4096 - info["history"],
                               "partitions": 1, "path": "long-window overlap-save (four-step FFT: split / rows / merge)"})
+            elif info.get("overlap_add_rows", 0):      # the overlap-add tile ran (tile_ola.hpp): blocks of 512 H frames, one launch for the whole call
+                paths.append({"lane": g["lane"], "rate": g["rate"], "streams": g["n"], "frames": g["F"], "taps": g["taps"], "fft": info["fft"], "hop": 512 * info["overlap_add_rows"],
+                              "partitions": 1, "path": "fused overlap-add"})
             else:
                 paths.append({"lane": g["lane"], "rate": g["rate"], "streams": g["n"], "frames": g["F"], "taps": g["taps"], "fft": info["fft"], "hop": info["hop"],
                               "partitions": info["partitions"], "path": "fused overlap-save" if info["path"] == 0 else "partitioned"})
         finite = all(bool(torch.isfinite(g["y"][:, -4096:]).all().item()) for g in legs)
         g0 = legs[0]
-        multi_kernel = all(pp["path"] != "fused overlap-save" for pp in paths) and bool(stages)
+        multi_kernel = all(not pp["path"].startswith("fused") for pp in paths) and bool(stages)
         if multi_kernel:
             # multi-kernel pipeline: every stage's launches cover all frames of the step; the dominant kernel is the longest stage
             kname = max(stages, key=lambda k: stages[k]["ms_per_step"])

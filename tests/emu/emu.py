@@ -11,7 +11,7 @@ _DEFS = os.environ.get("AW_EMU_DEFINES", "").split()          # e.g. "-DAW_SUBFF
 _LIB = os.path.join(_HERE, "libemu.so" if not _DEFS else "libemu_variant.so")
 _SRCS = [os.path.join(_HERE, "emu_harness.cpp"), os.path.join(_HERE, "emu_lw.cpp"), os.path.join(_ROOT, "airwave_amd/csrc/host/tables.cpp"),
          os.path.join(_ROOT, "airwave_amd/csrc/host/eq.cpp")]
-_DEPS = _SRCS + [os.path.join(_HERE, "emu_ctx.hpp")] + [os.path.join(_ROOT, "airwave_amd/csrc/device", f) for f in ("tile_ols.hpp", "tile_ols2.hpp", "tile_march.hpp", "tile_lw.hpp", "tile_lw16.hpp", "cplx.hpp", "eq_cascade.hpp")] + [
+_DEPS = _SRCS + [os.path.join(_HERE, "emu_ctx.hpp")] + [os.path.join(_ROOT, "airwave_amd/csrc/device", f) for f in ("tile_ols.hpp", "tile_ola.hpp", "tile_ols2.hpp", "tile_march.hpp", "tile_lw.hpp", "tile_lw16.hpp", "cplx.hpp", "eq_cascade.hpp")] + [
     os.path.join(_ROOT, "airwave_amd/csrc/host/tables.hpp"), os.path.join(_ROOT, "airwave_amd/csrc/host/eq.hpp")]
 _lib = None
 
@@ -35,6 +35,8 @@ def lib():
         _lib = ctypes.CDLL(_LIB)
         _lib.emu_fused_ols.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
                                        ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        _lib.emu_fused_ola.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
+                                       ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _lib.emu_partitioned.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
                                          ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
         _lib.emu_longwin.argtypes = [fp, fp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip,
@@ -67,6 +69,28 @@ def fused_ols(x, tracks, left_track, right_track, hop=None, hist=None, variant=1
                              tr.ctypes.data_as(fp), tr.shape[0], tr.shape[1], C, lt.ctypes.data_as(ip),
                              rt.ctypes.data_as(ip), F, S, hop, variant)
     assert rc == 0
+    return out
+
+
+def fused_ola(x, tracks, left_track, right_track, H=None, hist=None, workgroups=3):
+    """The overlap-add tile (tile_ola.hpp): x [streams][frames][C] -> [streams][frames][2]; hist: [streams][hist_len][C] (hist_len >= taps - 1)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    S, F, C = x.shape
+    tr = np.ascontiguousarray(tracks, dtype=np.float32)
+    lt = np.ascontiguousarray(left_track, dtype=np.int32)
+    rt = np.ascontiguousarray(right_track, dtype=np.int32)
+    if H is None:
+        H = min(8, (8192 - (tr.shape[1] - 1)) // 512)
+    out = np.full((S, F, 2), np.nan, dtype=np.float32)
+    h = None
+    hist_len = tr.shape[1] - 1
+    if hist is not None:
+        h = np.ascontiguousarray(hist, dtype=np.float32)
+        hist_len = h.shape[1]
+        assert h.shape == (S, hist_len, C)
+    rc = lib().emu_fused_ola(x.ctypes.data_as(fp), out.ctypes.data_as(fp), None if h is None else h.ctypes.data_as(fp),
+                             tr.ctypes.data_as(fp), tr.shape[0], tr.shape[1], C, lt.ctypes.data_as(ip), rt.ctypes.data_as(ip), F, S, hist_len, H, workgroups)
+    assert rc == 0, rc
     return out
 
 

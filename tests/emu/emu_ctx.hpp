@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../airwave_amd/csrc/device/tile_ols.hpp"
+#include "../../airwave_amd/csrc/device/tile_ola.hpp"
 #include "../../airwave_amd/csrc/device/tile_march.hpp"
 #include "../../airwave_amd/csrc/device/tile_lw.hpp"
 #include "../../airwave_amd/csrc/device/tile_lw16.hpp"
@@ -69,6 +70,15 @@ struct EmuCtx {
     void st_stream(awk::cf *q, awk::cf v) const { *q = v; }
     awk::cf ld_stream(const awk::cf *q) const { return *q; }
     void st_stream4(float *q, float a, float b, float c, float d) const { q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
+    // buffer loads: every dword at or past the descriptor's size reads as zero (the hardware's range check)
+    struct Buf { const unsigned char *base; unsigned bytes; };
+    Buf buf(const void *base, unsigned bytes) const { return Buf{static_cast<const unsigned char *>(base), bytes}; }
+    template <int N> void buf_ld(const Buf &b, unsigned off, int imm, float *dst) const {
+        for (int i = 0; i < N; ++i) {
+            const unsigned long long o = (unsigned long long)off + (unsigned)imm + 4u * i;
+            if (o + 4 <= b.bytes) std::memcpy(&dst[i], b.base + o, 4); else dst[i] = 0.0f;
+        }
+    }
     awk::cf xchg1(awk::cf v) const {          // value of lane ^ 1
         sh->xs[(size_t)tid_ * 2] = v;
         sh->wave[tid_ >> 6]->arrive_and_wait();

@@ -162,6 +162,47 @@ int emu_fused_ols(const float *in, float *out, const float *hist, const float *t
     return 0;
 }
 
+// The overlap-add tile (tile_ola.hpp): blocks of hop = 512 H frames, the carry in registers, one launch for every block of every
+// stream.  `n_workgroups` contiguous runs over the stream-major block list (runs that start mid-stream rebuild their carry).
+int emu_fused_ola(const float *in, float *out, const float *hist, const float *tracks, int n_tracks, int taps, int n_channels,
+                  const int32_t *left_track, const int32_t *right_track, long long frames, int n_streams, int hist_len, int H, int n_workgroups) {
+    using namespace awk;
+    const int hop = 512 * H;
+    if (H < 1 || H > 8 || taps - 1 > kN - hop || hist_len < taps - 1) return -1;
+    awh::Twiddles tw;
+    std::vector<cf2> tab;
+    awh::build_twiddles(tw);
+    awh::build_pair_tables(tracks, n_tracks, taps, n_channels, left_track, right_track, 0, taps, tab);
+    std::vector<float> zero_hist;
+    TileParams p{};
+    p.in = in; p.out = out; p.tab = tab.data(); p.tw1 = tw.tw1.data(); p.twa = tw.twa.data(); p.twb = tw.twb.data(); p.zeros = g_zeros;
+    p.frames = frames; p.n_channels = n_channels; p.n_pairs = (n_channels + 1) / 2;
+    p.hop = hop; p.hist_len = hist_len;
+    p.tiles_per_stream = (int)((frames + hop - 1) / hop);
+    if (!hist) { zero_hist.assign((size_t)n_streams * hist_len * n_channels, 0.f); hist = zero_hist.data(); }
+    p.hist = hist;
+    const long long n_tiles = (long long)n_streams * p.tiles_per_stream;
+    const long long G = n_workgroups < 1 ? 1 : (n_workgroups > n_tiles ? n_tiles : n_workgroups);
+    EmuShared sh;
+    int rc = 0;
+    for (long long g = 0; g < G; ++g) {
+        const long long first = n_tiles * g / G, end = n_tiles * (g + 1) / G;
+        std::vector<std::thread> th;
+        th.reserve(kThreads);
+        for (int t = 0; t < kThreads; ++t)
+            th.emplace_back([&, t]() {
+                EmuCtx ctx{t, &sh};
+#define AW_OLA_CASE(CS, HH) if (n_channels == CS && H == HH) { tiles_fused_ola<EmuCtx, CS, (CS + 1) / 2, HH>(ctx, p, first, end); return; }
+                AW_OLA_CASE(2, 7) AW_OLA_CASE(2, 8) AW_OLA_CASE(7, 7) AW_OLA_CASE(7, 8) AW_OLA_CASE(8, 7) AW_OLA_CASE(8, 8) AW_OLA_CASE(8, 5)
+                AW_OLA_CASE(14, 7) AW_OLA_CASE(14, 8) AW_OLA_CASE(14, 6) AW_OLA_CASE(16, 7) AW_OLA_CASE(5, 4) AW_OLA_CASE(12, 7) AW_OLA_CASE(6, 7)
+#undef AW_OLA_CASE
+                if (t == 0) rc = -2;
+            });
+        for (auto &x : th) x.join();
+    }
+    return rc;
+}
+
 // Partitioned (long-HRIR) path: kernel 1 (window spectra) then kernel 2 (CMAC over partitions + inverse).
 int emu_partitioned(const float *in, float *out, const float *hist, const float *tracks, int n_tracks, int taps,
                     int n_channels, const int32_t *left_track, const int32_t *right_track, long long frames,
