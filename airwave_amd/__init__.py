@@ -19,7 +19,7 @@ from .graph import AudioEffectGraph, AudioEffectPreparationResult, AudioEffectWa
 from .eq import (  # noqa: E402
     BiquadCoefficientBuilder, BiquadCoefficientError, EqualizerAPOParser, EqualizerAudioEffectError, EqualizerDefinition,
     EqualizerFilter, EqualizerParseError, EqualizerRuntimeEffect, ParametricEqualizerPreparationError,
-    ParametricEqualizerProcessor, ParametricEqualizerState,
+    ParametricEqualizerProcessor, ParametricEqualizerState, EqualizerNotFoldable, FoldedHRIR, fold_equalizer,
 )
 
 __all__ = [
@@ -27,7 +27,7 @@ __all__ = [
     "MixedRateBatch", "RateBucket", "bucket_by_rate", "resample_tracks",
     "BiquadCoefficientBuilder", "BiquadCoefficientError", "EqualizerAPOParser", "EqualizerAudioEffectError",
     "EqualizerDefinition", "EqualizerFilter", "EqualizerParseError", "EqualizerRuntimeEffect",
-    "ParametricEqualizerPreparationError", "ParametricEqualizerProcessor", "ParametricEqualizerState",
+    "ParametricEqualizerPreparationError", "ParametricEqualizerProcessor", "ParametricEqualizerState", "EqualizerNotFoldable", "FoldedHRIR", "fold_equalizer",
     "AirwaveError", "Context", "ConvolutionEngine", "HRIR", "HRIRChannelMap", "HRIRError", "HRIRManager",
     "InputLayout", "RealtimeAudioProcessor", "Resampler", "Spatializer", "WAVData", "WAVError", "WAVLoader",
     "default_context",

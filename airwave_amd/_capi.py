@@ -114,6 +114,7 @@ SIGNATURES = {
     "aw_eq_state_process": (_I32, [_V, _V, _V, _I64]),
     "aw_eq_state_filter_count": (_I32, [_V]),
     "aw_eq_state_preamp_linear": (_D, [_V]),
+    "aw_eq_fold_hrir": (_I32, [_V, _D, c_float_p, _I32, _I32, _D, _I32, c_float_p, c_int32_p, c_int32_p, ctypes.POINTER(ctypes.c_double)]),
     "aw_eq_create": (_I32, [_V, _D, _I32, _I32, c_void_pp]),
     "aw_eq_destroy": (None, [_V]),
     "aw_eq_set_target": (_I32, [_V, _V]),

@@ -250,6 +250,42 @@ aw_status aw_eq_state_process(aw_eq_state *s, const float *in, float *out, int64
 int32_t aw_eq_state_filter_count(const aw_eq_state *s) { return s ? s->s->t.n_filters : 0; }
 double aw_eq_state_preamp_linear(const aw_eq_state *s) { return s ? s->s->t.preamp : 0.0; }
 
+/* ---- the equalizer folded into the HRIR (host only) ---------------------------------------------------------- */
+aw_status aw_eq_fold_hrir(const aw_eq_definition *def, double sample_rate, const float *tracks, int32_t n_tracks, int32_t taps,
+                          double tail_tolerance, int32_t max_taps, float *out_tracks, int32_t *out_taps, int32_t *response_taps,
+                          double *tail_bound) try {
+    if (!tracks || !out_taps) return fail(AW_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_tracks <= 0 || taps <= 0 || max_taps < taps) return fail(AW_ERR_INVALID_ARGUMENT, "n_tracks, taps must be positive and max_taps >= taps");
+    if (!(tail_tolerance > 0.0) || !(tail_tolerance < 1.0)) return fail(AW_ERR_INVALID_ARGUMENT, "tail_tolerance must lie in (0, 1)");
+    awh::EqFold info;
+    int bad_index = 0, bad_kind = 0;
+    std::vector<float> folded;
+    const awh::EqDefinition *d = def ? &def->def : nullptr;
+    switch (awh::eq_fold_tracks(d, sample_rate, tracks, n_tracks, taps, tail_tolerance, max_taps, out_tracks ? &folded : nullptr, info, &bad_index, &bad_kind)) {
+        case awh::kEqPrepInvalidSampleRate: return fail(AW_ERR_EQ_INVALID_SAMPLE_RATE, "Sample rate must be finite and positive.");
+        case awh::kEqPrepNonFinitePreamp: return fail(AW_ERR_EQ_NON_FINITE_PREAMP, "Preamp must produce a finite linear gain.");
+        case awh::kEqPrepTooManyFilters:
+            return fail(AW_ERR_EQ_TOO_MANY_FILTERS, "Equalizer supports at most 64 filters; received " + std::to_string(bad_index) + ".");
+        case awh::kEqPrepInvalidFilter: {
+            int line = 0, seen = 0;
+            for (const auto &f : d->filters)
+                if (f.enabled && seen++ == bad_index) { line = f.source_line; break; }
+            return fail(AW_ERR_EQ_INVALID_FILTER, "Filter " + std::to_string(bad_index + 1) + " is invalid: " + biquad_error_text(bad_kind) +
+                                                      " [kind " + std::to_string(bad_kind) + ", line " + std::to_string(line) + "]");
+        }
+        case awh::kEqFoldTooLong:
+            return fail(AW_ERR_EQ_NOT_FOLDABLE, "the equalizer's impulse response does not decay to " + std::to_string(tail_tolerance) +
+                                                    " of its peak within " + std::to_string((long long)max_taps - taps + 1) +
+                                                    " frames: run the cascade after the spatializer");
+        default: break;
+    }
+    *out_taps = info.out_taps;
+    if (response_taps) *response_taps = info.response_taps;
+    if (tail_bound) *tail_bound = info.tail_bound;
+    if (out_tracks) std::memcpy(out_tracks, folded.data(), folded.size() * sizeof(float));
+    return AW_OK;
+} AW_NOEXCEPT_TAIL
+
 /* ---- processor ----------------------------------------------------------------------------- */
 aw_status aw_eq_create(aw_context *ctx, double sample_rate, int32_t n_streams, int32_t max_frames, aw_eq **out) try {
     if (!out) return fail(AW_ERR_INVALID_ARGUMENT, "out is NULL");

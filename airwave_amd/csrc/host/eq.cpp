@@ -360,4 +360,106 @@ int eq_prepare(const EqDefinition *def, double fs, EqPrepared &out, int *bad_ind
     return kEqPrepOk;
 }
 
+// ---- the equalizer folded into impulse responses (eq.hpp) ------------------------------------------------------------------------
+namespace {
+// ParametricEqualizerState.process :58-91 for one channel: Float64, transposed direct form II, the reference's subnormal flush
+struct Cascade {
+    std::vector<Biquad> c;
+    std::vector<double> z;      // [filter][2]
+    double preamp = 1.0;
+    void reset() { z.assign(c.size() * 2, 0.0); }
+    static double flush(double v) { return std::fabs(v) < 1e-30 ? 0.0 : v; }          // :93-96
+    double step(double x) {
+        double v = x * preamp;
+        for (size_t k = 0; k < c.size(); ++k) {
+            const Biquad &q = c[k];
+            const double y = q.b0 * v + z[2 * k];
+            const double z1 = q.b1 * v - q.a1 * y + z[2 * k + 1];
+            const double z2 = q.b2 * v - q.a2 * y;
+            z[2 * k] = flush(z1);
+            z[2 * k + 1] = flush(z2);
+            v = y;
+        }
+        return v;
+    }
+};
+}  // namespace
+
+int eq_fold_tracks(const EqDefinition *def, double fs, const float *tracks, int n_tracks, int taps, double tol, int max_taps,
+                   std::vector<float> *out, EqFold &info, int *bad_index, int *bad_kind) {
+    info = EqFold{};
+    if (!std::isfinite(fs) || !(fs > 0)) return kEqPrepInvalidSampleRate;
+    const double preamp_db = def ? def->preamp_db : 0.0;
+    Cascade eq;
+    eq.preamp = std::pow(10.0, preamp_db / 20.0);
+    if (!std::isfinite(preamp_db) || !std::isfinite(eq.preamp)) return kEqPrepNonFinitePreamp;
+    std::vector<const EqFilter *> enabled;
+    if (def)
+        for (const auto &f : def->filters)
+            if (f.enabled) enabled.push_back(&f);
+    if ((int)enabled.size() > awk::kEqMaxFilters) {
+        if (bad_index) *bad_index = (int)enabled.size();
+        return kEqPrepTooManyFilters;
+    }
+    for (size_t k = 0; k < enabled.size(); ++k) {
+        Biquad b;
+        const int kind = biquad_make(enabled[k]->type, enabled[k]->gain_db, enabled[k]->frequency_hz, enabled[k]->q, fs, &b);
+        if (kind) {
+            if (bad_index) *bad_index = (int)k;
+            if (bad_kind) *bad_kind = kind;
+            return kEqPrepInvalidFilter;
+        }
+        eq.c.push_back(b);
+    }
+    const long long cap = (long long)max_taps - taps + 1;         // longest response that still fits
+    if (cap < 1) return kEqFoldTooLong;
+    // impulse response over 4 x the allowed length: the tail sums below need what lies past the cut
+    const long long M = eq.c.empty() ? 1 : 4 * cap;
+    std::vector<double> g((size_t)M);
+    eq.reset();
+    for (long long n = 0; n < M; ++n) g[(size_t)n] = eq.step(n == 0 ? 1.0 : 0.0);
+    double peak = 0.0;
+    for (double v : g) peak = std::max(peak, std::fabs(v));
+    if (!(peak > 0.0) || !std::isfinite(peak)) {                   // a muted equalizer (preamp underflow): every folded track is zero
+        info.response_taps = 1; info.out_taps = taps; info.tail_bound = 0.0;
+        if (out) out->assign((size_t)n_tracks * taps, 0.0f);
+        return kEqPrepOk;
+    }
+    // what the simulation did not see: the response decays geometrically in the long run; bound it from its last two quarters
+    double rest = 0.0;
+    if (M >= 8) {
+        double b1 = 0.0, b2 = 0.0;
+        for (long long n = M / 2; n < 3 * M / 4; ++n) b1 += std::fabs(g[(size_t)n]);
+        for (long long n = 3 * M / 4; n < M; ++n) b2 += std::fabs(g[(size_t)n]);
+        // (a last quarter far below the tolerance is the recurrence's noise floor, not response: the reference's subnormal flush at 1e-30
+        // keeps a zero-input limit cycle of ~1e-29 alive for ever — 500 dB below anything a float32 output can show)
+        if (b2 > 1e-3 * tol * peak) {
+            const double rho = b1 > 0.0 ? b2 / b1 : 1.0;
+            if (!(rho < 0.999)) return kEqFoldTooLong;              // not decaying over the simulated span
+            rest = b2 * rho / (1.0 - rho);
+        }
+    }
+    long long L = M;
+    double tail = rest;
+    for (long long n = M - 1; n >= 1; --n) {                       // tail(n) = sum_{m >= n} |g[m]| + rest
+        const double with_n = tail + std::fabs(g[(size_t)n]);
+        if (with_n > tol * peak) break;
+        tail = with_n;
+        L = n;
+    }
+    if (L > cap) return kEqFoldTooLong;
+    info.response_taps = (int)L;
+    info.out_taps = (int)(taps + L - 1);
+    info.tail_bound = tail / peak;
+    if (!out) return kEqPrepOk;
+    out->assign((size_t)n_tracks * info.out_taps, 0.0f);
+    for (int t = 0; t < n_tracks; ++t) {
+        eq.reset();
+        float *dst = out->data() + (size_t)t * info.out_taps;
+        const float *src = tracks + (size_t)t * taps;
+        for (int n = 0; n < info.out_taps; ++n) dst[n] = (float)eq.step(n < taps ? (double)src[n] : 0.0);
+    }
+    return kEqPrepOk;
+}
+
 }  // namespace awh

@@ -47,4 +47,25 @@ enum { kEqPrepOk = 0, kEqPrepInvalidSampleRate = 1, kEqPrepInvalidFilter = 2, kE
 // *bad_kind = the BiquadCoefficientError kind; on kEqPrepTooManyFilters *bad_index = the count.
 int eq_prepare(const EqDefinition *def, double sample_rate, EqPrepared &out, int *bad_index, int *bad_kind);
 
+// The equalizer FOLDED INTO THE IMPULSE RESPONSES (round 6).  Between two setTarget calls the reference's equalizer is a linear
+// time-invariant filter (preamp x cascade of biquads, ParametricEqualizerProcessor.swift:58-91) that follows the spatializer in the graph
+// (AudioEffectGraph.swift:195-211), so  EQ(x * h) = x * (h * g)  with g its impulse response: a batch host that knows the definition
+// convolves every HRIR track with g ONCE, at activation, and the convolution kernels apply both effects in one pass — no second pass over
+// the stereo output, no Float64 recurrence per frame.  g is infinite; it is cut where what is left of it cannot matter:
+//   response_taps = the smallest L with  sum_{n >= L} |g[n]|  <=  tail_tolerance x max |g|
+// (sum measured over 4 x the allowed length plus a geometric bound on the rest), and the folded track is the first taps + L - 1 samples of
+// h * g, computed by running the reference's own Float64 recurrence over the zero-extended track.  The output then differs from the
+// reference's by at most tail_bound x (peak of the spatializer's output), tail_bound <= tail_tolerance, on top of the convolution's
+// own float32 rounding.  An equalizer whose response does not decay within max_taps - taps + 1 frames (a narrow band at a few Hz) is NOT
+// folded: kEqFoldTooLong, and the host runs the cascade kernel after the spatializer as before.
+struct EqFold {
+    int response_taps = 0;      // L: samples of g that are kept
+    int out_taps = 0;           // taps + L - 1
+    double tail_bound = 0.0;    // (sum of |g| past L, incl. the bound on what was not simulated) / max |g|
+};
+enum { kEqFoldTooLong = 5 };
+// Same validation and codes as eq_prepare.  out == nullptr: only `info` (the length) is computed.  def may be NULL (unity: g = delta).
+int eq_fold_tracks(const EqDefinition *def, double sample_rate, const float *tracks, int n_tracks, int taps, double tail_tolerance, int max_taps,
+                   std::vector<float> *out, EqFold &info, int *bad_index, int *bad_kind);
+
 }  // namespace awh

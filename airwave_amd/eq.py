@@ -193,6 +193,40 @@ class ParametricEqualizerState:
         return np.ascontiguousarray(y[:, 0]), np.ascontiguousarray(y[:, 1])
 
 
+class EqualizerNotFoldable(AirwaveError):
+    """aw_eq_fold_hrir: the equalizer's impulse response does not decay to the tolerance within the allowed length (AW_ERR_EQ_NOT_FOLDABLE)."""
+
+
+@dataclass
+class FoldedHRIR:
+    """HRIR tracks with an equalizer folded in (aw_eq_fold_hrir): tracks[i] = (h_i * g)[0 : taps + responseTaps - 1]."""
+    tracks: np.ndarray          # [n_tracks][taps + responseTaps - 1] float32
+    responseTaps: int           # samples of the equalizer's impulse response that were kept
+    tailBound: float            # (what was cut of it) / (its peak): the bound on the output difference relative to the spatializer output's peak
+
+
+def fold_equalizer(tracks, definition: Optional[EqualizerDefinition], sampleRate: float, tailTolerance: float = 1e-7, maxTaps: int = 65536) -> FoldedHRIR:
+    """The equalizer that follows the spatializer in the reference's graph (AudioEffectGraph.swift:195-211), folded into the HRIR tracks:
+    EQ(x * h) = x * (h * g).  Host only.  Raises EqualizerNotFoldable when the response is too long (the caller then runs
+    ParametricEqualizerState after the spatializer) and ParametricEqualizerPreparationError exactly as ParametricEqualizerState does."""
+    lib = _capi.load()
+    tr = np.ascontiguousarray(tracks, dtype=np.float32)
+    assert tr.ndim == 2
+    n, taps = tr.shape
+    out_taps, resp, bound = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double()
+
+    def call(dh, out):
+        st = lib.aw_eq_fold_hrir(dh, sampleRate, _fp(tr), n, taps, tailTolerance, maxTaps, out, ctypes.byref(out_taps), ctypes.byref(resp), ctypes.byref(bound))
+        if st == 17:
+            raise EqualizerNotFoldable(st, (lib.aw_last_error_message() or b"").decode("utf-8", "replace"))
+        _check_eq(st)
+    with _DefHandle(definition) as dh:
+        call(dh, None)                                        # the length first, then the tracks
+        folded = np.empty((n, out_taps.value), dtype=np.float32)
+        call(dh, _fp(folded))
+    return FoldedHRIR(folded, resp.value, bound.value)
+
+
 class ParametricEqualizerProcessor:
     crossfadeDurationSeconds = 0.020
     maximumCallbackFrames = 4096

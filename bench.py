@@ -244,7 +244,7 @@ def measured_ceilings(ctx) -> dict:
             "source": "aw_context_bandwidth_probe on this box, this process, before the timed region"}
 
 
-def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with_cpu: bool, with_check: bool = None, measured: dict = None):
+def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with_cpu: bool, with_check: bool = None, measured: dict = None, eq_mode: str = None):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -282,6 +282,7 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
     if wl.get("text_map"):            # the 14-channel reading of cfg 3: custom channels mapped by a HeSuVi-style text map
         cmap = aw.HRIRChannelMap.parseHeSuViFormat(open(os.path.join(ROOT, "tests", "golden", wl["text_map"])).read())
     eq_def = None
+    eq_mode = eq_mode or getattr(args, "eq", "auto")
     if wl.get("eq"):
         eq_def = aw.EqualizerAPOParser.parse(open(os.path.join(ROOT, "tests", "golden", "eq", "CCA CRA ParametricEq.txt"), "rb").read(), "CCA CRA ParametricEq.txt")
     mem_free0, mem_total = torch.cuda.mem_get_info()
@@ -292,7 +293,10 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
     activation = []                   # per leg: what aw_spatializer_reserve spent where (table build on host threads / upload / scratch pool)
     for li in range(n_lanes):
         lo, hi = li * S // n_lanes, (li + 1) * S // n_lanes
-        batch = aw.MixedRateBatch(tracks, 48000.0, layout, stream_rates[lo:hi], hrirMap=cmap, ctx=lane_ctx[li])
+        # the equalizer of cfg 4 follows the spatializer (AudioEffectGraph.swift:195-211); --eq auto / fold: folded into the HRIR at activation
+        # (aw_eq_fold_hrir: one pass over the audio), --eq cascade: the Float64 biquad kernel after the spatializer, in place
+        batch = aw.MixedRateBatch(tracks, 48000.0, layout, stream_rates[lo:hi], hrirMap=cmap, ctx=lane_ctx[li], equalizer=eq_def,
+                                  fold_equalizer=None if eq_mode == "auto" else eq_mode == "fold")
         batches.append(batch)
         for rate, b in batch.buckets.items():
             n, F = len(b.stream_ids), int(round(seconds * rate))
@@ -306,8 +310,8 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
             inf = b.spatializer.info()
             activation.append({"total_ms": round(total_ms, 1), "tables_ms": round(inf["reserve_tables_ms"], 1), "upload_ms": round(inf["reserve_upload_ms"], 1),
                                "scratch_alloc_ms": round(inf["reserve_scratch_ms"], 1), "scratch_bytes": inf["scratch_bytes"], "warm_context": False})
-            eq = aw.ParametricEqualizerState(eq_def, float(rate), n_streams=n, ctx=lane_ctx[li]) if eq_def is not None else None
-            legs.append(dict(lane=li, rate=rate, n=n, F=F, x=x, y=y, sp=b.spatializer, eq=eq, taps=b.hrir_taps, first=lo + b.stream_ids[0]))
+            legs.append(dict(lane=li, rate=rate, n=n, F=F, x=x, y=y, sp=b.spatializer, eq=b.equalizer, taps=b.hrir_taps, first=lo + b.stream_ids[0],
+                             eq_response_taps=b.eq_response_taps, eq_tail_bound=b.eq_tail_bound))
     batch = batches[0]
     torch.cuda.synchronize()
     mem_free1 = torch.cuda.mem_get_info()[0]
@@ -452,7 +456,8 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
-            "dtype": "f32" if eq_def is None else "f32 (convolution) + f64 (EQ)",
+            "dtype": "f32" if eq_def is None else ("f32 (convolution; the equalizer folded into the HRIR in f64 at activation)" if all(g["eq"] is None for g in legs)
+                                                    else "f32 (convolution) + f64 (EQ)"),
             "data": f"synthetic U(-0.5,0.5) counter RNG seed 0xA17AE+stream, resident in HBM; HRIR: {hrir_src}",
             "config": {
                 "workload": wl["desc"], "name": name, "streams_per_gpu": S, "streams_total": streams_total, "streams_this_rank": S, "frames_per_stream": g0["F"], "sample_rate": g0["rate"],
@@ -462,6 +467,8 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
                 "lanes": n_lanes,
                 "fft": paths[0]["fft"], "hop": paths[0]["hop"], "path": paths[0]["path"], "legs": paths,
                 "outputs_finite": finite,
+                **({"equalizer": {"filters": len(eq_def.filters), "mode": "folded into the HRIR (aw_eq_fold_hrir)" if g0["eq"] is None else "cascade kernel after the spatializer",
+                                  "response_taps": g0["eq_response_taps"], "tail_bound": g0["eq_tail_bound"]}} if eq_def is not None else {}),
                 # creation-time cost (not in the timed region; the reference does its HRIR partition FFTs at engine init too,
                 # ConvolutionEngine.swift:143-182): aw_spatializer_reserve = table build in float64 on host threads + upload + scratch pool
                 # per-rank HBM footprint of this workload (input + output + history + tables + scratch pool), of the device's total
@@ -489,6 +496,25 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
             result["roofline"]["eq_achieved_GBs"] = 16.0 * frames_step / (eq_ms * 1e-3) / 1e9      # 8 B in + 8 B out per frame
         if with_check is None:
             with_check = with_cpu
+        if with_check and world == 1 and eq_def is not None and len(legs) == 1:
+            # parity of the equalized configuration: the recurrence starts at the stream's first frame, so the streams are reset and one
+            # more (untimed) call of the same buffers runs; two streams' first 6144 frames against the oracle — float64 convolution, then
+            # the sequential Float64 cascade of ParametricEqualizerState.process on its float32 result, as the reference orders them
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import airwave_oracle as orc
+            batch.reset()
+            step()
+            torch.cuda.synchronize()
+            tr0 = aw.resample_tracks(tracks, 48000.0, float(g0["rate"]))
+            od = orc.EqualizerDefinition(eq_def.preampDB, [orc.EqualizerFilter(f.sourceLine, f.sourceNumber, f.isEnabled, f.type, f.frequencyHz, f.gainDB, f.q) for f in eq_def.filters])
+            err = 0.0
+            for s_ in (0, g0["n"] - 1):
+                ref = orc.spatialize_f64(g0["x"][s_, :6144].cpu().numpy(), tr0, lt, rt).astype(np.float32)
+                el, er = orc.eq_prepare(od, float(g0["rate"])).process(np.ascontiguousarray(ref[:, 0]), np.ascontiguousarray(ref[:, 1]))
+                err = max(err, orc.peak_rel_error(g0["y"][s_, :6144].cpu().numpy(), np.stack([el, er], axis=1)))
+            result["parity_spot_err"] = err
+            result["parity_spot"] = ("max peak-relative error of streams 0 and n-1, first 6144 output frames of one more call after a reset, against the float64 "
+                                     "convolution followed by the oracle's sequential Float64 biquad cascade; tolerance 1e-5")
         if with_check and world == 1 and eq_def is None and len(legs) == 1:
             # parity of the TIMED configuration (same buffers, same scratch chunking, same kernels): two streams' head and tail
             tr0 = aw.resample_tracks(tracks, 48000.0, float(g0["rate"]))
@@ -632,7 +658,7 @@ def compact_config(c: dict, full: bool) -> dict:
     keys = ["workload", "name", "streams_per_gpu", "frames_per_stream", "sample_rate", "input_channels", "hrir_tracks", "hrir_taps",
             "convolutions_per_stream", "parallelism", "fft", "hop", "path"]
     if full:
-        keys += ["streams_total", "streams_this_rank", "lanes", "outputs_finite", "activation_ms", "device_src_sha16", "host_src_sha16", "build_flags_sha16", "build_head"]
+        keys += ["equalizer", "streams_total", "streams_this_rank", "lanes", "outputs_finite", "activation_ms", "device_src_sha16", "host_src_sha16", "build_flags_sha16", "build_head"]
     out = _pick(c, keys)
     if not full:
         out["workload"] = out["workload"][:120]
@@ -666,7 +692,7 @@ def compact_line(result: dict) -> dict:
     if "parity_spot_err" in result:
         line["parity_spot_err"] = _r(result["parity_spot_err"], 4)
         line["parity_tolerance"] = 1e-5
-    for k in ("secondary", "secondary_cfg2"):
+    for k in ("secondary", "secondary_cfg2", "secondary_eq_cascade"):
         if k in result:
             line[k] = compact_secondary(result[k])
     if "secondary_end_to_end" in result:
@@ -690,7 +716,7 @@ def emit(result: dict) -> str:
                 pass
     line = compact_line(result)
     text = json.dumps(line, separators=(", ", ": "))
-    for k in ("secondary_end_to_end", "secondary_cfg2", "secondary"):
+    for k in ("secondary_end_to_end", "secondary_eq_cascade", "secondary_cfg2", "secondary"):
         if len(text) < LINE_LIMIT:
             break
         if line.pop(k, None) is not None:
@@ -749,6 +775,8 @@ def main() -> int:
     ap.add_argument("--cpu-sample-streams", type=int, default=48)
     ap.add_argument("--dry-run", action="store_true", help="no GPU: rehearse launch + rendezvous + aggregate only (tests)")
     ap.add_argument("--lanes", type=int, default=0, help="run the batch as this many chunks of streams on HIP streams of their own (default per workload; cfg4: see WORKLOADS)")
+    ap.add_argument("--eq", default="auto", choices=["auto", "fold", "cascade"],
+                    help="cfg4's equalizer: folded into the HRIR at activation (auto / fold) or the Float64 biquad kernel after the spatializer (cascade)")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the measured read / write / copy ceiling probe (roofline.measured)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive secondary legs (secondary_end_to_end)")
     ap.add_argument("--no-warm-activation", action="store_true", help="skip the second, warm-context activation (config.activation_warm)")
@@ -824,6 +852,12 @@ def main() -> int:
         if rank == 0:
             result["secondary_cfg2"] = {k: r3[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "roofline", "fp32_roof", "parity_spot_err") if k in r3}
             result["secondary_cfg2"]["note"] = "BASELINE configs[1] (7.1 -> RoomSH1.0, 128 streams x 10 s, all state on chip: the fused 8192-frame tile); value is never the headline"
+    if args.workload == "cfg4" and args.eq != "cascade" and not args.no_secondary and not args.streams and not args.seconds:
+        # the same configuration with the equalizer as a SEPARATE pass (the reference's structure: AudioEffectGraph runs two effects)
+        r4 = run_workload("cfg4", args, ctx, world, rank, backend, with_cpu=False, with_check=not args.no_cpu_baseline, measured=measured, eq_mode="cascade")
+        if rank == 0:
+            result["secondary_eq_cascade"] = {k: r4[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "roofline", "parity_spot_err") if k in r4}
+            result["secondary_eq_cascade"]["note"] = "cfg 4 with the equalizer as its own Float64 biquad-cascade pass over the stereo output (round 5's form); value is never the headline"
     e2e_of = {"cfg3": [("cfg3", 128), ("cfg2", 0)], "cfg2": [("cfg2", 0)], "cfg2-14ch": [("cfg2-14ch", 0)], "cfg1": [("cfg1", 0)]}
     if rank == 0 and world == 1 and not args.no_end_to_end and not args.streams and not args.seconds and args.workload in e2e_of:
         # SURVEY 8d "end-to-end incl. PCIe as secondary": the same hot path fed from host memory; never `value`
@@ -832,7 +866,7 @@ def main() -> int:
     rc = 0
     if rank == 0:
         print(emit(result), flush=True)
-        errs = [e for e in [result.get("parity_spot_err"), result.get("secondary", {}).get("parity_spot_err"), result.get("secondary_cfg2", {}).get("parity_spot_err")]
+        errs = [e for e in [result.get("parity_spot_err"), result.get("secondary", {}).get("parity_spot_err"), result.get("secondary_cfg2", {}).get("parity_spot_err"), result.get("secondary_eq_cascade", {}).get("parity_spot_err")]
                 + [r.get("parity_spot_err") for r in result.get("secondary_end_to_end", [])] if e is not None]
         if any(not (e < 1e-5) for e in errs):
             print(f"bench.py: parity spot check FAILED: {errs} (tolerance 1e-5)", file=sys.stderr)

@@ -52,7 +52,8 @@ enum {
     AW_ERR_EQ_INVALID_SAMPLE_RATE = 13,  /* ParametricEqualizerPreparationError.invalidSampleRate  ParametricEqualizerProcessor.swift:100-101 */
     AW_ERR_EQ_NON_FINITE_PREAMP = 14,    /* .nonFinitePreamp  :102 */
     AW_ERR_EQ_TOO_MANY_FILTERS = 15,     /* .tooManyFilters   :103 (also the maxFramesPerCallback guard, :148-150) */
-    AW_ERR_EQ_INVALID_FILTER = 16        /* .invalidFilter(index:error:)  :104; BiquadCoefficientError  BiquadCoefficientBuilder.swift:11-16 */
+    AW_ERR_EQ_INVALID_FILTER = 16,       /* .invalidFilter(index:error:)  :104; BiquadCoefficientError  BiquadCoefficientBuilder.swift:11-16 */
+    AW_ERR_EQ_NOT_FOLDABLE = 17          /* aw_eq_fold_hrir: the equalizer's impulse response does not decay to the tolerance within the allowed length */
 };
 AW_API const char *aw_status_string(aw_status s);
 AW_API const char *aw_last_error_message(void); /* thread-local, valid until the next failing call */
@@ -315,6 +316,23 @@ AW_API aw_status aw_eq_state_reset(aw_eq_state *s);                             
 AW_API aw_status aw_eq_state_process(aw_eq_state *s, const float *in_device, float *out_device, int64_t frames);
 AW_API int32_t aw_eq_state_filter_count(const aw_eq_state *s);
 AW_API double aw_eq_state_preamp_linear(const aw_eq_state *s);
+
+/* The equalizer FOLDED INTO THE HRIR (batch hosts; round 6).  In the reference's graph the equalizer follows the spatializer
+ * (AudioEffectGraph.swift:195-211: spatial effect, then equalizer) and, between two setTarget calls, is a linear time-invariant filter
+ * (preamp x biquad cascade, ParametricEqualizerProcessor.swift:58-91), so EQ(x * h) = x * (h * g) with g its impulse response.  This
+ * entry convolves every HRIR track with g once, on the host, in Float64 with the reference's own recurrence; a spatializer created
+ * from the folded tracks then applies both effects in its one pass over the audio — instead of ParametricEqualizerState.process
+ * re-reading and re-writing every stereo frame with ten sequential Float64 sections.  g is cut after response_taps = the smallest L
+ * with sum_{n >= L} |g[n]| <= tail_tolerance x max |g|; the result differs from EQ-after-spatializer by at most *tail_bound x the
+ * spatializer output's peak (tail_bound <= tail_tolerance; 1e-7 is two orders below the 1e-5 parity tolerance).
+ *   tracks: [n_tracks][taps] at sample_rate (resampled like HRIRManager.swift:389-403 does, if the device rate differs)
+ *   out_tracks: NULL = only *out_taps is computed (= taps + response_taps - 1); else [n_tracks][*out_taps]
+ * AW_ERR_EQ_NOT_FOLDABLE: the response does not decay to the tolerance within max_taps - taps + 1 frames (a narrow band at a few Hz):
+ * the host keeps the cascade (aw_eq_state_process / aw_eq_process after the spatializer).  Validation and its errors as
+ * aw_eq_state_create.  definition NULL = unity (the tracks come back unchanged).  Host only: no device work. */
+AW_API aw_status aw_eq_fold_hrir(const aw_eq_definition *definition_or_null, double sample_rate, const float *tracks, int32_t n_tracks,
+                                 int32_t taps, double tail_tolerance, int32_t max_taps, float *out_tracks, int32_t *out_taps,
+                                 int32_t *response_taps, double *tail_bound);
 
 /* ParametricEqualizerProcessor  :116-408: starts at unity; aw_eq_set_target prepares and publishes a
  * target that the next process call crossfades to over max(1, round(0.020 * sample_rate)) frames
