@@ -19,6 +19,7 @@ _V, _I32, _I64, _U64, _D, _SZ, _S = ctypes.c_void_p, ctypes.c_int32, ctypes.c_in
 SIGNATURES = {
     "aw_status_string": (_S, [_I32]),
     "aw_last_error_message": (_S, []),
+    "aw_last_eq_filter_error": (_I32, [c_int32_p, c_int32_p, c_int32_p]),
     "aw_version": (_S, []),
     "aw_context_create": (_I32, [_I32, c_void_pp]),
     "aw_context_create_on_stream": (_I32, [_I32, _V, c_void_pp]),

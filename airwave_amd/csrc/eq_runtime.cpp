@@ -62,7 +62,7 @@ aw_status prepare_state(aw_context *ctx, const awh::EqDefinition *def, double sa
             int line = 0, seen = 0;
             for (const auto &f : def->filters)
                 if (f.enabled && seen++ == bad_index) { line = f.source_line; break; }
-            return fail(AW_ERR_EQ_INVALID_FILTER, "Filter " + std::to_string(bad_index + 1) + " is invalid: " + biquad_error_text(bad_kind) +
+            return awr::fail_eq_filter(bad_index, bad_kind, line, "Filter " + std::to_string(bad_index + 1) + " is invalid: " + biquad_error_text(bad_kind) +
                                                       " [kind " + std::to_string(bad_kind) + ", line " + std::to_string(line) + "]");
         }
         default: break;
@@ -270,7 +270,7 @@ aw_status aw_eq_fold_hrir(const aw_eq_definition *def, double sample_rate, const
             int line = 0, seen = 0;
             for (const auto &f : d->filters)
                 if (f.enabled && seen++ == bad_index) { line = f.source_line; break; }
-            return fail(AW_ERR_EQ_INVALID_FILTER, "Filter " + std::to_string(bad_index + 1) + " is invalid: " + biquad_error_text(bad_kind) +
+            return awr::fail_eq_filter(bad_index, bad_kind, line, "Filter " + std::to_string(bad_index + 1) + " is invalid: " + biquad_error_text(bad_kind) +
                                                       " [kind " + std::to_string(bad_kind) + ", line " + std::to_string(line) + "]");
         }
         case awh::kEqFoldTooLong:

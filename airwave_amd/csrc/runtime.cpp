@@ -88,13 +88,22 @@ struct aw_context::CopyPool {
 namespace awr {
 
 static thread_local std::string g_last_error;
+// the structured part of AW_ERR_EQ_INVALID_FILTER (aw_last_eq_filter_error): valid until the thread's next failing call
+static thread_local struct { bool valid; int index, kind, line; } g_eq_filter_error = {false, 0, 0, 0};
 
 void set_error(const std::string &msg) { g_last_error = msg; }
 aw_status fail(aw_status code, const std::string &msg) {
     g_last_error = msg;
+    g_eq_filter_error.valid = false;
     return code;
 }
+aw_status fail_eq_filter(int enabled_index, int kind, int source_line, const std::string &msg) {
+    g_last_error = msg;
+    g_eq_filter_error = {true, enabled_index, kind, source_line};
+    return AW_ERR_EQ_INVALID_FILTER;
+}
 aw_status hip_fail(hipError_t e, const char *what) {
+    g_eq_filter_error.valid = false;
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
     return e == hipErrorOutOfMemory ? AW_ERR_OUT_OF_MEMORY : AW_ERR_HIP;
 }
@@ -124,6 +133,14 @@ const char *aw_version(void) { return "airwave-hip 0.1 (gfx950)"; }
 
 const char *aw_last_error_message(void) { return awr::g_last_error.c_str(); }
 
+int32_t aw_last_eq_filter_error(int32_t *enabled_index, int32_t *error_kind, int32_t *source_line) {
+    if (!awr::g_eq_filter_error.valid) return 0;
+    if (enabled_index) *enabled_index = awr::g_eq_filter_error.index;
+    if (error_kind) *error_kind = awr::g_eq_filter_error.kind;
+    if (source_line) *source_line = awr::g_eq_filter_error.line;
+    return 1;
+}
+
 const char *aw_status_string(aw_status s) {
     switch (s) {
         case AW_OK: return "ok";
@@ -143,6 +160,7 @@ const char *aw_status_string(aw_status s) {
         case AW_ERR_EQ_NON_FINITE_PREAMP: return "Preamp must produce a finite linear gain.";   // :108-109
         case AW_ERR_EQ_TOO_MANY_FILTERS: return "Equalizer supports at most 64 filters";   // :110-111
         case AW_ERR_EQ_INVALID_FILTER: return "Filter is invalid";                          // :112-113
+        case AW_ERR_EQ_NOT_FOLDABLE: return "Equalizer response too long to fold into the HRIR";
         default: return "unknown status";
     }
 }

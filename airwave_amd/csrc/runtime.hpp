@@ -16,6 +16,7 @@ namespace awr {
 
 void set_error(const std::string &msg);
 aw_status fail(aw_status code, const std::string &msg);
+aw_status fail_eq_filter(int enabled_index, int kind, int source_line, const std::string &msg);      // AW_ERR_EQ_INVALID_FILTER + aw_last_eq_filter_error
 aw_status hip_fail(hipError_t e, const char *what);
 bool context_literal_resampler(const aw_context *ctx);
 // The C ABI promises "no exceptions": every entry point that can allocate host memory (containers, strings, threads) is a

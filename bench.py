@@ -659,16 +659,16 @@ def compact_config(c: dict, full: bool) -> dict:
             "convolutions_per_stream", "parallelism", "fft", "hop", "path"]
     if full:
         keys += ["equalizer", "streams_total", "streams_this_rank", "lanes", "outputs_finite", "activation_ms", "device_src_sha16", "host_src_sha16", "build_flags_sha16", "build_head"]
+    if not full:          # a secondary: what identifies the workload and the kernels that ran (its description is in bench_detail.json)
+        keys = ["name", "streams_per_gpu", "frames_per_stream", "input_channels", "hrir_taps", "fft", "hop", "path"]
     out = _pick(c, keys)
-    if not full:
-        out["workload"] = out["workload"][:120]
     if len(c.get("legs", [])) > 1:
         out["legs"] = [_pick(l, ["rate", "streams", "frames", "taps", "fft", "hop", "partitions"]) for l in c["legs"]]
     return out
 
 
 def compact_secondary(r: dict) -> dict:
-    out = _pick(r, ["value", "unit", "steps", "warmup", "ms_per_step", "parity_spot_err", "note"])
+    out = _pick(r, ["value", "steps", "warmup", "ms_per_step", "parity_spot_err", "note"])
     out["config"] = compact_config(r["config"], full=False)
     out["roofline"] = compact_roofline(r["roofline"], full=False)
     if "fp32_roof" in r:
@@ -692,7 +692,7 @@ def compact_line(result: dict) -> dict:
     if "parity_spot_err" in result:
         line["parity_spot_err"] = _r(result["parity_spot_err"], 4)
         line["parity_tolerance"] = 1e-5
-    for k in ("secondary", "secondary_cfg2", "secondary_eq_cascade"):
+    for k in ("secondary", "secondary_cfg2", "secondary_cfg2_14ch", "secondary_eq_cascade"):
         if k in result:
             line[k] = compact_secondary(result[k])
     if "secondary_end_to_end" in result:
@@ -716,7 +716,7 @@ def emit(result: dict) -> str:
                 pass
     line = compact_line(result)
     text = json.dumps(line, separators=(", ", ": "))
-    for k in ("secondary_end_to_end", "secondary_eq_cascade", "secondary_cfg2", "secondary"):
+    for k in ("secondary_end_to_end", "secondary_eq_cascade", "secondary_cfg2_14ch", "secondary_cfg2", "secondary"):
         if len(text) < LINE_LIMIT:
             break
         if line.pop(k, None) is not None:
@@ -852,6 +852,11 @@ def main() -> int:
         if rank == 0:
             result["secondary_cfg2"] = {k: r3[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "roofline", "fp32_roof", "parity_spot_err") if k in r3}
             result["secondary_cfg2"]["note"] = "BASELINE configs[1] (7.1 -> RoomSH1.0, 128 streams x 10 s, all state on chip: the fused 8192-frame tile); value is never the headline"
+        # ... and the same configuration with 14-channel input, north_star's literal layout ("synthetic 48 kHz 14-ch input"), on chip too since round 6
+        r5 = run_workload("cfg2-14ch", a2, ctx, world, rank, backend, with_cpu=False, with_check=not args.no_cpu_baseline, measured=measured)
+        if rank == 0:
+            result["secondary_cfg2_14ch"] = {k: r5[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "roofline", "fp32_roof", "parity_spot_err") if k in r5}
+            result["secondary_cfg2_14ch"]["note"] = "cfg 2 with 14-channel input through the parseHeSuViFormat text map (the overlap-add tile); value is never the headline"
     if args.workload == "cfg4" and args.eq != "cascade" and not args.no_secondary and not args.streams and not args.seconds:
         # the same configuration with the equalizer as a SEPARATE pass (the reference's structure: AudioEffectGraph runs two effects)
         r4 = run_workload("cfg4", args, ctx, world, rank, backend, with_cpu=False, with_check=not args.no_cpu_baseline, measured=measured, eq_mode="cascade")
@@ -866,7 +871,8 @@ def main() -> int:
     rc = 0
     if rank == 0:
         print(emit(result), flush=True)
-        errs = [e for e in [result.get("parity_spot_err"), result.get("secondary", {}).get("parity_spot_err"), result.get("secondary_cfg2", {}).get("parity_spot_err"), result.get("secondary_eq_cascade", {}).get("parity_spot_err")]
+        errs = [e for e in [result.get("parity_spot_err"), result.get("secondary", {}).get("parity_spot_err"), result.get("secondary_cfg2", {}).get("parity_spot_err"), result.get("secondary_cfg2_14ch", {}).get("parity_spot_err"),
+                           result.get("secondary_eq_cascade", {}).get("parity_spot_err")]
                 + [r.get("parity_spot_err") for r in result.get("secondary_end_to_end", [])] if e is not None]
         if any(not (e < 1e-5) for e in errs):
             print(f"bench.py: parity spot check FAILED: {errs} (tolerance 1e-5)", file=sys.stderr)

@@ -57,6 +57,12 @@ enum {
 };
 AW_API const char *aw_status_string(aw_status s);
 AW_API const char *aw_last_error_message(void); /* thread-local, valid until the next failing call */
+/* The structured part of the calling thread's last AW_ERR_EQ_INVALID_FILTER — what EqualizerRuntimeEffect.map builds
+ * EqualizerAudioEffectError.invalidFilter(line:reason:) from (EqualizerRuntimeEffect.swift:80-100): the index among the ENABLED filters
+ * (ParametricEqualizerPreparationError.invalidFilter(index:error:), ParametricEqualizerProcessor.swift:188-202), the
+ * BiquadCoefficientError kind (aw_biquad_make) and that filter's sourceLine (0 if the definition carried none).  Returns 1 and fills
+ * the non-NULL outputs, or 0 when the thread's last failing call was something else. */
+AW_API int32_t aw_last_eq_filter_error(int32_t *enabled_index, int32_t *error_kind, int32_t *source_line);
 
 /* ---- context: device + stream + twiddle tables -------------------------------------------------
  * Replaces FFTSetupManager.shared.getSetup(log2n:) (FFTSetupManager.swift:41-60): the twiddle

@@ -10,12 +10,40 @@ public final class BatchSpatializer {
     public let streams: Int
     public let channels: Int
 
+    /// The equalizer of the batch, if one was folded into the HRIR: samples of its impulse response that were kept and the bound on what
+    /// the cut can change relative to the spatializer output's peak (aw_eq_fold_hrir).  nil: no equalizer, or not folded.
+    public private(set) var foldedEqualizer: (responseTaps: Int, tailBound: Double)?
+
     /// tracks: planar HRIR ([track][tap]); leftTrack/rightTrack per input channel, -1 = speaker without a mapping
     /// (skipped like HRIRManager.swift:370-372).  Throws the reference's error categories as NSError codes.
-    public init(context: HIPContext, tracks: [[Float]], sampleRate: Double, leftTrack: [Int32], rightTrack: [Int32], streams: Int) throws {
+    /// equalizer: the definition AudioEffectGraph would run AFTER the spatial effect (AudioEffectGraph.swift:195-211).  A batch host knows
+    /// it up front, so it is folded into the HRIR here — EQ(x * h) = x * (h * g), one pass over the audio instead of two — when its impulse
+    /// response decays within `equalizerMaxTaps`; otherwise (AW_ERR_EQ_NOT_FOLDABLE) the initialiser throws and the host runs
+    /// `HIPEqualizerEffect` / aw_eq_process on the output as the reference's graph does.
+    public init(context: HIPContext, tracks: [[Float]], sampleRate: Double, leftTrack: [Int32], rightTrack: [Int32], streams: Int,
+                equalizer: HIPEqualizerDefinition? = nil, equalizerTailTolerance: Double = 1e-7, equalizerMaxTaps: Int32 = 65536) throws {
         precondition(leftTrack.count == rightTrack.count)
-        let taps = tracks.first?.count ?? 0
-        let flat = tracks.flatMap { $0 }
+        var taps = tracks.first?.count ?? 0
+        var flat = tracks.flatMap { $0 }
+        if let definition = equalizer {
+            guard let def = HIPEqualizerEffect.makeDefinitionHandle(definition) else { throw BatchSpatializer.error(AW_ERR_OUT_OF_MEMORY) }
+            defer { aw_eq_definition_destroy(def) }
+            var outTaps: Int32 = 0, response: Int32 = 0, bound = 0.0
+            var st = flat.withUnsafeBufferPointer {
+                aw_eq_fold_hrir(def, sampleRate, $0.baseAddress, Int32(tracks.count), Int32(taps), equalizerTailTolerance, equalizerMaxTaps, nil, &outTaps, &response, &bound)
+            }
+            guard st == AW_OK else { throw BatchSpatializer.error(st) }
+            var folded = [Float](repeating: 0, count: tracks.count * Int(outTaps))
+            st = flat.withUnsafeBufferPointer { src in
+                folded.withUnsafeMutableBufferPointer { dst in
+                    aw_eq_fold_hrir(def, sampleRate, src.baseAddress, Int32(tracks.count), Int32(taps), equalizerTailTolerance, equalizerMaxTaps, dst.baseAddress, &outTaps, &response, &bound)
+                }
+            }
+            guard st == AW_OK else { throw BatchSpatializer.error(st) }
+            flat = folded
+            taps = Int(outTaps)
+            foldedEqualizer = (Int(response), bound)
+        }
         var hrir: OpaquePointer?
         var st = flat.withUnsafeBufferPointer { aw_hrir_create(context.handle, $0.baseAddress, Int32(tracks.count), Int32(taps), sampleRate, &hrir) }
         guard st == AW_OK, let h = hrir else { throw BatchSpatializer.error(st) }

@@ -1,26 +1,54 @@
 //  HIPEqualizerEffect.swift
 //  Drop-in `AudioEqualizerEffect` (Airwave/AudioEffectGraph.swift:51-54) backed by the MI355X EQ
 //  (aw_eq_* in airwave_hip.h).  Same control/render split as Airwave/EqualizerRuntimeEffect.swift:
-//  `prepare` / `setTarget` run on the control thread and may allocate, `process` has the
-//  `StereoAudioProcessing` signature and passes audio through until a processor exists.
+//  `prepare(definition:sampleRate:)` / `setTarget(definition:)` — the protocol's exact shape — run on the control
+//  thread and may allocate, `process` has the `StereoAudioProcessing` signature and passes audio through until a
+//  processor exists.  The definition types mirror Airwave/EqualizerPreset.swift:9-27 field for field (the app's own
+//  are internal to its module; INTEGRATION.md shows the two-line conversion and the conformance the app adds).
 //  Not compiled in this repository's image (no swiftc); see INTEGRATION.md.
 
 import Foundation
 import CAirwaveHIP
 
-public struct HIPEqualizerFilter {
-    public var isEnabled: Bool
-    public var type: Int32          // 0 peaking, 1 lowShelf, 2 highShelf (EqualizerFilterType)
-    public var frequencyHz: Double
-    public var gainDB: Double
-    public var q: Double
+/// EqualizerFilterType   EqualizerPreset.swift:3-7
+public enum HIPEqualizerFilterType: Int32, Equatable {
+    case peaking = 0, lowShelf = 1, highShelf = 2
 }
 
-public enum HIPEqualizerError: Error {
+/// EqualizerFilter   EqualizerPreset.swift:9-17 — `sourceLine` / `sourceNumber` travel with the filter: a rejected filter is
+/// reported by the line of the Equalizer APO file it came from (EqualizerRuntimeEffect.swift:85-89).
+public struct HIPEqualizerFilter: Equatable {
+    public let sourceLine: Int
+    public let sourceNumber: Int?
+    public let isEnabled: Bool
+    public let type: HIPEqualizerFilterType
+    public let frequencyHz: Double
+    public let gainDB: Double
+    public let q: Double
+    public init(sourceLine: Int, sourceNumber: Int?, isEnabled: Bool, type: HIPEqualizerFilterType, frequencyHz: Double, gainDB: Double, q: Double) {
+        self.sourceLine = sourceLine; self.sourceNumber = sourceNumber; self.isEnabled = isEnabled; self.type = type
+        self.frequencyHz = frequencyHz; self.gainDB = gainDB; self.q = q
+    }
+}
+
+/// EqualizerDefinition   EqualizerPreset.swift:19-27
+public struct HIPEqualizerDefinition: Equatable {
+    public let preampDB: Double
+    public let filters: [HIPEqualizerFilter]
+    public init(preampDB: Double = 0, filters: [HIPEqualizerFilter] = []) { self.preampDB = preampDB; self.filters = filters }
+}
+
+/// EqualizerAudioEffectError   AudioEffectGraph.swift:27-46 (+ .parse for the static parser below)
+public enum HIPEqualizerError: Error, Equatable {
+    case invalidFilter(line: Int?, reason: String)
     case invalidSampleRate
-    case invalidFilter(reason: String)
     case unavailable(String)
     case parse(String)
+
+    public var filterLine: Int? {
+        if case .invalidFilter(let line, _) = self { return line }
+        return nil
+    }
 }
 
 /// One sample-rate-specific processor (`aw_eq`).  Destroyed when the LAST reference goes away — the control side's or the
@@ -33,7 +61,7 @@ final class EqualizerBox {
     deinit { aw_eq_destroy(handle) }
 }
 
-public final class HIPEqualizerEffect /* : AudioEqualizerEffect */ {
+public final class HIPEqualizerEffect {      // the app declares `extension HIPEqualizerEffectAdapter: AudioEqualizerEffect` (INTEGRATION.md 1b)
     private let context: HIPContext
     // The publication scheme of Airwave/EqualizerRuntimeEffect.swift:6-8,57-61: the control thread publishes a processor under
     // `processorLock`, the render thread takes one try-lock snapshot per callback into `audioThreadProcessor` and otherwise keeps
@@ -53,26 +81,40 @@ public final class HIPEqualizerEffect /* : AudioEqualizerEffect */ {
         retiredLock.withLock { $0.reserveCapacity(kRetireCapacity) }
     }
 
-    /// EqualizerAPOParser.parse(data:filename:) -> definition handle (caller destroys with aw_eq_definition_destroy).
-    public static func parse(data: Data) throws -> OpaquePointer {
+    /// EqualizerAPOParser.parse(data:filename:)   EqualizerAPOParser.swift:36-151 — the library's parser, read back into the value type
+    /// (source lines and numbers included: aw_eq_definition_filter).
+    public static func parse(data: Data) throws -> HIPEqualizerDefinition {
         var def: OpaquePointer?
         var issues = [CChar](repeating: 0, count: 4096)
         let st = data.withUnsafeBytes { aw_eq_parse($0.baseAddress, data.count, &def, &issues, issues.count) }
         guard st == AW_OK, let d = def else { throw HIPEqualizerError.parse(String(cString: issues)) }
-        return d
+        defer { aw_eq_definition_destroy(d) }
+        var filters: [HIPEqualizerFilter] = []
+        for i in 0..<aw_eq_definition_filter_count(d) {
+            var line: Int32 = 0, number: Int64 = -1, enabled: Int32 = 0, type: Int32 = 0
+            var f = 0.0, g = 0.0, q = 0.0
+            guard aw_eq_definition_filter(d, i, &line, &number, &enabled, &type, &f, &g, &q) == AW_OK else { continue }
+            filters.append(HIPEqualizerFilter(sourceLine: Int(line), sourceNumber: number < 0 ? nil : Int(number), isEnabled: enabled != 0,
+                                              type: HIPEqualizerFilterType(rawValue: type) ?? .peaking, frequencyHz: f, gainDB: g, q: q))
+        }
+        return HIPEqualizerDefinition(preampDB: aw_eq_definition_preamp_db(d), filters: filters)
     }
 
-    private func makeDefinition(preampDB: Double, filters: [HIPEqualizerFilter]) -> OpaquePointer? {
+    /// The definition as the C ABI's host object, `sourceLine` / `sourceNumber` included (aw_eq_definition_set_source): the library
+    /// reports a rejected filter by them (aw_last_eq_filter_error).  nil definition = nil handle = unity.
+    private func makeDefinition(_ definition: HIPEqualizerDefinition) -> OpaquePointer? { Self.makeDefinitionHandle(definition) }
+    static func makeDefinitionHandle(_ definition: HIPEqualizerDefinition) -> OpaquePointer? {
         var def: OpaquePointer?
-        guard aw_eq_definition_create(preampDB, &def) == AW_OK, let d = def else { return nil }
-        for f in filters {
-            _ = aw_eq_definition_add_filter(d, f.isEnabled ? 1 : 0, f.type, f.frequencyHz, f.gainDB, f.q)
+        guard aw_eq_definition_create(definition.preampDB, &def) == AW_OK, let d = def else { return nil }
+        for (i, f) in definition.filters.enumerated() {
+            _ = aw_eq_definition_add_filter(d, f.isEnabled ? 1 : 0, f.type.rawValue, f.frequencyHz, f.gainDB, f.q)
+            _ = aw_eq_definition_set_source(d, Int32(i), Int32(f.sourceLine), Int64(f.sourceNumber ?? -1))
         }
         return d
     }
 
-    /// AudioEqualizerEffect.prepare(definition:sampleRate:)   EqualizerRuntimeEffect.swift:10-34
-    public func prepare(preampDB: Double?, filters: [HIPEqualizerFilter], sampleRate: Double) throws {
+    /// AudioEqualizerEffect.prepare(definition:sampleRate:)   AudioEffectGraph.swift:52, EqualizerRuntimeEffect.swift:10-34
+    public func prepare(definition: HIPEqualizerDefinition?, sampleRate: Double) throws {
         guard sampleRate.isFinite, sampleRate > 0 else { throw HIPEqualizerError.invalidSampleRate }
         let box: EqualizerBox
         if let current = controlProcessor, current.sampleRate == sampleRate {
@@ -89,32 +131,68 @@ public final class HIPEqualizerEffect /* : AudioEqualizerEffect */ {
             processorLock.withLock { $0 = box }
         }
         drainRetiredProcessors()
-        try publish(box, preampDB: preampDB, filters: filters)
+        try publish(box, definition: definition)
     }
 
-    /// AudioEqualizerEffect.setTarget(definition:)   EqualizerRuntimeEffect.swift:36-48
-    public func setTarget(preampDB: Double?, filters: [HIPEqualizerFilter]) throws {
+    /// AudioEqualizerEffect.setTarget(definition:)   AudioEffectGraph.swift:53, EqualizerRuntimeEffect.swift:36-48
+    public func setTarget(definition: HIPEqualizerDefinition?) throws {
         guard let box = controlProcessor else {
             throw HIPEqualizerError.unavailable("Equalizer has not been prepared for an output.")
         }
         drainRetiredProcessors()
-        try publish(box, preampDB: preampDB, filters: filters)
+        try publish(box, definition: definition)
     }
 
     /// `aw_eq_set_target` / `aw_eq_drain_retired` take the processor's own publication locks, `aw_eq_process_planar` only tries
     /// them (ParametricEqualizerProcessor.swift:322,342,380,393): safe against a concurrent `process` on the same handle.
-    private func publish(_ box: EqualizerBox, preampDB: Double?, filters: [HIPEqualizerFilter]) throws {
-        let def = preampDB.flatMap { makeDefinition(preampDB: $0, filters: filters) }   // nil = unity
+    private func publish(_ box: EqualizerBox, definition: HIPEqualizerDefinition?) throws {
+        let def = definition.flatMap { makeDefinition($0) }        // nil = unity
         defer { if let d = def { aw_eq_definition_destroy(d) } }
         let st = aw_eq_set_target(box.handle, def)
         if st != AW_OK {                                           // :27-33: fall back to unity, then report
-            let reason = String(cString: aw_last_error_message())
+            let error = Self.map(st, definition: definition)       // (reads the thread's error state before the calls below replace it)
             _ = aw_eq_set_target(box.handle, nil)
             _ = aw_eq_drain_retired(box.handle)
-            throw st == AW_ERR_EQ_INVALID_SAMPLE_RATE ? HIPEqualizerError.invalidSampleRate
-                                                      : HIPEqualizerError.invalidFilter(reason: reason)
+            throw error
         }
         _ = aw_eq_drain_retired(box.handle)
+    }
+
+    /// EqualizerRuntimeEffect.map   EqualizerRuntimeEffect.swift:80-100: ParametricEqualizerPreparationError -> EqualizerAudioEffectError.
+    /// `.invalidFilter(index:error:)` names the filter by its index among the ENABLED filters; the line is that filter's `sourceLine`
+    /// (the library looked it up the same way and reports it with the index: aw_last_eq_filter_error), the reason the
+    /// BiquadCoefficientError's description without the "Filter N is invalid:" prefix of the preparation error.
+    static func map(_ status: aw_status, definition: HIPEqualizerDefinition?) -> HIPEqualizerError {
+        switch status {
+        case AW_ERR_EQ_INVALID_FILTER:
+            var index: Int32 = 0, kind: Int32 = 0, line: Int32 = 0
+            guard aw_last_eq_filter_error(&index, &kind, &line) == 1 else {
+                return .invalidFilter(line: nil, reason: String(cString: aw_last_error_message()))
+            }
+            let enabled = (definition?.filters ?? []).filter(\.isEnabled)
+            let sourceLine: Int? = enabled.indices.contains(Int(index)) ? enabled[Int(index)].sourceLine : nil
+            return .invalidFilter(line: sourceLine, reason: biquadErrorDescription(kind))
+        case AW_ERR_EQ_INVALID_SAMPLE_RATE:
+            return .invalidSampleRate
+        case AW_ERR_EQ_NON_FINITE_PREAMP:
+            return .invalidFilter(line: nil, reason: "Preamp produces a non-finite gain.")
+        case AW_ERR_EQ_TOO_MANY_FILTERS:
+            let count = (definition?.filters ?? []).filter(\.isEnabled).count
+            return .invalidFilter(line: nil, reason: "Equalizer supports at most 64 filters; received \(count).")
+        default:
+            return .unavailable(String(cString: aw_last_error_message()))
+        }
+    }
+
+    /// BiquadCoefficientError.errorDescription   BiquadCoefficientBuilder.swift:18-26 (kinds as aw_biquad_make reports them)
+    static func biquadErrorDescription(_ kind: Int32) -> String {
+        switch kind {
+        case 1: return "Sample rate must be finite and positive."
+        case 2: return "Frequency must be finite, positive, and below Nyquist."
+        case 3: return "Q must be finite and positive."
+        case 4: return "Filter parameters must be finite."
+        default: return "Filter coefficients must be finite."
+        }
     }
 
     /// Control thread: destroys the processors the render thread has let go of (their deinit runs here, not in `process`).

@@ -48,7 +48,7 @@ def test_line_of_the_round5_result_is_short_and_complete(bench, full, tmp_path, 
     assert d["parity_spot_err"] < 1e-5
     for k in ("secondary", "secondary_cfg2"):
         s = d[k]
-        assert set(("value", "ms_per_step", "steps", "parity_spot_err")) <= set(s) and "frac" in s["roofline"] and "activation" not in s["config"]
+        assert set(("value", "ms_per_step", "steps", "parity_spot_err")) <= set(s) and "frac" in s["roofline"] and "activation" not in s["config"] and "workload" not in s["config"]
     assert [e["name"] for e in d["secondary_end_to_end"]] == ["cfg3", "cfg2"] and all(e["pageable_value"] < e["value"] for e in d["secondary_end_to_end"])
     # nothing is lost: the detail file holds the full result
     detail = json.load(open(tmp_path / bench.DETAIL_FILE))

@@ -176,3 +176,29 @@ def test_eq_needs_a_device_or_fails_loudly():
     with pytest.raises(aw.AirwaveError) as e:
         aw.ParametricEqualizerProcessor(48000.0)
     assert e.value.name == "NO_DEVICE"
+
+
+def test_invalid_filter_is_reported_with_index_kind_and_source_line():
+    """aw_last_eq_filter_error: the structured form of ParametricEqualizerPreparationError.invalidFilter(index:error:) plus the sourceLine
+    EqualizerRuntimeEffect.map looks up (EqualizerRuntimeEffect.swift:80-100) — the index counts ENABLED filters only.  Through the host-only
+    entry aw_eq_fold_hrir (the preparation checks are the same as aw_eq_state_create's, which needs a device)."""
+    import ctypes
+    import numpy as np
+    from airwave_amd import _capi
+    lib = _capi.load()
+    i, k, l = ctypes.c_int32(-1), ctypes.c_int32(-1), ctypes.c_int32(-1)
+    d = aw.EqualizerDefinition(0.0, [aw.EqualizerFilter(11, 1, True, 0, 1000.0, 3.0, 1.0),
+                                     aw.EqualizerFilter(12, 2, False, 0, -5.0, 3.0, 1.0),         # disabled: never validated, not counted
+                                     aw.EqualizerFilter(13, 3, True, 1, 100.0, 3.0, 0.0),         # Q = 0: invalidQ, second ENABLED filter
+                                     aw.EqualizerFilter(14, 4, True, 0, 99000.0, 3.0, 1.0)])
+    h = np.ones((1, 8), np.float32)
+    with pytest.raises(aw.ParametricEqualizerPreparationError) as e:
+        aw.fold_equalizer(h, d, 48000.0)
+    assert e.value.status == 16 and "Filter 2 is invalid: Q must be finite and positive." in str(e.value)
+    assert lib.aw_last_eq_filter_error(ctypes.byref(i), ctypes.byref(k), ctypes.byref(l)) == 1
+    assert (i.value, k.value, l.value) == (1, 3, 13)
+    # any other failing call on the thread clears it
+    with pytest.raises(aw.ParametricEqualizerPreparationError):
+        aw.fold_equalizer(h, None, -1.0)
+    assert lib.aw_last_eq_filter_error(ctypes.byref(i), ctypes.byref(k), ctypes.byref(l)) == 0
+    assert lib.aw_last_eq_filter_error(None, None, None) == 0

@@ -71,6 +71,9 @@ def test_default_line_with_driver_style_flags_carries_the_secondaries():
     c2 = d["secondary_cfg2"]
     assert c2["steps"] >= 100 and c2["warmup"] >= 40 and c2["config"]["name"] == "cfg2" and c2["parity_spot_err"] < 1e-5
     assert 0.15 < c2["roofline"]["frac"] < 0.40 and 0.12 < d["roofline"]["frac"] < 0.40
+    c14 = d["secondary_cfg2_14ch"]                     # north_star's literal layout on the on-chip tile (round 6: the overlap-add form)
+    assert c14["config"]["name"] == "cfg2-14ch" and c14["config"]["input_channels"] == 14 and c14["config"]["path"] == "fused overlap-add"
+    assert c14["parity_spot_err"] < 1e-5 and 0.15 < c14["roofline"]["frac"] < 0.40 and c2["config"]["path"] == "fused overlap-add"
     assert [e["name"] for e in d["secondary_end_to_end"]] == ["cfg3", "cfg2"]
     # traffic: the committed PMC profile of THESE device sources, or an explicit refusal that says why — never a stale number
     assert d["roofline"]["traffic"] is not None or "profile" in d["roofline"]["traffic_note"], d["roofline"]

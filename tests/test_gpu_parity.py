@@ -397,3 +397,63 @@ def test_streams_stay_independent_when_a_neighbour_holds_nan(aw, oracle, monkeyp
         for s in (0, 2):
             assert np.isfinite(y[s]).all(), (lw, s)
             assert oracle.peak_rel_error(y[s], oracle.spatialize_f64(x[s], h, lt, rt)[F:]) < TOL, (lw, s)
+
+
+def _write_float_wav(path, tracks, rate):
+    """[track][frame] float32 -> RIFF/WAVE, IEEE float, interleaved."""
+    import struct
+    n, frames = tracks.shape
+    data = np.ascontiguousarray(tracks.T).astype("<f4").tobytes()
+    block = n * 4
+    body = b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 3, n, rate, rate * block, block, 32) + b"data" + struct.pack("<I", len(data)) + data
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+@pytest.mark.parametrize("speakers", [2, 6, 8, ["FL", "FR", "FC", "BL", "BR", "SL", "SR"], ["FC", "LFE"]])
+def test_seven_track_hrir_through_preset_activation(aw, oracle, tmp_path, speakers):
+    """A11 end to end: a 7-track (left-ear-only) HeSuVi file takes hesuvi7Channel (HRIRManager.swift:355-360) — FL = (0, 1) but
+    FR = (1, 0): the right speakers reuse the left-ear tracks mirrored; FC and LFE both read track 2 for BOTH ears; BL / BR = (3, 4) /
+    (4, 3), SL / SR = (5, 6) / (6, 5) (VirtualSpeaker.swift:224-250).  Audio through aw_preset_activate against the oracle's own
+    assembly of the same file and the float64 truth, with distinct seeded tracks so that any swapped or shared index shows."""
+    h = oracle.synth_hrir(7, 1500, seed=77)
+    path = str(tmp_path / "seven.wav")
+    _write_float_wav(path, h, 48000)
+    layout = aw.InputLayout.detect(speakers) if isinstance(speakers, int) else aw.InputLayout(speakers, "custom")
+    names = list(layout.channels)
+    mgr = aw.HRIRManager()
+    sp = mgr.activatePreset(path, 48000.0, layout, n_streams=2)
+    assert mgr.isReady
+    w = oracle.wav_load(path)
+    assert w.channel_count == 7 and np.array_equal(w.audio_data, h)
+    tracks, lt, rt = oracle.assemble_tracks(w, names)
+    want = {"FL": (0, 1), "FR": (1, 0), "FC": (2, 2), "LFE": (2, 2), "BL": (3, 4), "BR": (4, 3), "SL": (5, 6), "SR": (6, 5)}
+    assert [(int(a), int(b)) for a, b in zip(lt, rt)] == [want[s] for s in names]
+    x = oracle.synth_input(2, 20011, len(names), seed=5)
+    y = sp.process(x)
+    for s in range(2):
+        assert oracle.peak_rel_error(y[s], oracle.spatialize_f64(x[s], tracks, lt, rt)) < TOL
+    assert oracle.peak_rel_error(y[1, :6000], oracle.spatialize_f32(x[1:2, :6000], tracks, lt, rt)[0]) < TOL
+    if "FC" in names and "LFE" in names:
+        # FC and LFE share track 2 for both ears: swapping the two input channels changes nothing, and both ears get the same signal from them
+        i, j = names.index("FC"), names.index("LFE")
+        xs = np.zeros_like(x)
+        xs[:, :, i], xs[:, :, j] = x[:, :, j], x[:, :, i]
+        sp.reset()
+        a = sp.process(xs)
+        xo = np.zeros_like(x)
+        xo[:, :, i], xo[:, :, j] = x[:, :, i], x[:, :, j]
+        sp.reset()
+        b = sp.process(xo)
+        assert np.allclose(a, b, rtol=0, atol=2e-6 * np.abs(b).max()) and np.allclose(b[..., 0], b[..., 1], rtol=0, atol=2e-6 * np.abs(b).max())
+    if "FL" in names and "FR" in names:
+        # FR is FL mirrored: the same signal on FR alone gives FL's output with the ears exchanged
+        i, j = names.index("FL"), names.index("FR")
+        xl, xr = np.zeros_like(x), np.zeros_like(x)
+        xl[:, :, i] = x[:, :, 0]
+        xr[:, :, j] = x[:, :, 0]
+        sp.reset()
+        yl = sp.process(xl)
+        sp.reset()
+        yr = sp.process(xr)
+        assert np.allclose(yl[..., 0], yr[..., 1], rtol=0, atol=2e-6 * np.abs(yl).max()) and np.allclose(yl[..., 1], yr[..., 0], rtol=0, atol=2e-6 * np.abs(yl).max())

@@ -69,3 +69,45 @@ def test_boxes_retain_their_context_and_the_package_builds_where_the_library_exi
     assert "pthread_mutex_trylock" in lock and "canImport(Glibc)" in lock
     act = _body(sp, "public func activatePreset(")
     assert re.search(r"guard aw_spatializer_reserve\(.*== AW_OK else", act)       # a failed reserve is an activation failure
+
+
+def test_equalizer_effect_has_the_protocols_shape_and_maps_errors_like_the_reference():
+    """AudioEqualizerEffect (AudioEffectGraph.swift:51-54): prepare(definition:sampleRate:) / setTarget(definition:) over a definition
+    that mirrors EqualizerPreset.swift:9-27 field for field (sourceLine / sourceNumber included), and the error mapping of
+    EqualizerRuntimeEffect.swift:80-100: .invalidFilter(line:reason:) with the sourceLine of the enabled filter the library names."""
+    src = open(EQ).read()
+    assert re.search(r"public func prepare\(definition: HIPEqualizerDefinition\?, sampleRate: Double\) throws", src)
+    assert re.search(r"public func setTarget\(definition: HIPEqualizerDefinition\?\) throws", src)
+    assert "preampDB: Double?, filters:" not in src                                  # round 5's shape is gone
+    flt = _body(src, "public struct HIPEqualizerFilter")
+    for field in ("let sourceLine: Int", "let sourceNumber: Int?", "let isEnabled: Bool", "let type: HIPEqualizerFilterType",
+                  "let frequencyHz: Double", "let gainDB: Double", "let q: Double"):
+        assert field in flt, field
+    d = _body(src, "public struct HIPEqualizerDefinition")
+    assert "let preampDB: Double" in d and "let filters: [HIPEqualizerFilter]" in d and "preampDB: Double = 0, filters: [HIPEqualizerFilter] = []" in d
+    err = _body(src, "public enum HIPEqualizerError")
+    assert "case invalidFilter(line: Int?, reason: String)" in err and "case invalidSampleRate" in err and "case unavailable(String)" in err
+    assert "var filterLine: Int?" in err
+    # the definition handed to the library carries the source lines; the mapping reads the structured error, not the message text
+    mk = _body(src, "static func makeDefinitionHandle(")
+    assert "aw_eq_definition_set_source" in mk and "f.sourceLine" in mk and "f.sourceNumber ?? -1" in mk
+    m = _body(src, "static func map(")
+    assert "aw_last_eq_filter_error(&index, &kind, &line)" in m and "filter(\\.isEnabled)" in m and "enabled[Int(index)].sourceLine" in m
+    assert 'case AW_ERR_EQ_NON_FINITE_PREAMP:' in m and '"Preamp produces a non-finite gain."' in m
+    assert "Equalizer supports at most 64 filters; received" in m and "case AW_ERR_EQ_INVALID_SAMPLE_RATE:" in m
+    pub = _body(src, "private func publish(")
+    assert pub.index("Self.map(st") < pub.index("aw_eq_set_target(box.handle, nil)")    # the error state is read before the unity fallback replaces it
+    desc = _body(src, "static func biquadErrorDescription(")
+    for text in ("Sample rate must be finite and positive.", "Frequency must be finite, positive, and below Nyquist.", "Q must be finite and positive.",
+                 "Filter parameters must be finite.", "Filter coefficients must be finite."):
+        assert text in desc                                                          # BiquadCoefficientBuilder.swift:18-26
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "final class HIPEqualizerEffectAdapter: AudioEqualizerEffect" in integ and "func prepare(definition: EqualizerDefinition?, sampleRate: Double) throws" in integ
+    assert "EqualizerAudioEffectError.invalidFilter(line: line, reason: reason)" in integ
+
+
+def test_batch_spatializer_folds_a_known_equalizer():
+    src = open(os.path.join(ROOT, "swift", "AirwaveHIP", "Sources", "AirwaveHIP", "BatchSpatializer.swift")).read()
+    init = _body(src, "public init(context: HIPContext, tracks:")
+    assert "equalizer: HIPEqualizerDefinition? = nil" in src and init.count("aw_eq_fold_hrir(") == 2       # the length, then the tracks
+    assert "aw_eq_definition_destroy(def)" in init and "foldedEqualizer = (Int(response), bound)" in init
