@@ -53,6 +53,6 @@ for k, v in by_kernel.items():
 r = line["roofline"]
 print("bench:", round(line["value"] / 1e9, 2), "G frames/s, frac", round(r["frac"], 4), "frac_of_measured", r.get("frac_of_measured"), r.get("measured"), r["stages_ms_per_step"])
 if "secondary" in line:
-    s2 = line["secondary"]; print("secondary:", round(s2["value"] / 1e9, 2), "G frames/s, frac", round(s2["roofline"]["frac"], 4), s2["roofline"]["stages_ms_per_step"])
+    s2 = line["secondary"]; print("secondary:", round(s2["value"] / 1e9, 2), "G frames/s, frac", round(s2["roofline"]["frac"], 4), s2["roofline"].get("stages_ms_per_step", "(bench_detail.json)"))
 if "cpu_baseline" in line:
     print("cpu:", line["cpu_baseline"])
