@@ -27,6 +27,7 @@
 //
 // Shared with the CPU thread-emulation harness (tests/emu/): the Ctx supplies buf() / buf_ld<N>().
 #pragma once
+#include <utility>
 #include "tile_ols.hpp"
 
 namespace awk {
@@ -46,6 +47,12 @@ template <int NP> struct OlaEarly { static constexpr bool value = NP >= 7; };
 #ifndef AW_OLA_TABG
 #define AW_OLA_TABG 0                  // table entries per part (pair_subfft_cmac_h): 0 = per layout (8 from seven pairs, else 16)
 #endif
+#ifndef AW_OLA_TAB_EARLY
+#define AW_OLA_TAB_EARLY 0             // bit 0: layouts of up to four pairs request a pair's tables before its row transform
+#endif
+#ifndef AW_OLA_PREFETCH_MID
+#define AW_OLA_PREFETCH_MID 0          // 1: the next block's frames are requested right behind the block's last table request (ola_subfft_cmac)
+#endif
 
 // One block of one stream: frames idx0 + t + 512 j (j < H) of the source behind `src`, every channel, into raw[j][*].
 // idx is relative to the descriptor's first row and may be negative (history blocks reach before the first kept row): those
@@ -53,6 +60,13 @@ template <int NP> struct OlaEarly { static constexpr bool value = NP >= 7; };
 template <int CS, int H, class Ctx>
 AW_HD void ola_load_block(Ctx &ctx, const typename Ctx::Buf &src, int idx0, int t, float (&raw)[H][2 * ((CS + 1) / 2)]) {
     constexpr int CP = 2 * ((CS + 1) / 2);
+#ifdef AW_ABL_OLA_NOLOAD       // timing ablation only (wrong results): no frame loads
+#pragma unroll
+    for (int j = 0; j < H; ++j)
+#pragma unroll
+        for (int c = 0; c < CP; ++c) raw[j][c] = 0.001f * (float)(t + c) + (float)idx0 + 0.5f * j;
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < H; ++j) {
         const int idx = idx0 + t + 512 * j;
@@ -100,6 +114,64 @@ AW_HD void ola_pass1(const cf (&xin)[H], const cf (&pw)[16], cf *buf, int t) {
     for (int k1 = 0; k1 < 16; ++k1) buf[k1 * kRowStride + t] = v[k1];
 }
 
+// Row transforms + multiply-accumulate of one pair (pair_subfft_cmac_h of tile_ols.hpp) with two hooks for this tile:
+//   TAB_EARLY  the pair's 16 table entries were requested by the caller BEFORE the row transform (64 VGPRs that the overlap-save tile,
+//              with 128 registers of frames, never had): they travel under the transform instead of being waited for after it;
+//   PREFETCH   right behind the pair's LAST table request, the next block's frame loads are queued into `raw` — vector-memory
+//              results return in issue order, so frames requested before a table load would hold that load's consumer up for an HBM
+//              round trip, frames requested after the last one delay nobody.
+template <int N, class F, int... I> AW_HD void ola_static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> AW_HD void ola_static_for(F &&f) { ola_static_for_impl<N>(static_cast<F &&>(f), std::make_integer_sequence<int, N>{}); }
+
+template <class Buf> struct OlaNext { Buf src; int idx0; };     // the next block's source and first row (wave-uniform)
+template <int G, bool TAB_EARLY, bool PREFETCH, int CS, int H, class Ctx>
+AW_HD void ola_subfft_cmac(Ctx &ctx, const TileParams &p, int pair, cf *buf, const cf *twa, cf2 (&tab)[16], int lane, int wave, cf (&wacc)[16],
+                           const OlaNext<typename Ctx::Buf> &next, int t, float (&raw)[H][2 * ((CS + 1) / 2)]) {
+    static_assert(!TAB_EARLY || G == 16, "early tables come whole");
+    const HLane L = hl_make(ctx, buf, twa, lane, wave);
+    auto after = [&] { if constexpr (PREFETCH) ola_load_block<CS, H>(ctx, next.src, next.idx0, t, raw); };
+    if constexpr (TAB_EARLY) after();
+    cf z[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) z[j] = ctx.ld(L.row + L.h + 32 * j);
+    sub_fft512h_fwd(ctx, z, L);
+    if constexpr (G == 16) { if constexpr (!TAB_EARLY) { load_tab_h(p, pair, wave, lane, tab); after(); } }
+    else load_tab_part_h<G>(p, pair, wave, lane, 0, tab);
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) L.row[L.col + 32 * kb] = z[kb];
+    ctx.wave_sync();
+    if constexpr (G == 16) {
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            int idx = L.pidx - 32 * kb;
+            if (kb == 0) idx &= 511;                               // only (row 0, column 0) wraps: 512 -> 0
+            const cf zp = ctx.ld(L.prow + idx);
+            wacc[kb] = cfma(z[kb], tab[kb].a, wacc[kb]);
+            wacc[kb] = cfmac(zp, tab[kb].b, wacc[kb]);
+        }
+    } else {
+        static_assert(2 * G <= 16, "two parts in flight inside tab[16]");
+#pragma unroll
+        for (int part = 0; part < 16 / G; ++part) {
+            cf2 *cur = tab + G * (part & 1);
+            if (part + 1 < 16 / G) {
+                load_tab_part_h<G>(p, pair, wave, lane, part + 1, tab + G * ((part + 1) & 1));
+                if (part + 2 == 16 / G) after();
+            }
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int kb = G * part + i;
+                int idx = L.pidx - 32 * kb;
+                if (kb == 0) idx &= 511;
+                const cf zp = ctx.ld(L.prow + idx);
+                wacc[kb] = cfma(z[kb], cur[i].a, wacc[kb]);
+                wacc[kb] = cfmac(zp, cur[i].b, wacc[kb]);
+            }
+        }
+    }
+    ctx.wave_sync();    // partner reads done before this wave reuses its rows as scratch
+}
+
 // where a run's next block comes from (all wave-uniform)
 struct OlaCursor {
     long long id;          // first tile id of the launch order that no segment has claimed yet
@@ -140,12 +212,15 @@ AW_HD void tiles_fused_ola(Ctx &ctx, const TileParams &p, long long first, long 
         c.id += n;
     };
     // a block's frames: input rows k hop + ..., or (k < 0) history rows hist_len + k hop + ...
-    auto load = [&](const OlaCursor &c, float (&raw)[H][CP]) {
+    auto source = [&](const OlaCursor &c) {
         const bool from_hist = c.k < 0;                                                        // uniform: blocks never straddle frame 0
         const float *base = from_hist ? p.hist + c.stream * (long long)p.hist_len * CS : p.in + c.stream * p.frames * CS;
         const unsigned bytes = (unsigned)((from_hist ? (long long)p.hist_len : p.frames) * (CS * 4));
-        const typename Ctx::Buf src = ctx.buf(base, bytes);
-        ola_load_block<CS, H>(ctx, src, c.k * hop + (from_hist ? p.hist_len : 0), t, raw);
+        return OlaNext<typename Ctx::Buf>{ctx.buf(base, bytes), c.k * hop + (from_hist ? p.hist_len : 0)};
+    };
+    auto load = [&](const OlaCursor &c, float (&raw)[H][CP]) {
+        const OlaNext<typename Ctx::Buf> s = source(c);
+        ola_load_block<CS, H>(ctx, s.src, s.idx0, t, raw);
     };
     begin_segment(cur);
     float raw[H][CP];
@@ -173,11 +248,15 @@ AW_HD void tiles_fused_ola(Ctx &ctx, const TileParams &p, long long first, long 
             else { begin_segment(nx); nx_fresh = true; }
         }
 
-        // batches of two pairs through buf0 / buf1, as tiles_fused_ols: pass 1 of both, barrier, row transforms + CMAC of each
-#pragma unroll
-        for (int b = 0; b < (NP + 1) / 2; ++b) {
-            const int pair0 = 2 * b;
-            const bool two = pair0 + 1 < NP;
+        // batches of two pairs through buf0 / buf1, as tiles_fused_ols: pass 1 of both, barrier, row transforms + CMAC of each.
+        // (a compile-time loop: which batch is the last one, and whether it has a second pair, select template instantiations)
+        const OlaNext<typename Ctx::Buf> nsrc = source(nx);
+        ola_static_for<(NP + 1) / 2>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            constexpr int pair0 = 2 * b;
+            constexpr bool two = pair0 + 1 < NP;
+            constexpr bool last_batch = b == (NP + 1) / 2 - 1;
+            constexpr bool kMid = AW_OLA_PREFETCH_MID != 0;
             if (b > 0) ctx.barrier();                    // every wave is done reading buf0 / buf1
             {
                 cf pw[16];
@@ -186,22 +265,27 @@ AW_HD void tiles_fused_ola(Ctx &ctx, const TileParams &p, long long first, long 
 #pragma unroll
                 for (int j = 0; j < H; ++j) x[j] = mk(raw[j][2 * pair0], raw[j][2 * pair0 + 1]);
                 ola_pass1<H>(x, pw, buf0, t);
-                if (two) {
+                if constexpr (two) {
 #pragma unroll
                     for (int j = 0; j < H; ++j) x[j] = mk(raw[j][2 * pair0 + 2], raw[j][2 * pair0 + 3]);
                     ola_pass1<H>(x, pw, buf1, t);
                 }
             }
             ctx.barrier();
-            if (OlaEarly<NP>::value && b == (NP + 1) / 2 - 1) load(nx, raw);      // every channel of this block has been through pass 1
+            if constexpr (!kMid && OlaEarly<NP>::value && last_batch) load(nx, raw);        // every channel of this block has been through pass 1
             constexpr int kTabG = AW_OLA_TABG ? AW_OLA_TABG : NP >= 7 ? 8 : 16;
+            constexpr bool kTabEarly = (AW_OLA_TAB_EARLY & 1) != 0 && NP <= 4 && kTabG == 16;
             cf2 tab[16];
-            pair_subfft_cmac_h<kTabG>(ctx, p, pair0, buf0, twa, tab, lane, wave, wacc, false);
-            if (two) pair_subfft_cmac_h<kTabG>(ctx, p, pair0 + 1, buf1, twa, tab, lane, wave, wacc, false);
-        }
+            if constexpr (kTabEarly) load_tab_h(p, pair0, wave, lane, tab);
+            ola_subfft_cmac<kTabG, kTabEarly, kMid && last_batch && !two, CS, H>(ctx, p, pair0, buf0, twa, tab, lane, wave, wacc, nsrc, t, raw);
+            if constexpr (two) {
+                if constexpr (kTabEarly) load_tab_h(p, pair0 + 1, wave, lane, tab);
+                ola_subfft_cmac<kTabG, kTabEarly, kMid && last_batch, CS, H>(ctx, p, pair0 + 1, buf1, twa, tab, lane, wave, wacc, nsrc, t, raw);
+            }
+        });
 
         tile_inverse_rows_h(ctx, wacc, buf0, twa);
-        if (!OlaEarly<NP>::value) load(nx, raw);       // few registers are live here; the last block re-reads its own frames (no branch around 100 registers)
+        if (!AW_OLA_PREFETCH_MID && !OlaEarly<NP>::value) load(nx, raw);       // few registers are live here; the last block re-reads its own frames (no branch around 100 registers)
 
         // radix-16 across rows: y[j] = block position t + 512 j; add the carry; j < H are frames, the rest is the new carry
         ctx.barrier();
@@ -223,7 +307,12 @@ AW_HD void tiles_fused_ola(Ctx &ctx, const TileParams &p, long long first, long 
             if (j < NC) y[j] = y[j] + carry[j];
             if (j < H) {
                 const long long f = f0 + t + 512 * j;
-                if (store && f < p.frames) ctx.st_stream(reinterpret_cast<cf *>(out_s + f * 2), y[j]);
+#ifdef AW_ABL_OLA_NOSTORE      // timing ablation only (wrong results): no output stores
+                if (store && f < p.frames && y[j].x == 1.2345e-30f)
+#else
+                if (store && f < p.frames)
+#endif
+                    ctx.st_stream(reinterpret_cast<cf *>(out_s + f * 2), y[j]);
             }
         }
 #pragma unroll

@@ -11,7 +11,7 @@ seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 240.0
 rng = np.random.default_rng(seed)
 TOL = 1e-5
-fails, n = [], 0
+fails, n, ola_used = [], 0, 0
 t_end = time.time() + budget
 while time.time() < t_end:
     C = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]))
@@ -46,7 +46,20 @@ while time.time() < t_end:
     # round 5: the host entry in chunks of streams (1-MB chunks: a few streams each, ragged last chunk) and the host table builder
     if rng.random() < 0.3: env["AW_HOST_CHUNK_MB"] = "1"
     if rng.random() < 0.15: env["AW_LW_TABLES"] = "host"
-    for k in ("AW_WINDOW", "AW_PART_FWD", "AW_PART_CMAC", "AW_PART_HERM", "AW_SPEC_SCRATCH_MB", "AW_LW", "AW_LW_ROWS_PB", "AW_LW_ROWS_FORM", "AW_HOST_CHUNK_MB", "AW_LW_TABLES"):
+    # round 6: the overlap-add tile (tile_ola.hpp) on calls of every size (AW_OLA_MIN_BLOCKS=0), wherever a kernel exists (AW_OLA=1) or
+    # by the policy, on few or many persistent workgroups (where the launch cuts the streams into runs); HRIR lengths around its block steps
+    r5 = rng.random()
+    if r5 < 0.45:
+        env["AW_OLA_MIN_BLOCKS"] = "0"
+        if rng.random() < 0.7: env["AW_OLA"] = "1"
+        if rng.random() < 0.5: env["AW_PERSISTENT_WGS"] = str(int(rng.choice([8, 9, 31, 100, 256])))
+        if rng.random() < 0.7:
+            C = int(rng.choice([4, 6, 7, 8, 10, 12, 14, 16]))
+            taps = int(rng.choice([3585, 3969, 4097, 4098, 4320, 4609, 4610, 5000, 5121, 5122, int(rng.integers(2, 5200))]))
+            env.pop("AW_WINDOW", None)
+            if env.get("AW_LW") not in (None, "0") and rng.random() < 0.7: env.pop("AW_LW")
+    elif r5 < 0.55: env["AW_OLA"] = "0"
+    for k in ("AW_WINDOW", "AW_PART_FWD", "AW_PART_CMAC", "AW_PART_HERM", "AW_SPEC_SCRATCH_MB", "AW_LW", "AW_LW_ROWS_PB", "AW_LW_ROWS_FORM", "AW_HOST_CHUNK_MB", "AW_LW_TABLES", "AW_OLA", "AW_OLA_MIN_BLOCKS", "AW_PERSISTENT_WGS"):
         os.environ.pop(k, None)
     os.environ.update(env)
     n_tracks = int(rng.choice([2, 7, 14]))
@@ -62,10 +75,11 @@ while time.time() < t_end:
     if os.environ.get("AW_FUZZ_TRACE"):
         print("CASE", C, taps, S, total, bounds, env, n_tracks, flush=True)
     try:
-        ctx = aw.Context(0) if any(k in env for k in ("AW_LW_ROWS_PB", "AW_LW_ROWS_FORM", "AW_HOST_CHUNK_MB", "AW_LW_TABLES")) else None        # (those knobs are read when a context is created)
+        ctx = aw.Context(0) if any(k in env for k in ("AW_LW_ROWS_PB", "AW_LW_ROWS_FORM", "AW_HOST_CHUNK_MB", "AW_LW_TABLES", "AW_OLA_MIN_BLOCKS", "AW_PERSISTENT_WGS")) else None        # (those knobs are read when a context is created)
         sp = aw.Spatializer(aw.HRIR(h, ctx=ctx), lt, rt, n_streams=S, ctx=ctx) if ctx else aw.Spatializer(aw.HRIR(h), lt, rt, n_streams=S)
-        info = sp.info()
         y = np.concatenate([sp.process(x[:, a:b]) for a, b in zip(bounds[:-1], bounds[1:])], axis=1)
+        info = sp.info()
+        ola_used += 1 if info.get("overlap_add_rows") else 0
         err = 0.0
         # the tolerance is relative to the output peak; a call of a few frames can have a peak far below the scale of the terms
         # that were summed (one frame: a single random dot product), so the peak is floored at a quarter of the typical output
@@ -83,4 +97,4 @@ while time.time() < t_end:
     if not ok:
         fails.append((C, taps, S, total, bounds, env, n_tracks, lt.tolist(), rt.tolist(), info, err))
         print("FAIL", fails[-1], flush=True)
-print(f"seed {seed}: {n} cases, {len(fails)} failures")
+print(f"seed {seed}: {n} cases ({ola_used} whose last call ran the overlap-add tile), {len(fails)} failures")
