@@ -25,7 +25,7 @@
 #pragma once
 #include "cplx.hpp"
 
-// Timing ablations (wrong results; tools/eq_ablate.sh only): bit 0 no recurrence, 1 no in-wave scan,
+// Timing ablations (wrong results; tools/archive/eq_ablate.sh only): bit 0 no recurrence, 1 no in-wave scan,
 // 2 no wave chaining, 3 no zero-input correction.
 #ifndef AW_EQ_ABL
 #define AW_EQ_ABL 0

@@ -97,7 +97,7 @@ hipError_t launch_eq_cascade(const EqParams &p, int n_streams, hipStream_t strea
     if (n_streams <= 0 || p.frames <= 0) return hipSuccess;
     // split the ears over two workgroups while the per-ear grid still fits the CUs in one round (three workgroups per CU):
     // 128 streams 2.34 -> 1.76 ms, 384 streams 3.80 -> 3.42 ms; 448 streams 3.92 vs 4.53 ms and 512 streams 4.14 vs 4.61 ms
-    // the other way (tools/ab_eq_split.sh)
+    // the other way (tools/archive/ab_eq_split.sh)
     const int cus = p.cus > 0 ? p.cus : 256, force = p.ear_split;       // from the context (read once at its creation)
     const bool split = force >= 0 ? force != 0 : 2 * n_streams <= 3 * cus;
     if (split)

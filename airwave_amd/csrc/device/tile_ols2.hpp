@@ -112,7 +112,7 @@ AW_HD void pair_subfft_cmac2(Ctx &ctx, const TileParams &p, int pair, cf *buf, c
     for (int j = 0; j < 8; ++j) { z[0][j] = ctx.ld(row0 + lane + 64 * j); z[1][j] = ctx.ld(row1 + lane + 64 * j); }
     ctx.wave_sync();
     // Row 0's table entries for both outputs are issued BEFORE the sub-FFTs (their L2 latency, ~2 k cycles each
-    // when exposed — phase stamps, tools/stamps2.py — hides under the three radix-8 passes); row 1's are issued
+    // when exposed — phase stamps, tools/archive/stamps2.py — hides under the three radix-8 passes); row 1's are issued
     // into the same registers as soon as row 0's are consumed.  64 table VGPRs in flight at most.
 #if defined(AW_ABL2) && (AW_ABL2 & 1)      // timing ablation only (wrong results): forward transform kept, CMAC phase dropped
     sub_fft512x2<false>(ctx, z, row0, row1, twa, twb, lane);

@@ -118,7 +118,7 @@ def load_hrir(name, taps: int):
 
 def committed_traffic(workload: str, S: int, F: int, C: int):
     """Fabric-side (L2 <-> Infinity Cache / HBM) bytes per step from the newest committed rocprofv3 PMC profile of this
-    same workload (profiles/*/traffic_<workload>.json, made by tools/profile_round5.sh: separate --pmc passes, read bytes
+    same workload (profiles/*/traffic_<workload>.json, made by tools/archive/profile_round5.sh: separate --pmc passes, read bytes
     from TCC_EA0_RDREQ_{32,64,128}B because FETCH_SIZE counts a 128-B request as 64 B on gfx950).  PMC counters cannot be
     collected from inside this process, so this is the last committed measurement — and only one made on THESE kernels: a
     profile records digests of csrc/device, of the host side of the library (runtime.cpp: launch policy, chunking; host/: table
@@ -426,7 +426,7 @@ def run_workload(name: str, args, ctx, world: int, rank: int, backend: str, with
             "traffic_source": os.path.relpath(tr[0], ROOT) if tr else None,
             "traffic_head": tr[1].get("git_head") if tr else None,
             "traffic_device_src_sha16": tr[1].get("device_src_sha16") if tr else None,
-            "traffic_note": ("committed profile of these very device sources, made on another box by tools/profile_round5.sh; not measured in this run"
+            "traffic_note": ("committed profile of these very device sources, made on another box by tools/archive/profile_round5.sh; not measured in this run"
                              if tr else tr_why),
         }
         if multi_kernel:

@@ -174,7 +174,7 @@ AW_API int32_t aw_spatializer_kernel_time(aw_spatializer *sp, double *avg_ms, co
  * returns 0.  total_ms / launches are over all calls; names are static strings. */
 AW_API int32_t aw_spatializer_stage_time(aw_spatializer *sp, int32_t index, const char **name, double *total_ms, int32_t *launches);
 
-/* Diagnostic builds only (library compiled with -DAW_STAMPS=1, see tools/stamps.py): copies the
+/* Diagnostic builds only (library compiled with -DAW_STAMPS=1, see tools/archive/stamps.py): copies the
  * per-workgroup phase time stamps of the last fused-kernel launch to host_out as
  * [workgroup][16] uint64 shader-clock values.  The shipped library returns AW_ERR_INVALID_ARGUMENT. */
 AW_API aw_status aw_spatializer_debug_stamps(aw_spatializer *sp, uint64_t *host_out, int64_t capacity_words,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns gpurun_out/profile_<name>/<workload>/ (tools/profile_round2.sh) into the committed files under profiles/<name>/:
+"""Turns gpurun_out/profile_<name>/<workload>/ (tools/archive/profile_round2.sh) into the committed files under profiles/<name>/:
 bench_<w>.json (the bench line), kernel_stats_<w>.csv (rocprofv3 --stats), traffic_<w>.json (per-kernel fabric-side bytes
 per step from the TCC_EA0 request counters + SQ counters; bench.py reads it for roofline.traffic)."""
 import collections, csv, glob, json, os, shutil, sys
