@@ -265,6 +265,30 @@ aw_status aw_context_timer_stop(aw_context *c, float *ms) try {
     return AW_OK;
 } AW_NOEXCEPT_TAIL
 
+// Grows the context's scratch pool to `need` complex elements (the caller holds launch_mu).  The pool is shared by every handle of the
+// context, so a failed growth must not take it away from handles that reserved it earlier (round-5 advice): the old size is allocated
+// again before the error is returned — if even that fails the pool is empty and the next process call of any handle allocates again (or
+// reports the same error).  hipFree waits for the device: launches of other handles that still read the old buffer have finished.
+static aw_status pool_grow(aw_context *c, size_t need) {
+    const size_t old = c->pool_capacity;
+    if (c->d_pool) AW_HIP_TRY(hipFree(c->d_pool));
+    c->d_pool = nullptr; c->pool_capacity = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_pool), need * sizeof(awk::cf));
+    if (e != hipSuccess) {
+        c->d_pool = nullptr;
+        if (old > 0 && hipMalloc(reinterpret_cast<void **>(&c->d_pool), old * sizeof(awk::cf)) == hipSuccess) {
+            c->device_allocs += 1;
+            c->pool_capacity = old;
+        } else {
+            c->d_pool = nullptr;
+        }
+        return awr::hip_fail(e, "scratch pool");
+    }
+    c->device_allocs += 1;
+    c->pool_capacity = need;
+    return AW_OK;
+}
+
 /* The context's scratch pool (runtime.hpp), sized ahead of time: a host that knows its largest batch pays the one large hipMalloc at
  * start-up (its wall time is erratic on these boxes: 0.2 ms ... 3.7 s, profiles/round5_v1/alloc_probe.txt) instead of inside the first
  * aw_spatializer_reserve / process that needs it.  Grow-only; bytes the pool already holds are kept. */
@@ -274,12 +298,7 @@ aw_status aw_context_reserve_scratch(aw_context *c, size_t bytes) try {
     std::lock_guard<std::mutex> lk(c->launch_mu);
     const size_t need = (bytes + sizeof(awk::cf) - 1) / sizeof(awk::cf);
     if (c->pool_capacity >= need) return AW_OK;
-    if (c->d_pool) AW_HIP_TRY(hipFree(c->d_pool));          // (hipFree waits for the device: nothing still reads the old buffer)
-    c->d_pool = nullptr; c->pool_capacity = 0;
-    AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_pool), need * sizeof(awk::cf)));
-    c->device_allocs += 1;
-    c->pool_capacity = need;
-    return AW_OK;
+    return pool_grow(c, need);
 } AW_NOEXCEPT_TAIL
 size_t aw_context_scratch_bytes(const aw_context *c) { return c ? c->pool_capacity * sizeof(awk::cf) : 0; }
 
@@ -900,13 +919,7 @@ static size_t part_budget(aw_spatializer *sp) {
 static aw_status part_ensure_scratch(aw_spatializer *sp, size_t need) {
     aw_context *c = sp->ctx;
     if (c->pool_capacity >= need) return AW_OK;
-    // (hipFree waits for the device: launches of other handles that still read the old buffer have finished)
-    if (c->d_pool) AW_HIP_TRY(hipFree(c->d_pool));
-    c->d_pool = nullptr; c->pool_capacity = 0;
-    AW_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_pool), need * sizeof(awk::cf)));
-    c->device_allocs += 1;
-    c->pool_capacity = need;
-    return AW_OK;
+    return pool_grow(c, need);
 }
 // the buffer a call inside what aw_spatializer_reserve() sized may count on (its stream chunk is clamped to it: never a reallocation)
 static size_t sp_held_scratch(const aw_spatializer *sp, int64_t frames) { return frames <= sp->reserved_frames ? sp->ctx->pool_capacity : 0; }

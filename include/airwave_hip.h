@@ -137,10 +137,15 @@ AW_API aw_status aw_spatializer_process(aw_spatializer *sp, const float *in_devi
 /* Same with HOST buffers; synchronous.  A multi-stream batch crosses PCIe in chunks of streams, double buffered on three HIP
  * streams (H2D of chunk k+1 || kernels of chunk k || D2H of chunk k-1; streams are independent, so chunks are); page-locked
  * buffers (aw_host_alloc_pinned) move by DMA directly, pageable ones are bounced through page-locked chunks by host copy threads.  Small batches and
- * single streams (the plug-in shaped calls of aw_engine_* / aw_realtime_*) go in one piece. */
+ * single streams (the plug-in shaped calls of aw_engine_* / aw_realtime_*) go in one piece.
+ * The call holds the context's launch lock from entry to return (other handles of the context wait for its whole PCIe time); on an
+ * error the contents of out_host are unspecified and the streams' state is that of a failed call: aw_spatializer_reset before reuse.
+ * Without aw_spatializer_reserve_host the first call also creates the pipeline's streams, events and copy threads. */
 AW_API aw_status aw_spatializer_process_host(aw_spatializer *sp, const float *in_host, float *out_host, int64_t frames);
 /* aw_spatializer_reserve plus the device-side staging of the host entry for calls of up to max_frames frames (two chunks
- * each way): afterwards aw_spatializer_process_host does not allocate either. */
+ * each way): afterwards aw_spatializer_process_host does not allocate either.  (The scratch pool is sized as aw_spatializer_reserve
+ * sizes it — for the whole batch — although the host entry only ever runs one staged chunk of streams at a time; AW_SPEC_SCRATCH_MB
+ * bounds it for hosts that never use the device entry.) */
 AW_API aw_status aw_spatializer_reserve_host(aw_spatializer *sp, int64_t max_frames);
 /* StereoAudioProcessing.process shape (AudioPipeline.swift:3-11) for a 1-stream, 2-channel
  * spatializer: planar HOST buffers, input_right may be NULL (mono duplication). Zero latency. */

@@ -143,6 +143,19 @@ class EqualizerDefinition {
     double preampDB() const { return aw_eq_definition_preamp_db(h_); }
     int filterCount() const { return aw_eq_definition_filter_count(h_); }
     const aw_eq_definition *get() const { return h_; }
+    // aw_eq_fold_hrir: this equalizer folded into HRIR tracks ([nTracks][taps] planar at sampleRate) — EQ(x * h) = x * (h * g), the spatial
+    // effect and the equalizer that follows it (AudioEffectGraph.swift:195-211) in one pass.  Returns [nTracks][outTaps]; throws
+    // aw::Error(AW_ERR_EQ_NOT_FOLDABLE) when the response does not decay within maxTaps - taps + 1 frames (run the cascade then).
+    struct Folded { std::vector<float> tracks; int taps; int responseTaps; double tailBound; };
+    Folded foldInto(const float *tracks, int nTracks, int taps, double sampleRate, double tailTolerance = 1e-7, int maxTaps = 65536) const {
+        Folded f{};
+        int32_t outTaps = 0, response = 0;
+        check(aw_eq_fold_hrir(h_, sampleRate, tracks, nTracks, taps, tailTolerance, maxTaps, nullptr, &outTaps, &response, &f.tailBound));
+        f.tracks.resize((size_t)nTracks * (size_t)outTaps);
+        check(aw_eq_fold_hrir(h_, sampleRate, tracks, nTracks, taps, tailTolerance, maxTaps, f.tracks.data(), &outTaps, &response, &f.tailBound));
+        f.taps = outTaps; f.responseTaps = response;
+        return f;
+    }
   private:
     explicit EqualizerDefinition(aw_eq_definition *d) : h_(d) {}
     aw_eq_definition *h_ = nullptr;

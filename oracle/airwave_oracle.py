@@ -727,7 +727,9 @@ def eq_prepare(definition: Optional[EqualizerDefinition], sample_rate: float) ->
     if not np.isfinite(sample_rate) or sample_rate <= 0:
         raise EqualizerPreparationError("invalidSampleRate")
     preamp = definition.preamp_db if definition else 0.0
-    if not np.isfinite(preamp) or not np.isfinite(10.0 ** (preamp / 20.0) if abs(preamp) < 1e4 else np.inf):
+    # pow(10, preampDB / 20) :176-179 — Python raises OverflowError where C returns +inf; a hugely NEGATIVE preamp underflows to 0, which is
+    # finite and accepted by the reference (found by tools/fuzz_host.py in round 6: the guard used to treat |preamp| >= 1e4 as infinite)
+    if not np.isfinite(preamp) or preamp / 20.0 > 308.0:
         raise EqualizerPreparationError("nonFinitePreamp")
     enabled = [f for f in (definition.filters if definition else []) if f.is_enabled]
     if len(enabled) > 64:

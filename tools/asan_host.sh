@@ -17,5 +17,5 @@ g++ -shared -fPIC -pthread -fsanitize=address,undefined -o airwave_amd/libairwav
     -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
 export LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)"
 export ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 AIRWAVE_HIP_LIBRARY=$PWD/airwave_amd/libairwave_hip_asan.so
-python -m pytest tests -q -m "not gpu" -x -k "capi or eq_host or data_model or mixed or effect or contract or abi" 2>&1 | tail -3
+python -m pytest tests -q -m "not gpu" -x -k "capi or eq_host or eq_fold_host or data_model or mixed or effect or contract or abi or provenance" 2>&1 | tail -3
 python tools/fuzz_host.py --seconds "${1:-60}" 2>&1 | grep -v RuntimeWarning | grep -v "astype" | tail -3

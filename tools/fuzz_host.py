@@ -183,6 +183,36 @@ def fuzz_numeric(rng, stats):
     stats["numeric"] += 1
 
 
+def fuzz_fold(rng, stats):
+    """aw_eq_fold_hrir (round 6): random definitions, track shapes, tolerances and length limits.  Either the documented refusals /
+    preparation errors, or folded tracks that equal the oracle's recurrence over the zero-extended tracks bit for bit."""
+    stats["fold"] += 1
+    vals = [20.0, 60.0, 105.0, 1000.0, 9000.0, 0.0, -3.0, 0.7, 1.41, 12.0, 30.0, 23999.0, 24000.0, 1e9, float("nan"), float("inf"), 1e-300]
+    n_f = rng.choice([0, 1, 2, 3, 10, 64, 65])
+    filters = [aweq.EqualizerFilter(i + 1, i + 1, rng.random() < 0.85, rng.randrange(0, 3), rng.choice(vals) if rng.random() < 0.03 else rng.uniform(20, 20000),
+                                    rng.uniform(-12, 12), rng.choice(vals) if rng.random() < 0.03 else rng.uniform(0.3, 6)) for i in range(n_f)]
+    d = None if rng.random() < 0.05 else aweq.EqualizerDefinition(rng.choice([0.0, -6.0, 3.5, float("nan"), 1e4, -1e4]) if rng.random() < 0.1 else rng.uniform(-12, 6), filters)
+    rate = rng.choice([44100.0, 48000.0, 96000.0, 48000.0, 96000.0, 8000.0, 0.0, float("nan")])
+    n, taps = rng.randrange(1, 4), rng.choice([1, 2, 7, 64, 300])
+    h = np.asarray([[rng.uniform(-1, 1) for _ in range(taps)] for _ in range(n)], dtype=np.float32)
+    tol = rng.choice([1e-7, 1e-5, 1e-3, 1e-10])
+    max_taps = rng.choice([taps, taps + 1, 400, 4096, 65536])
+    try:
+        f = aw.fold_equalizer(h, d, rate, tailTolerance=tol, maxTaps=max_taps)
+    except aw.EqualizerNotFoldable:
+        stats["fold_refused"] += 1
+        return
+    except aweq.ParametricEqualizerPreparationError:
+        stats["fold_invalid"] += 1
+        return
+    assert f.tracks.shape == (n, taps + f.responseTaps - 1) and f.tracks.shape[1] <= max_taps and 0.0 <= f.tailBound <= tol, (f.tracks.shape, f.tailBound)
+    od = None if d is None else orc.EqualizerDefinition(d.preampDB, [orc.EqualizerFilter(x.sourceLine, x.sourceNumber, x.isEnabled, x.type, x.frequencyHz, x.gainDB, x.q) for x in d.filters])
+    x = np.zeros(f.tracks.shape[1], np.float32)
+    x[:taps] = h[0]
+    want, _ = orc.eq_prepare(od, rate).process(x, x.copy())
+    assert np.array_equal(f.tracks[0], want), "folded track differs from the oracle's recurrence"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
@@ -196,7 +226,7 @@ def main():
                  "# comment\nfl=0,7\n\nFR = 8 , 1 # trailing\nTFL = 10,11\nbogus line\nFC=x,1\n", "FL=4294967296,1\nFR=-1,2\n"]
     apo_seeds = [open(os.path.join(GOLDEN, "eq", n), "rb").read() for n in sorted(os.listdir(os.path.join(GOLDEN, "eq"))) if n.endswith(".txt")] or \
                 [b"Preamp: -6.2 dB\nFilter 1: ON PK Fc 100 Hz Gain -3.5 dB Q 1.41\nFilter 2: ON LSC Fc 105 Hz Gain 5 dB Q 0.7\n"]
-    stats = {k: 0 for k in ("wav", "wav_decoded", "wav_library_stricter", "wav_category_differs", "map", "map_refused", "apo", "numeric")}
+    stats = {k: 0 for k in ("wav", "wav_decoded", "wav_library_stricter", "wav_category_differs", "map", "map_refused", "apo", "numeric", "fold", "fold_refused", "fold_invalid")}
     t0 = time.time()
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "f.wav")
@@ -205,6 +235,7 @@ def main():
             fuzz_text_map(rng, map_seeds, stats)
             fuzz_apo(rng, apo_seeds, stats)
             fuzz_numeric(rng, stats)
+            fuzz_fold(rng, stats)
     print("fuzz_host:", " ".join(f"{k}={v}" for k, v in stats.items()), f"library={os.environ.get('AIRWAVE_HIP_LIBRARY', 'default')}", "OK")
 
 
