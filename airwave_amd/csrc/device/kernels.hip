@@ -165,6 +165,7 @@ hipError_t prepare_kernels(LaunchCfg *cfg) {
         if (const char *e10 = getenv("AW_LW_ROWS16_WGS")) cfg->lw_rows16_wgs = atoi(e10) >= 1 && atoi(e10) <= 4 ? atoi(e10) : cfg->lw_rows16_wgs;
         if (const char *e12 = getenv("AW_LW_TABLES")) cfg->lw_tables_on_gpu = std::strcmp(e12, "host") == 0 ? 0 : 1;
         if (const char *e13 = getenv("AW_OLA_MIN_BLOCKS")) cfg->ola_min_blocks_per_wg = atoi(e13) >= 0 ? atoi(e13) : cfg->ola_min_blocks_per_wg;
+        if (const char *e14 = getenv("AW_HOST_OUT_ASYNC")) cfg->host_out_async = atoi(e14) != 0;
         if (const char *e11 = getenv("AW_HOST_CHUNK_MB")) cfg->host_chunk_mb = atoi(e11) >= 1 ? atoi(e11) : cfg->host_chunk_mb;
     }
 #define AW_SET_VEC(CS, NP)                                                                           \

@@ -88,6 +88,7 @@ struct LaunchCfg {
     int hop_align = 64;           // fused windows start on multiples of this many frames (AW_HOP_ALIGN; 1 = off)
     int lw_tables_on_gpu = 1;     // long-window filter tables built by the prep kernels (prep_kernels.hip); 0 = the float64 host builder (AW_LW_TABLES=host)
     int ola_min_blocks_per_wg = -1; // overlap-add tile: calls with fewer blocks per persistent workgroup run the overlap-save tile (AW_OLA_MIN_BLOCKS; -1 = per layout, runtime.cpp ola_min_blocks(); 0 = always the overlap-add tile)
+    int host_out_async = 1;       // host entry on pageable buffers: the copy OUT of a chunk runs on output copy threads beside the next copy IN (AW_HOST_OUT_ASYNC=0: on the driver thread, round 5's form)
     int host_chunk_mb = 96;       // host entry of a multi-stream batch: input megabytes per staged chunk of streams (AW_HOST_CHUNK_MB; a few ms of PCIe Gen5 = the pipeline's fill / drain)
 };
 hipError_t prepare_kernels(LaunchCfg *cfg);   // fills cfg from the current device + environment; sets the dynamic-LDS attribute on every tile kernel

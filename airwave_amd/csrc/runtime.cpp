@@ -66,6 +66,30 @@ struct aw_context::CopyPool {
             }
         }
     }
+    // start() hands a buffer to the workers and returns; wait() blocks until it is copied (a pool with no worker copies in wait()).  One
+    // job at a time per pool: the host entry uses a second, smaller pool for the output direction so that the copy OUT of chunk k-1 runs
+    // beside the copy IN of chunk k+1 instead of after it on the driver thread (round 6).
+    void start(void *d, const void *s_, size_t n) {
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return done == n_slices; });
+        if (n == 0) return;
+        dst = static_cast<char *>(d); src = static_cast<const char *>(s_); bytes = n;
+        const int parts = (int)std::min<size_t>(std::max<size_t>(workers.size(), 1), std::max<size_t>(1, n >> 20));
+        slice = ((n + parts - 1) / parts + 4095) & ~(size_t)4095;
+        n_slices = (int)((n + slice - 1) / slice); next = 0; done = 0; ++gen;
+        cv_work.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        int i;
+        while (workers.empty() && take(i)) {          // no thread could be started: the waiter does the work
+            lk.unlock();
+            slice_copy(i);
+            lk.lock();
+            ++done;
+        }
+        cv_done.wait(lk, [&] { return done == n_slices; });
+    }
     void copy(void *d, const void *s_, size_t n) {
         if (n == 0) return;
         std::unique_lock<std::mutex> lk(m);
@@ -224,6 +248,7 @@ void aw_context_destroy(aw_context *c) {
     if (c->d_zeros) (void)hipFree(c->d_zeros);
     if (c->d_pool) (void)hipFree(c->d_pool);
     delete c->copy_pool;
+    delete c->copy_pool_out;
     if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
     if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
     for (int i = 0; i < 2; ++i) {
@@ -1421,6 +1446,9 @@ static aw_status host_pipeline_objects(aw_context *c) {
         const unsigned hw = std::thread::hardware_concurrency();
         c->copy_pool = new (std::nothrow) aw_context::CopyPool((int)std::min(12u, std::max(1u, hw / 4)));
         if (!c->copy_pool) return fail(AW_ERR_OUT_OF_MEMORY, "copy threads");
+        // the output direction moves a quarter or less of the input's bytes (8 against 4 C per frame): a few threads of its own
+        c->copy_pool_out = new (std::nothrow) aw_context::CopyPool((int)std::min(4u, std::max(1u, hw / 8)));
+        if (!c->copy_pool_out) return fail(AW_ERR_OUT_OF_MEMORY, "copy threads");
     }
     // (a failure half-way leaves what exists in place: the next call makes the rest, aw_context_destroy frees whatever is there)
     if (!c->s_h2d) AW_HIP_TRY(hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
@@ -1502,10 +1530,16 @@ aw_status aw_spatializer_process_host(aw_spatializer *sp, const float *in, float
     int k = 0;
     int64_t prev_s0 = -1; int prev_ns = 0;
     hipError_t he = hipSuccess;
-    auto drain_prev = [&](int slot_prev) {          // chunk k-1's output: wait for its D2H, then copy it to the caller's buffer
+    // chunk k-1's output: wait for its D2H, then hand it to the output copy threads (they work while this thread copies chunk k+1 IN;
+    // the bounce slot is waited for before a later D2H is queued into it, and once more at the end)
+    auto drain_prev = [&](int slot_prev) {
         if (!page_out || prev_s0 < 0 || he != hipSuccess) return;
         he = hipEventSynchronize(c->ev_d2h[slot_prev]);
-        if (he == hipSuccess) c->copy_pool->copy(out + (size_t)prev_s0 * out_ps, sp->h_bounce_out + (size_t)slot_prev * cs * out_ps, (size_t)prev_ns * out_ps * sizeof(float));
+        if (he != hipSuccess) return;
+        float *d = out + (size_t)prev_s0 * out_ps; const float *b = sp->h_bounce_out + (size_t)slot_prev * cs * out_ps;
+        const size_t n = (size_t)prev_ns * out_ps * sizeof(float);
+        if (c->cfg.host_out_async) c->copy_pool_out->start(d, b, n);
+        else c->copy_pool->copy(d, b, n);            // AW_HOST_OUT_ASYNC=0 (A/B): round 5's form, on the driver thread
     };
     for (int64_t s0 = 0; s0 < sp->n_streams && he == hipSuccess; s0 += cs, ++k) {
         const int ns = (int)std::min<int64_t>(cs, sp->n_streams - s0), slot = k & 1;
@@ -1528,16 +1562,19 @@ aw_status aw_spatializer_process_host(aw_spatializer *sp, const float *in, float
         if (st != AW_OK) break;
         he = hipEventRecord(c->ev_run[slot], c->stream);
         if (he == hipSuccess) he = hipStreamWaitEvent(c->s_d2h, c->ev_run[slot], 0);
-        float *dst = page_out ? sp->h_bounce_out + (size_t)slot * cs * out_ps : out + (size_t)s0 * out_ps;   // (bounce slot: chunk k-2's copy-out finished on this thread)
+        if (page_out) c->copy_pool_out->wait();          // chunk k-2's copy-out has left this bounce slot (it had a whole chunk's time)
+        float *dst = page_out ? sp->h_bounce_out + (size_t)slot * cs * out_ps : out + (size_t)s0 * out_ps;
         if (he == hipSuccess) he = hipMemcpyAsync(dst, d_out, (size_t)ns * out_ps * sizeof(float), hipMemcpyDeviceToHost, c->s_d2h);
         if (he == hipSuccess) he = hipEventRecord(c->ev_d2h[slot], c->s_d2h);
         drain_prev(slot ^ 1);
         prev_s0 = s0; prev_ns = ns;
     }
     const hipError_t e1 = hipStreamSynchronize(c->s_h2d), e2 = hipStreamSynchronize(c->stream), e3 = hipStreamSynchronize(c->s_d2h);
+    if (page_out && (st != AW_OK || he != hipSuccess)) c->copy_pool_out->wait();       // no copy thread outlives the call
     if (st != AW_OK) return st;          // (a failed chunk: the streams are drained, the history has not been flipped)
     AW_HIP_TRY(he); AW_HIP_TRY(e1); AW_HIP_TRY(e2); AW_HIP_TRY(e3);
     drain_prev((k - 1) & 1);             // the last chunk's output
+    if (page_out) c->copy_pool_out->wait();
     AW_HIP_TRY(he);
     sp->hist_cur ^= 1;
     return AW_OK;

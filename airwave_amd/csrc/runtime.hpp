@@ -57,6 +57,7 @@ struct aw_context {
     std::atomic<long long> sync_copies{0};                          // blocking hipMemcpy calls likewise (table uploads)
     // host-entry pipeline (aw_spatializer_process_host on a multi-stream batch): H2D of chunk k+1 || kernels of chunk k || D2H of chunk k-1
     struct CopyPool;                                                // a few host threads that copy slices of one buffer at a time (runtime.cpp)
+    CopyPool *copy_pool_out = nullptr;                              // a second, smaller pool for the output direction (copy OUT of chunk k-1 beside copy IN of chunk k+1)
     CopyPool *copy_pool = nullptr;                                  // made with the pipeline objects; pageable caller buffers are bounced through page-locked chunks by it
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_run[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
