@@ -50,6 +50,15 @@ template <int NP> struct OlaEarly { static constexpr bool value = NP >= 7; };
 #ifndef AW_OLA_TAB_EARLY
 #define AW_OLA_TAB_EARLY 0             // bit 0: layouts of up to four pairs request a pair's tables before its row transform
 #endif
+#ifndef AW_OLA_PAIR2
+#define AW_OLA_PAIR2 0                 // 1: layouts of up to four pairs run the two pairs of a batch through the row transforms together (ola_subfft_cmac2)
+#endif
+#ifndef AW_OLA_PAIR2_G
+#define AW_OLA_PAIR2_G 4
+#endif
+#ifndef AW_OLA_PAIR2_MAXNP
+#define AW_OLA_PAIR2_MAXNP 4
+#endif
 #ifndef AW_OLA_PREFETCH_MID
 #define AW_OLA_PREFETCH_MID 0          // 1: the next block's frames are requested right behind the block's last table request (ola_subfft_cmac)
 #endif
@@ -172,6 +181,77 @@ AW_HD void ola_subfft_cmac(Ctx &ctx, const TileParams &p, int pair, cf *buf, con
     ctx.wave_sync();    // partner reads done before this wave reuses its rows as scratch
 }
 
+// Two pairs of a batch through the row transforms and the multiply-accumulate TOGETHER (AW_OLA_PAIR2): the same instruction sequence as
+// ola_subfft_cmac, with every step issued for both pairs before the wave waits — pair p in buf0, pair p + 1 in buf1, so the exchanges do
+// not collide — which halves the number of LDS round trips a wave sits through per pair (the tile is bound by that chain, not by its
+// butterflies: tools/ubench/ola_bench with AW_ABL_NOFFT runs no faster) and shares the row twiddles between the two transforms.
+// 32 more VGPRs for the second spectrum and table parts of four entries for both pairs: layouts of up to four pairs only.
+template <int G, class Ctx>
+AW_HD void ola_subfft_cmac2(Ctx &ctx, const TileParams &p, int pair, cf *buf_a, cf *buf_b, const cf *twa, int lane, int wave, cf (&wacc)[16]) {
+    static_assert(G == 4 || G == 8, "table parts in flight for two pairs");
+    const HLane La = hl_make(ctx, buf_a, twa, lane, wave), Lb = hl_make(ctx, buf_b, twa, lane, wave);
+    cf za[16], zb[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { za[j] = ctx.ld(La.row + La.h + 32 * j); zb[j] = ctx.ld(Lb.row + Lb.h + 32 * j); }
+    // sub_fft512h_fwd for both (tile_ols.hpp), step by step
+    fft16<false>(za);
+    fft16<false>(zb);
+#pragma unroll
+    for (int m = 1; m < 16; m += 8) {                 // row twiddles w_512^{h ka}: one LDS read serves both transforms
+        cf w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (m + i < 16) w[i] = ctx.ld(La.twh + 32 * (m + i));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (m + i < 16) { za[m + i] = twmul<false>(za[m + i], w[i]); zb[m + i] = twmul<false>(zb[m + i], w[i]); }
+    }
+    const cf w32 = ctx.opaque(La.w32);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        ctx.xswap(za[q], za[q + 8], 4);
+        ctx.xswap(zb[q], zb[q + 8], 4);
+        const cf ea = za[q] + za[q + 8], oa = za[q] - za[q + 8];
+        const cf eb = zb[q] + zb[q + 8], ob = zb[q] - zb[q + 8];
+        za[q] = ea; za[q + 8] = cmul(oa, w32);
+        zb[q] = eb; zb[q + 8] = cmul(ob, w32);
+    }
+    ctx.wave_sync();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { La.row[La.e2w + 17 * r] = za[r]; Lb.row[Lb.e2w + 17 * r] = zb[r]; }
+    ctx.wave_sync();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { za[r] = ctx.ld(La.row + La.e2r + r); zb[r] = ctx.ld(Lb.row + Lb.e2r + r); }
+    ctx.wave_sync();
+    fft16<false>(za);
+    fft16<false>(zb);
+    // tables: parts of G entries per pair, two parts per pair in flight
+    cf2 ta[2 * G], tb[2 * G];
+    load_tab_part_h<G>(p, pair, wave, lane, 0, ta);
+    load_tab_part_h<G>(p, pair + 1, wave, lane, 0, tb);
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) { La.row[La.col + 32 * kb] = za[kb]; Lb.row[Lb.col + 32 * kb] = zb[kb]; }
+    ctx.wave_sync();
+#pragma unroll
+    for (int part = 0; part < 16 / G; ++part) {
+        cf2 *ca = ta + G * (part & 1), *cb = tb + G * (part & 1);
+        if (part + 1 < 16 / G) {
+            load_tab_part_h<G>(p, pair, wave, lane, part + 1, ta + G * ((part + 1) & 1));
+            load_tab_part_h<G>(p, pair + 1, wave, lane, part + 1, tb + G * ((part + 1) & 1));
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int kb = G * part + i;
+            int idx = La.pidx - 32 * kb;
+            if (kb == 0) idx &= 511;                               // only (row 0, column 0) wraps: 512 -> 0
+            const cf pa = ctx.ld(La.prow + idx), pb = ctx.ld(Lb.prow + idx);
+            wacc[kb] = cfma(za[kb], ca[i].a, wacc[kb]);
+            wacc[kb] = cfmac(pa, ca[i].b, wacc[kb]);
+            wacc[kb] = cfma(zb[kb], cb[i].a, wacc[kb]);
+            wacc[kb] = cfmac(pb, cb[i].b, wacc[kb]);
+        }
+    }
+    ctx.wave_sync();    // partner reads done before this wave reuses its rows as scratch
+}
+
 // where a run's next block comes from (all wave-uniform)
 struct OlaCursor {
     long long id;          // first tile id of the launch order that no segment has claimed yet
@@ -275,12 +355,16 @@ AW_HD void tiles_fused_ola(Ctx &ctx, const TileParams &p, long long first, long 
             if constexpr (!kMid && OlaEarly<NP>::value && last_batch) load(nx, raw);        // every channel of this block has been through pass 1
             constexpr int kTabG = AW_OLA_TABG ? AW_OLA_TABG : NP >= 7 ? 8 : 16;
             constexpr bool kTabEarly = (AW_OLA_TAB_EARLY & 1) != 0 && NP <= 4 && kTabG == 16;
-            cf2 tab[16];
-            if constexpr (kTabEarly) load_tab_h(p, pair0, wave, lane, tab);
-            ola_subfft_cmac<kTabG, kTabEarly, kMid && last_batch && !two, CS, H>(ctx, p, pair0, buf0, twa, tab, lane, wave, wacc, nsrc, t, raw);
-            if constexpr (two) {
-                if constexpr (kTabEarly) load_tab_h(p, pair0 + 1, wave, lane, tab);
-                ola_subfft_cmac<kTabG, kTabEarly, kMid && last_batch, CS, H>(ctx, p, pair0 + 1, buf1, twa, tab, lane, wave, wacc, nsrc, t, raw);
+            if constexpr (AW_OLA_PAIR2 != 0 && two && NP <= AW_OLA_PAIR2_MAXNP) {
+                ola_subfft_cmac2<AW_OLA_PAIR2_G>(ctx, p, pair0, buf0, buf1, twa, lane, wave, wacc);
+            } else {
+                cf2 tab[16];
+                if constexpr (kTabEarly) load_tab_h(p, pair0, wave, lane, tab);
+                ola_subfft_cmac<kTabG, kTabEarly, kMid && last_batch && !two, CS, H>(ctx, p, pair0, buf0, twa, tab, lane, wave, wacc, nsrc, t, raw);
+                if constexpr (two) {
+                    if constexpr (kTabEarly) load_tab_h(p, pair0 + 1, wave, lane, tab);
+                    ola_subfft_cmac<kTabG, kTabEarly, kMid && last_batch, CS, H>(ctx, p, pair0 + 1, buf1, twa, tab, lane, wave, wacc, nsrc, t, raw);
+                }
             }
         });
 
