@@ -13,7 +13,7 @@
 #if defined(AW_ABL_NOLOAD) || defined(AW_ABL_NOTAB) || defined(AW_ABL_NOCMAC) || defined(AW_ABL_NOPARTNER) || defined(AW_ABL_NOSTORE) || \
     defined(AW_ABL_FWD_NOSTORE) || defined(AW_ABL2) || defined(AW_ABL_NOFFT) || defined(AW_ABL_NOBARRIER) || defined(AW_ABL_MARCH_NOSTORE) || \
     defined(AW_ABL_MARCH_NOLOAD) || defined(AW_LW_ABL_SPLIT_NOLOAD) || defined(AW_LW_ABL_SPLIT_NOSTORE) || defined(AW_LW_ABL_ROWS_NOLOAD) || \
-    defined(AW_LW_ABL_ROWS_NOTAB) || defined(AW_LW_ABL_ROWS_NOSTORE) || defined(AW_ABL_OLA_NOLOAD) || defined(AW_ABL_OLA_NOSTORE) || \
+    defined(AW_LW_ABL_ROWS_NOTAB) || defined(AW_LW_ABL_ROWS_NOSTORE) || defined(AW_ABL_OLA_NOLOAD) || defined(AW_ABL_OLA_NOSTORE) || defined(AW_ABL_OLA_NOPARTNER) || defined(AW_ABL_NOTWLDS) || defined(AW_ABL_NOXCHG) || \
     (defined(AW_EQ_ABL) && AW_EQ_ABL != 0)
 #error "timing-ablation macro in a product build: ablations give wrong results; build them with -DAW_ABLATION_BUILD=1 and a library suffix (airwave_amd/build.py)"
 #endif

@@ -146,15 +146,21 @@ AW_HD void ola_subfft_cmac(Ctx &ctx, const TileParams &p, int pair, cf *buf, con
     sub_fft512h_fwd(ctx, z, L);
     if constexpr (G == 16) { if constexpr (!TAB_EARLY) { load_tab_h(p, pair, wave, lane, tab); after(); } }
     else load_tab_part_h<G>(p, pair, wave, lane, 0, tab);
+#ifndef AW_ABL_OLA_NOPARTNER    // (timing ablation, wrong results: no publish of Z / no partner reads through LDS)
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) L.row[L.col + 32 * kb] = z[kb];
     ctx.wave_sync();
+#endif
     if constexpr (G == 16) {
 #pragma unroll
         for (int kb = 0; kb < 16; ++kb) {
             int idx = L.pidx - 32 * kb;
             if (kb == 0) idx &= 511;                               // only (row 0, column 0) wraps: 512 -> 0
+#ifdef AW_ABL_OLA_NOPARTNER
+            const cf zp = z[15 - kb];
+#else
             const cf zp = ctx.ld(L.prow + idx);
+#endif
             wacc[kb] = cfma(z[kb], tab[kb].a, wacc[kb]);
             wacc[kb] = cfmac(zp, tab[kb].b, wacc[kb]);
         }

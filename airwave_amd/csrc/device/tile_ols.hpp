@@ -247,6 +247,11 @@ template <class Ctx> AW_HD HLane hl_make(Ctx &ctx, cf *buf, const cf *twh, int l
 }
 // a[ka] *= w_512^{h ka} (INV: conjugate); the entries are requested eight at a time before their multiplies
 template <bool INV, class Ctx> AW_HD void hl_tw_apply(Ctx &ctx, cf (&a)[16], const HLane &L) {
+#ifdef AW_ABL_NOTWLDS          // timing ablation only (wrong results): row twiddles without their LDS table reads
+#pragma unroll
+    for (int m = 1; m < 16; ++m) a[m] = twmul<INV>(a[m], mk(L.w32.x + 0.001f * m, L.w32.y));
+    return;
+#endif
 #pragma unroll
     for (int m = 1; m < 16; m += 8) {
         cf w[8];
@@ -273,6 +278,7 @@ template <class Ctx> AW_HD void sub_fft512h_fwd(Ctx &ctx, cf (&a)[16], const HLa
         a[q + 8] = cmul(o, w32);
     }
     ctx.stamp(19);
+#ifndef AW_ABL_NOXCHG          // (timing ablation, wrong results: the 16 x 16 LDS transpose of the row transform removed)
     ctx.wave_sync();                         // the half-wave's loads of its row have returned
 #pragma unroll
     for (int r = 0; r < 16; ++r) L.row[L.e2w + 17 * r] = a[r];
@@ -280,6 +286,7 @@ template <class Ctx> AW_HD void sub_fft512h_fwd(Ctx &ctx, cf (&a)[16], const HLa
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = ctx.ld(L.row + L.e2r + r);
     ctx.wave_sync();
+#endif
     ctx.stamp(20);
     fft16<false>(a);
     ctx.stamp(21);
@@ -287,6 +294,7 @@ template <class Ctx> AW_HD void sub_fft512h_fwd(Ctx &ctx, cf (&a)[16], const HLa
 // inverse (unnormalised), the mirror image: a[kb] = X[col + 32 kb]  ->  a[j] = x[h + 32 j]
 template <class Ctx> AW_HD void sub_fft512h_inv(Ctx &ctx, cf (&a)[16], const HLane &L) {
     fft16<true>(a);
+#ifndef AW_ABL_NOXCHG
     ctx.wave_sync();
 #pragma unroll
     for (int r = 0; r < 16; ++r) L.row[L.e2r + r] = a[r];
@@ -294,6 +302,7 @@ template <class Ctx> AW_HD void sub_fft512h_inv(Ctx &ctx, cf (&a)[16], const HLa
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = ctx.ld(L.row + L.e2w + 17 * r);
     ctx.wave_sync();
+#endif
     const cf w32 = ctx.opaque(L.w32);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
