@@ -79,3 +79,24 @@ def test_default_line_with_driver_style_flags_carries_the_secondaries():
     assert d["roofline"]["traffic"] is not None or "profile" in d["roofline"]["traffic_note"], d["roofline"]
     full = json.load(open(os.path.join(ROOT, d["detail"])))
     assert full["secondary_cfg2"]["config"]["activation"] and full["roofline"]["frac_scope"]
+
+
+@pytest.mark.gpu
+def test_strong_scaling_and_equalizer_modes_run_on_the_gpu():
+    """`--scaling strong` on one GPU (the job total on rank 0, every rate bucket present) and cfg 4's two equalizer forms, small: the line
+    says which scaling / which form, the legs are the policy's kernels, parity spot checks hold."""
+    def run(*argv):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1 and len(lines[0]) < 8000
+        return json.loads(lines[0])
+    d = run("--scaling", "strong", "--workload", "cfg5", "--streams", "24", "--seconds", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert d["scaling"] == "strong" and d["config"]["streams_total"] == 24 and d["config"]["streams_this_rank"] == 24
+    assert [l["rate"] for l in d["config"]["legs"]] == [44100.0, 48000.0, 96000.0] and [l["streams"] for l in d["config"]["legs"]] == [8, 8, 8]
+    d = run("--workload", "cfg4", "--streams", "16", "--seconds", "2", "--steps", "2", "--warmup", "1", "--cpu-sample-streams", "2")
+    eq = d["config"]["equalizer"]
+    assert "folded" in eq["mode"] and 11000 < eq["response_taps"] < 13000 and eq["tail_bound"] <= 1e-7 and d["parity_spot_err"] < 1e-5
+    assert d["config"]["hrir_taps"] == 8640 + eq["response_taps"] - 1 and d["cpu_baseline"]["kind"] == "port"
+    d = run("--workload", "cfg4", "--eq", "cascade", "--streams", "16", "--seconds", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary")
+    assert "cascade" in d["config"]["equalizer"]["mode"] and d["config"]["hrir_taps"] == 8640 and "f64" in d["dtype"]
