@@ -33,6 +33,7 @@ SOURCES = [
     "device/ola_kernels_c.hip",
     "device/ola_kernels_d.hip",
     "device/ola_kernels_e.hip",
+    "device/ola_kernels_f.hip",
     "device/eq_kernels.hip",
     "device/probe_kernels.hip",
     "device/prep_kernels.hip",
@@ -54,7 +55,7 @@ EXTRA_FLAGS = {"device/march_kernels.hip": [] if os.environ.get("AW_MARCH_SLP") 
                "device/lw_split_d.hip": ["-fno-slp-vectorize"], "device/lw_split_e.hip": ["-fno-slp-vectorize"],
                # the overlap-add tile kernels: the same tile code, the same reason
                "device/ola_kernels.hip": ["-fno-slp-vectorize"], "device/ola_kernels_a.hip": ["-fno-slp-vectorize"], "device/ola_kernels_b.hip": ["-fno-slp-vectorize"],
-               "device/ola_kernels_c.hip": ["-fno-slp-vectorize"], "device/ola_kernels_d.hip": ["-fno-slp-vectorize"], "device/ola_kernels_e.hip": ["-fno-slp-vectorize"],
+               "device/ola_kernels_c.hip": ["-fno-slp-vectorize"], "device/ola_kernels_d.hip": ["-fno-slp-vectorize"], "device/ola_kernels_e.hip": ["-fno-slp-vectorize"], "device/ola_kernels_f.hip": ["-fno-slp-vectorize"],
                "device/kernels.hip": [] if os.environ.get("AW_KERNELS_SLP") else ["-fno-slp-vectorize"],
                # the even 16384-frame layouts kept SLP through round 3 (their 8 x 8 x 8 form measured faster with it); on the half-wave row
                # transform they do not: 4 / 6 / 8 channels 66.8 / 46.5 / 33.4 -> 68.8 / 52.9 / 35.4 G frames/s (tools/ols2_ab.py)

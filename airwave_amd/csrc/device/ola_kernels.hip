@@ -13,7 +13,7 @@ int fused_ola_rows(int n_channels, int taps) {
     if (H > 8) H = 8;
     if (H < 6) return 0;
     switch (n_channels) {
-        case 4: case 6: case 7: case 8: case 10: case 12: case 14: case 16: return H;
+        case 4: case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: return H;
         default: return 0;
     }
 }
@@ -30,6 +30,7 @@ hipError_t prepare_ola_kernels() {
     if (e == hipSuccess) e = prepare_ola_c();
     if (e == hipSuccess) e = prepare_ola_d();
     if (e == hipSuccess) e = prepare_ola_e();
+    if (e == hipSuccess) e = prepare_ola_f();
     return e;
 }
 
@@ -45,7 +46,7 @@ hipError_t launch_fused_ola(const TileParams &p, int H, int n_streams, hipStream
     const dim3 grid((unsigned)(n_tiles < wgs ? n_tiles : wgs));
     if (ev0) (void)hipEventRecord(ev0, stream);
     const bool ok = launch_ola_a(p, H, grid, n_tiles, stream) || launch_ola_b(p, H, grid, n_tiles, stream) || launch_ola_c(p, H, grid, n_tiles, stream) ||
-                    launch_ola_d(p, H, grid, n_tiles, stream) || launch_ola_e(p, H, grid, n_tiles, stream);
+                    launch_ola_d(p, H, grid, n_tiles, stream) || launch_ola_e(p, H, grid, n_tiles, stream) || launch_ola_f(p, H, grid, n_tiles, stream);
     if (ev1) (void)hipEventRecord(ev1, stream);
     return ok ? hipGetLastError() : hipErrorInvalidValue;
 }

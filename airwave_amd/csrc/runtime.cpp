@@ -470,6 +470,9 @@ static aw_status sp_alloc_hist(aw_spatializer *sp) {
 //   12 ch  3000: 36.7 / 36.4, 3585: 34.1 / 36.2, 4320: 29.8 / 32.9 / 25.7                             -> 0.80
 //   14 ch  3000: 29.7 / 27.5, 3585: 27.5 / 27.6, 4320: 23.5 / 27.7 / 23.8, 5121: 20.1 / 25.4 / 23.7   -> 0.89
 //   16 ch  2048: 24.1 / 24.5, 4320: 17.6 / 22.7 / 20.6, 5121: 14.9 / 21.3 / 20.4                      -> 0.66
+// odd wide layouts (profiles/round6_v5/ola_sweep_odd.txt): 9 ch 3000: 42.5 / 43.1, 4320: 33.9 / 38.8 / 31.6; 11 ch 4320: 29.3 / 33.4 / 28.1;
+//   13 ch 4320: 24.1 / 28.6 / 24.9 -> 0.78 each; 15 ch 2048: 24.6 / 26.7, 4320: 17.7 / 24.2 / 21.7 -> 0.62; 5 channels: the 16384-frame
+//   tile stays faster at every length (64.5 against 57.4 at 4320 taps): no kernel
 // (tools/ola_sweep.py regenerates the table).  AW_OLA=0 never, AW_OLA=1 wherever a kernel exists.
 static int ola_policy(int n_channels, int taps, int hist_len) {
     int mode = -1;
@@ -486,9 +489,13 @@ static int ola_policy(int n_channels, int taps, int hist_len) {
         case 6: need = 0.90; break;
         case 7: need = 0.875; break;
         case 8: need = 0.89; break;
+        case 9: need = 0.78; break;
         case 10: need = 0.74; break;
+        case 11: need = 0.78; break;
         case 12: need = 0.80; break;
+        case 13: need = 0.78; break;
         case 14: need = 0.89; break;
+        case 15: need = 0.62; break;
         default: need = 0.66; break;      // 16 channels
     }
     return 512.0 * H >= need * hop_ols ? H : 0;

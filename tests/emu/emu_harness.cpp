@@ -194,7 +194,7 @@ int emu_fused_ola(const float *in, float *out, const float *hist, const float *t
                 EmuCtx ctx{t, &sh};
 #define AW_OLA_CASE(CS, HH) if (n_channels == CS && H == HH) { tiles_fused_ola<EmuCtx, CS, (CS + 1) / 2, HH>(ctx, p, first, end); return; }
                 AW_OLA_CASE(2, 7) AW_OLA_CASE(2, 8) AW_OLA_CASE(7, 7) AW_OLA_CASE(7, 8) AW_OLA_CASE(8, 7) AW_OLA_CASE(8, 8) AW_OLA_CASE(8, 5)
-                AW_OLA_CASE(14, 7) AW_OLA_CASE(14, 8) AW_OLA_CASE(14, 6) AW_OLA_CASE(16, 7) AW_OLA_CASE(5, 4) AW_OLA_CASE(12, 7) AW_OLA_CASE(6, 7)
+                AW_OLA_CASE(14, 7) AW_OLA_CASE(14, 8) AW_OLA_CASE(14, 6) AW_OLA_CASE(16, 7) AW_OLA_CASE(5, 4) AW_OLA_CASE(12, 7) AW_OLA_CASE(6, 7) AW_OLA_CASE(13, 7) AW_OLA_CASE(9, 8)
 #undef AW_OLA_CASE
                 if (t == 0) rc = -2;
             });

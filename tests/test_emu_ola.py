@@ -22,7 +22,7 @@ def _room_map(oracle, golden_dir, channels):
     return wav.audio_data, lt, rt
 
 
-@pytest.mark.parametrize("channels,workgroups", [(8, 3), (14, 2), (7, 4), (2, 1), (16, 2), (12, 5), (6, 3)])
+@pytest.mark.parametrize("channels,workgroups", [(8, 3), (14, 2), (7, 4), (2, 1), (16, 2), (12, 5), (6, 3), (13, 3)])
 def test_emulated_overlap_add_tile_matches_truth(oracle, golden_dir, channels, workgroups):
     """4320 taps -> blocks of 7 x 512 frames.  16 500 frames = 5 blocks per stream (the last one ragged); the runs cut streams in the
     middle (carry rebuilt from two warm-up blocks), start at stream starts (warm-up blocks in the zero history) and cross stream ends."""
@@ -43,7 +43,7 @@ def test_emulated_overlap_add_result_does_not_depend_on_the_run_cut(oracle, gold
     assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("channels,taps,H", [(8, 3969, 8), (14, 4000, 8), (8, 5500, 5), (14, 5000, 6), (5, 6100, 4), (7, 4609, 7), (2, 300, 8)])
+@pytest.mark.parametrize("channels,taps,H", [(8, 3969, 8), (14, 4000, 8), (8, 5500, 5), (14, 5000, 6), (5, 6100, 4), (7, 4609, 7), (2, 300, 8), (9, 3969, 8)])
 def test_emulated_overlap_add_block_lengths(oracle, channels, taps, H):
     """Every block length the library carries (H = 5 .. 8 rows of 512 frames) and the shortest the tile supports (4), at the longest
     HRIR each one holds or near it; a short HRIR on the longest block."""

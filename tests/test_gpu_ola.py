@@ -28,7 +28,7 @@ def _maps(channels):
     return (np.arange(channels) % 14).astype(np.int32), ((np.arange(channels) * 3 + 7) % 14).astype(np.int32)
 
 
-@pytest.mark.parametrize("channels", [4, 6, 7, 8, 10, 12, 14, 16])
+@pytest.mark.parametrize("channels", [4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
 def test_every_layout_of_the_overlap_add_tile_matches_truth_and_port(aw, oracle, golden_dir, forced, channels):
     """RoomSH1.0 (4320 taps: blocks of 7 x 512 frames), 5 streams of 30 001 frames: 9 blocks per stream, the last one ragged; 45 blocks on
     45 workgroups, so every run starts inside a stream or at its start and rebuilds its carry."""
@@ -47,10 +47,10 @@ def test_every_layout_of_the_overlap_add_tile_matches_truth_and_port(aw, oracle,
 
 
 @pytest.mark.parametrize("channels,taps,rows", [(8, 3969, 8), (14, 3969, 8), (7, 4097, 8), (8, 4098, 7), (14, 4609, 7), (8, 4610, 6), (14, 5121, 6),
-                                                (4, 5122, 0), (16, 5633, 0), (12, 2000, 8), (9, 4320, 0), (2, 4320, 0)])
+                                                (4, 5122, 0), (16, 5633, 0), (12, 2000, 8), (9, 4320, 7), (13, 3969, 8), (15, 5121, 6), (5, 4098, 0), (3, 4320, 0), (2, 4320, 0)])
 def test_block_length_follows_the_hrir_length(aw, oracle, forced, channels, taps, rows):
     """H = 8 rows of 512 frames up to 4097 taps, 7 up to 4609, 6 up to 5121; longer HRIRs and layouts without a kernel
-    (odd wide layouts, stereo: its 16384-frame tile is faster) stay on the overlap-save tiles.  Each at the edge of its range."""
+    (mono, stereo, 3 and 5 channels: their 16384-frame tiles are faster) stay on the overlap-save tiles.  Each at the edge of its range."""
     h = oracle.synth_hrir(14, taps, seed=taps)
     lt, rt = _maps(channels)
     sp = aw.Spatializer(aw.HRIR(h, ctx=forced), lt, rt, n_streams=2, ctx=forced)

@@ -54,7 +54,7 @@ while time.time() < t_end:
         if rng.random() < 0.7: env["AW_OLA"] = "1"
         if rng.random() < 0.5: env["AW_PERSISTENT_WGS"] = str(int(rng.choice([8, 9, 31, 100, 256])))
         if rng.random() < 0.7:
-            C = int(rng.choice([4, 6, 7, 8, 10, 12, 14, 16]))
+            C = int(rng.choice([4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]))
             taps = int(rng.choice([3585, 3969, 4097, 4098, 4320, 4609, 4610, 5000, 5121, 5122, int(rng.integers(2, 5200))]))
             env.pop("AW_WINDOW", None)
             if env.get("AW_LW") not in (None, "0") and rng.random() < 0.7: env.pop("AW_LW")
